@@ -1,0 +1,178 @@
+/*
+ * ggs_hip.h -- C-ABI of libggs_hip.so, the MI355X (gfx950) implementation of
+ * the LDA Grouped Gibbs Sampler hot path.
+ *
+ * The reference (clintpgeorge/LDAGroupedGibbsSampler) is 100 % Java and has no
+ * FFI; this header is the boundary a thin JNI shim binds (INTEGRATION.md shows
+ * the shim).  Every entry point names the reference method(s) whose work it
+ * replaces; paths are relative to src/main/java/cc/mallet/ in the reference:
+ *   GGS   = topics/LDAGroupedGibbsSampler.java
+ *   UPLDA = topics/UncollapsedParallelLDA.java
+ *   MSLDA = topics/ModifiedSimpleLDA.java
+ *
+ * Conventions: plain pointers and sizes only; every function returns
+ * GGS_OK (0) or a GGS_ERR_* code, with text available from ggs_last_error();
+ * the caller owns every host buffer, which is only touched during the call; a
+ * handle is driven by ONE coordinator thread (as the Java sampler is,
+ * UPLDA:552-943).  Host layouts mirror the Java getters: counts are
+ * int32 [V][K] (getTypeTopicMatrix), Phi is double [K][V] (getPhi).
+ */
+#ifndef GGS_HIP_H
+#define GGS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GGS_ABI_VERSION 1
+
+typedef struct ggs_handle ggs_handle;
+
+enum {
+  GGS_OK = 0,
+  GGS_ERR_NEGATIVE_COUNT = 1, /* IllegalStateException "Invalid count!" GGS:84-85; UPLDA:475-481 */
+  GGS_ERR_INVALID_TOPIC = 2,  /* IllegalStateException "Topic sampled is invalid!" GGS:116-118    */
+  GGS_ERR_RNG_EXHAUSTED = 3,  /* a rejection loop used more than GGS_MAX_BLOCKS Philox blocks      */
+  GGS_ERR_BAD_ARG = 4,        /* IllegalArgumentException (e.g. ParallelRandoms.java:61-63)        */
+  GGS_ERR_HIP = 5,            /* a HIP runtime call failed; text has the hipError string           */
+  GGS_ERR_STATE = 6,          /* call order violated (e.g. sweep before set_corpus)                */
+  GGS_ERR_UNSUPPORTED = 7,
+  GGS_ERR_INVARIANT = 8       /* paranoid check failed (UPLDA:299-338)                             */
+};
+
+enum {
+  GGS_FLAG_PARANOID = 1 << 0,     /* run ggs_check_invariants after every sweep
+                                     (ParanoidUncollapsedParallelLDA.java:14-55)   */
+  GGS_FLAG_SAVE_PHI_MEAN = 1 << 1 /* cfg key save_phi_mean, UPLDA:205,1331-1335    */
+};
+
+/* RNG stream addressing.  The reference draws from ThreadLocalRandom and a
+ * nanoTime-seeded xorshift (GGS:107, util/XORShiftRandom.java:7) and is not
+ * reproducible; this library defines a counter-based stream instead:
+ * Philox4x32-10, key = (seed lo, seed hi),
+ * counter = (elem lo, elem hi, purpose << 24 | block, iteration). */
+enum {
+  GGS_PURPOSE_Z = 1,       /* elem = global token index          */
+  GGS_PURPOSE_THETA = 2,   /* elem = global doc index * K + k    */
+  GGS_PURPOSE_PHI = 3,     /* elem = k * V + v                   */
+  GGS_PURPOSE_INIT_PHI = 4 /* elem = k * V + v                   */
+};
+#define GGS_MAX_BLOCKS 4096
+
+typedef struct ggs_config {
+  int32_t struct_size;    /* = sizeof(ggs_config), for ABI growth                              */
+  int32_t num_topics;     /* cfg key "topics"; MSLDA:126-127                                   */
+  int32_t num_types;      /* alphabet size V; UPLDA:361                                        */
+  int32_t device_id;      /* HIP device ordinal this handle lives on                           */
+  const double *alpha;    /* K values, or NULL to use alpha_scalar for every topic (MSLDA:129-135) */
+  double alpha_scalar;    /* cfg key "alpha"                                                   */
+  double beta;            /* cfg key "beta"; MSLDA:136                                         */
+  uint64_t seed;          /* key of the Philox streams                                         */
+  int32_t flags;          /* GGS_FLAG_*                                                        */
+  int32_t phi_burn_in;    /* iterations: (phi_mean_burnin/100)*iterations, UPLDA:206-207       */
+  int32_t phi_mean_thin;  /* cfg key phi_mean_thin, UPLDA:208                                  */
+  int32_t reserved;
+} ggs_config;
+
+typedef struct ggs_timings {
+  double theta_ms;  /* cumulative: per-document theta draw (GGS:57-72)                         */
+  double z_ms;      /* cumulative: token loop (GGS:79-130)                                     */
+  double merge_ms;  /* cumulative: updateCounts (UPLDA:1107-1221)                              */
+  double phi_ms;    /* cumulative: samplePhi (GGS:139-198)                                     */
+  int64_t sweeps;
+  int64_t tokens_sampled;
+} ggs_timings;
+
+/* ---- lifecycle ------------------------------------------------------------ */
+/* replaces: new LDAGroupedGibbsSampler(config) (GGS:25-27, UPLDA ctor :134-215) */
+int ggs_create(const ggs_config *cfg, ggs_handle **out);
+void ggs_destroy(ggs_handle *h);
+const char *ggs_last_error(const ggs_handle *h);
+int ggs_abi_version(void);
+/* Run every kernel on this hipStream_t (NULL = the legacy default stream). */
+int ggs_set_stream(ggs_handle *h, void *hip_stream);
+
+/* ---- corpus and initial state --------------------------------------------- */
+/* replaces: the data part of addInstances (UPLDA:357-456, GGS:33-37): CSR of
+ * FeatureSequence.getFeatures() in instance order.  doc_base / tok_base are the
+ * global indices of this shard's first document / token (0 for one GPU); they
+ * only enter the RNG element ids, so a doc-sharded run draws exactly what a
+ * one-GPU run draws. */
+int ggs_set_corpus(ggs_handle *h, int64_t num_docs, const int64_t *doc_ptr /*D+1*/,
+                   const int32_t *tokens /*N*/, int64_t doc_base, int64_t tok_base);
+/* replaces: initialDrawTopicIndicator loop (UPLDA:398-406,458-460): z0 =
+ * java.util.Random(seed).nextInt(K) in (doc, position) order, counts rebuilt.
+ * Sequential stream => only valid on an unsharded corpus (tok_base == 0). */
+int ggs_init_z_java_lcg(ggs_handle *h, int32_t seed);
+/* Host utility: the first n values of java.util.Random(seed).nextInt(bound) -- what a
+ * doc-sharded start-up slices per rank before ggs_set_z (the stream is sequential). */
+int ggs_java_lcg_next_ints(int32_t seed, int32_t bound, int64_t n, int32_t *out);
+/* replaces: setZIndicators (UPLDA:1797-1843): rebuild counts from z, zero the
+ * deltas and (redraw_phi != 0) re-draw Phi as initialSamplePhi does. */
+int ggs_set_z(ggs_handle *h, const int32_t *z /*N*/, int32_t redraw_phi);
+/* replaces: initialSamplePhi (UPLDA:1287-1294 -> MarsagliaSparseDirichlet.java:31-55) */
+int ggs_init_phi(ggs_handle *h);
+/* currentIteration (UPLDA:646); enters the RNG counters */
+int ggs_set_iteration(ggs_handle *h, int32_t iteration);
+int ggs_get_iteration(const ggs_handle *h, int32_t *iteration);
+
+/* ---- the sweep ------------------------------------------------------------- */
+/* replaces one loop body of sample() (UPLDA:645-687) n_sweeps times:
+ * loopOverBatches (GGS:47-132 for every document), updateCounts, samplePhi.
+ * Returns after the device is idle.  n_sweeps = 1 keeps the Java per-iteration
+ * abort / exec_time / diagnostics loop in the caller. */
+int ggs_sweep(ggs_handle *h, int32_t n_sweeps);
+/* The same, split where a doc-sharded run exchanges counts:
+ *   begin = ++iteration, theta draw + z draw -> deltas (UPLDA:660)
+ *   [caller sum-all-reduces the delta buffer across shards]
+ *   end   = updateCounts + samplePhi (UPLDA:664-687) */
+int ggs_sweep_begin(ggs_handle *h);
+int ggs_sweep_end(ggs_handle *h);
+/* replaces: sampleZGivenPhi (UPLDA:975-1014): z step + updateCounts, Phi kept */
+int ggs_sample_z_given_phi(ggs_handle *h, int32_t n_sweeps);
+/* Device pointer / element count of the int32 [V][K] delta buffer
+ * (batchLocalTopicTypeUpdates, UPLDA:102, transposed) for an in-place RCCL
+ * all-reduce by the caller; or let the caller supply the buffer. */
+int ggs_delta_device_ptr(ggs_handle *h, void **dev_ptr, int64_t *num_elems);
+int ggs_use_external_delta(ggs_handle *h, void *dev_ptr /* V*K int32, zeroed */);
+/* Device pointer of the int32 [V][K] type-topic counts (typeTopicCounts, MSLDA:73):
+ * a doc-sharded start-up sum-all-reduces it once after ggs_set_z(h, z, 0) and
+ * before ggs_init_phi, so every shard holds the corpus-wide counts. */
+int ggs_counts_device_ptr(ggs_handle *h, void **dev_ptr, int64_t *num_elems);
+/* Corpus-wide token count (all shards); what ggs_check_invariants expects the
+ * counts to sum to.  Defaults to this handle's own token count. */
+int ggs_set_global_token_count(ggs_handle *h, int64_t n_tokens);
+int ggs_get_delta(ggs_handle *h, int32_t *delta /*[V][K]*/);
+int ggs_set_delta(ggs_handle *h, const int32_t *delta /*[V][K]*/);
+/* Block until everything queued on the handle's stream has finished; surfaces
+ * device-side error flags (what Java throws from the worker threads). */
+int ggs_synchronize(ggs_handle *h);
+
+/* ---- state copy-back (the Java getters) ------------------------------------ */
+int ggs_get_z(ggs_handle *h, int32_t *z /*N*/);                         /* getZIndicators, MSLDA:464-477 */
+int ggs_get_type_topic_counts(ggs_handle *h, int32_t *n_wk /*[V][K]*/); /* getTypeTopicMatrix, UPLDA:226-234 */
+int ggs_get_topic_totals(ggs_handle *h, int32_t *n_k /*K*/);            /* getTopicTotals, MSLDA:976 */
+int ggs_get_phi(ggs_handle *h, double *phi /*[K][V]*/);                 /* getPhi, UPLDA:1946-1948 */
+int ggs_set_phi(ggs_handle *h, const double *phi /*[K][V]*/);           /* setPhi, UPLDA:1897-1926 */
+int ggs_get_phi_mean(ggs_handle *h, double *phi_mean /*[K][V]*/, int32_t *n_sampled); /* getPhiMeans, UPLDA:1954-1966 */
+int ggs_get_theta(ggs_handle *h, int64_t doc_begin, int64_t doc_end, double *theta /*[(end-begin)][K]*/); /* thetaMatrix, GGS:72, UPLDA:716-720 */
+int ggs_get_doc_topic_counts(ggs_handle *h, int64_t doc_begin, int64_t doc_end, int32_t *n_dk); /* getDocumentTopicMatrix, MSLDA:536-547 */
+int ggs_get_timings(ggs_handle *h, ggs_timings *out);                   /* zSamplingTimeCum / phiSamplingTimeCum, UPLDA:642-693 */
+int ggs_reset_timings(ggs_handle *h);
+/* replaces: ensureConsistentTopicTypeCounts (UPLDA:299-338) + the "all deltas
+ * zero at postSample" assert (ParanoidUncollapsedParallelLDA.java:42-55). */
+int ggs_check_invariants(ggs_handle *h);
+/* Launch geometry of the z kernel, for bench.py's roofline accounting. */
+int ggs_get_launch_info(ggs_handle *h, int64_t *num_chunks, int32_t *lds_bytes_z, int32_t *docs_per_block_theta);
+/* ---- primitives, exported so the parity tests can pin each layer ----------- */
+int ggs_debug_philox(int32_t device_id, int64_t n, const uint32_t *ctr /*n*4*/, const uint32_t *key /*n*2*/, uint32_t *out /*n*4*/);
+int ggs_debug_math(int32_t device_id, int32_t op /*0 log,1 pow,2 sqrt,3 div*/, int64_t n, const double *x, const double *y, double *out);
+int ggs_debug_draw(int32_t device_id, int32_t kind /*0 uniform,1 gaussian,2 gamma*/, uint64_t seed, uint32_t iteration,
+                   uint32_t purpose, uint64_t elem0, int64_t n, const double *shape, double *out, int32_t *status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GGS_HIP_H */

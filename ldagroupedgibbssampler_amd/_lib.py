@@ -1,0 +1,130 @@
+"""Loader of libggs_hip.so (the C-ABI declared in include/ggs_hip.h).
+
+There is no CPU fallback: if the shared library is missing or does not load, the
+import of anything that needs it raises.  ``build()`` compiles it in-tree with
+hipcc for gfx950 (works without a GPU; the .so then travels to the GPU box).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libggs_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ggs_hip.h")
+
+ABI_VERSION = 1
+
+
+class GGSConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("num_topics", C.c_int32),
+        ("num_types", C.c_int32),
+        ("device_id", C.c_int32),
+        ("alpha", C.POINTER(C.c_double)),
+        ("alpha_scalar", C.c_double),
+        ("beta", C.c_double),
+        ("seed", C.c_uint64),
+        ("flags", C.c_int32),
+        ("phi_burn_in", C.c_int32),
+        ("phi_mean_thin", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class GGSTimings(C.Structure):
+    _fields_ = [
+        ("theta_ms", C.c_double),
+        ("z_ms", C.c_double),
+        ("merge_ms", C.c_double),
+        ("phi_ms", C.c_double),
+        ("sweeps", C.c_int64),
+        ("tokens_sampled", C.c_int64),
+    ]
+
+
+_vp = C.c_void_p
+_dp = C.POINTER(C.c_double)
+_ip = C.POINTER(C.c_int32)
+_lp = C.POINTER(C.c_int64)
+_up = C.POINTER(C.c_uint32)
+
+# name -> (restype, argtypes); must list every symbol include/ggs_hip.h declares
+# (tests/test_abi_symbols.py checks the two against each other).
+SIGNATURES = {
+    "ggs_create": (C.c_int, [C.POINTER(GGSConfig), C.POINTER(_vp)]),
+    "ggs_destroy": (None, [_vp]),
+    "ggs_last_error": (C.c_char_p, [_vp]),
+    "ggs_abi_version": (C.c_int, []),
+    "ggs_set_stream": (C.c_int, [_vp, _vp]),
+    "ggs_set_corpus": (C.c_int, [_vp, C.c_int64, _lp, _ip, C.c_int64, C.c_int64]),
+    "ggs_init_z_java_lcg": (C.c_int, [_vp, C.c_int32]),
+    "ggs_java_lcg_next_ints": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _ip]),
+    "ggs_set_z": (C.c_int, [_vp, _ip, C.c_int32]),
+    "ggs_init_phi": (C.c_int, [_vp]),
+    "ggs_set_iteration": (C.c_int, [_vp, C.c_int32]),
+    "ggs_get_iteration": (C.c_int, [_vp, _ip]),
+    "ggs_sweep": (C.c_int, [_vp, C.c_int32]),
+    "ggs_sweep_begin": (C.c_int, [_vp]),
+    "ggs_sweep_end": (C.c_int, [_vp]),
+    "ggs_sample_z_given_phi": (C.c_int, [_vp, C.c_int32]),
+    "ggs_delta_device_ptr": (C.c_int, [_vp, C.POINTER(_vp), _lp]),
+    "ggs_use_external_delta": (C.c_int, [_vp, _vp]),
+    "ggs_counts_device_ptr": (C.c_int, [_vp, C.POINTER(_vp), _lp]),
+    "ggs_set_global_token_count": (C.c_int, [_vp, C.c_int64]),
+    "ggs_get_delta": (C.c_int, [_vp, _ip]),
+    "ggs_set_delta": (C.c_int, [_vp, _ip]),
+    "ggs_synchronize": (C.c_int, [_vp]),
+    "ggs_get_z": (C.c_int, [_vp, _ip]),
+    "ggs_get_type_topic_counts": (C.c_int, [_vp, _ip]),
+    "ggs_get_topic_totals": (C.c_int, [_vp, _ip]),
+    "ggs_get_phi": (C.c_int, [_vp, _dp]),
+    "ggs_set_phi": (C.c_int, [_vp, _dp]),
+    "ggs_get_phi_mean": (C.c_int, [_vp, _dp, _ip]),
+    "ggs_get_theta": (C.c_int, [_vp, C.c_int64, C.c_int64, _dp]),
+    "ggs_get_doc_topic_counts": (C.c_int, [_vp, C.c_int64, C.c_int64, _ip]),
+    "ggs_get_timings": (C.c_int, [_vp, C.POINTER(GGSTimings)]),
+    "ggs_reset_timings": (C.c_int, [_vp]),
+    "ggs_check_invariants": (C.c_int, [_vp]),
+    "ggs_get_launch_info": (C.c_int, [_vp, _lp, _ip, _ip]),
+    "ggs_debug_philox": (C.c_int, [C.c_int32, C.c_int64, _up, _up, _up]),
+    "ggs_debug_math": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _dp, _dp, _dp]),
+    "ggs_debug_draw": (C.c_int, [C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int64,
+                                 _dp, _dp, _ip]),
+}
+
+
+def build(force=False):
+    """Compile libggs_hip.so in-tree (hipcc --offload-arch=gfx950)."""
+    srcs = [os.path.join(CSRC, f) for f in ("ggs_api.hip", "ggs_kernels.hpp", "ggs_device_math.hpp")] + [HEADER_PATH]
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
+        return LIB_PATH
+    subprocess.check_call(["make", "-C", CSRC, "libggs_hip.so"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """dlopen libggs_hip.so and type every entry point.  Raises if it is absent:
+    the product has no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libggs_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(needs hipcc); there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    got = L.ggs_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError("libggs_hip.so ABI version %d, expected %d" % (got, ABI_VERSION))
+    _lib = L
+    return L

@@ -1,0 +1,678 @@
+// ggs_api.hip -- host side of libggs_hip.so: handle, launches, C-ABI (include/ggs_hip.h).
+//
+// Build (see build.py): hipcc -O3 --offload-arch=gfx950 -ffp-contract=off -fPIC -shared
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ggs_kernels.hpp"
+
+using namespace ggs;
+
+namespace {
+
+constexpr int kThetaBlock = 256;
+constexpr int kMaxLdsBytes = 160 * 1024;
+
+struct Events {
+  hipEvent_t e[6];
+  bool ok = false;
+};
+
+}  // namespace
+
+struct ggs_handle {
+  int32_t K = 0, V = 0, Kp = 0, pitch16 = 0, device = 0;
+  double beta = 0;
+  std::vector<double> alpha;
+  uint64_t seed = 0;
+  int32_t flags = 0, phi_burn_in = 0, phi_thin = 1;
+  int32_t iteration = 0;
+  int32_t n_sampled_phi = 0;
+
+  int64_t D = 0, N = 0, C = 0, doc_base = 0, tok_base = 0, global_tokens = -1;
+  bool have_corpus = false, have_phi = false, in_sweep = false;
+  int32_t theta_docs_per_block = 0, theta_lds = 0, z_lds = 0;
+
+  hipStream_t stream = nullptr;
+  // device buffers
+  int64_t *d_doc_ptr = nullptr, *d_chunk_start = nullptr;
+  int32_t *d_tok = nullptr, *d_z = nullptr, *d_chunk_doc = nullptr, *d_chunk_len = nullptr;
+  double *d_alpha = nullptr, *d_theta = nullptr, *d_phiT = nullptr, *d_mag = nullptr, *d_tot = nullptr, *d_phi_mean = nullptr;
+  int32_t *d_n_wk = nullptr, *d_delta = nullptr, *d_n_k = nullptr;
+  bool delta_external = false;
+  uint32_t *d_status = nullptr;
+  void *d_scratch = nullptr;
+  size_t scratch_bytes = 0;
+
+  Events ev;
+  ggs_timings tm{};
+  std::string err;
+};
+
+namespace {
+
+int set_err(ggs_handle *h, int code, const std::string &msg) {
+  if (h) h->err = msg;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                        \
+  do {                                                                                          \
+    hipError_t _e = (expr);                                                                     \
+    if (_e != hipSuccess)                                                                       \
+      return set_err((h), GGS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+  } while (0)
+
+int bind_device(ggs_handle *h) {
+  HIP_TRY(h, hipSetDevice(h->device));
+  return GGS_OK;
+}
+
+template <typename T>
+int dev_alloc(ggs_handle *h, T **p, size_t count) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  HIP_TRY(h, hipMalloc(reinterpret_cast<void **>(p), std::max<size_t>(count, 1) * sizeof(T)));
+  return GGS_OK;
+}
+
+int ensure_scratch(ggs_handle *h, size_t bytes) {
+  if (h->scratch_bytes >= bytes) return GGS_OK;
+  if (h->d_scratch) (void)hipFree(h->d_scratch);
+  h->d_scratch = nullptr; h->scratch_bytes = 0;
+  HIP_TRY(h, hipMalloc(&h->d_scratch, bytes));
+  h->scratch_bytes = bytes;
+  return GGS_OK;
+}
+
+int grid_for(int64_t n, int block, int per_thread = 1) {
+  const int64_t want = (n + (int64_t)block * per_thread - 1) / ((int64_t)block * per_thread);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(want, 256 * 8));  // grid-stride above ~8 blocks/CU
+}
+
+// Surfaces what the Java code throws from its worker threads.
+int check_status(ggs_handle *h) {
+  uint32_t st = 0;
+  HIP_TRY(h, hipMemcpyAsync(&st, h->d_status, sizeof st, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (!st) return GGS_OK;
+  HIP_TRY(h, hipMemsetAsync(h->d_status, 0, sizeof(uint32_t), h->stream));
+  if (st & ST_INVALID_TOPIC) return set_err(h, GGS_ERR_INVALID_TOPIC, "LDAGroupedGibbsSampler: Topic sampled is invalid!");
+  if (st & ST_NEGATIVE_COUNT) return set_err(h, GGS_ERR_NEGATIVE_COUNT, "Negative count for topic (Invalid count!)");
+  if (st & ST_BAD_SHAPE) return set_err(h, GGS_ERR_BAD_ARG, "alpha and beta must be strictly positive (gamma shape <= 0)");
+  return set_err(h, GGS_ERR_RNG_EXHAUSTED, "a gamma rejection loop exceeded GGS_MAX_BLOCKS Philox blocks");
+}
+
+int launch_count_rebuild(ggs_handle *h) {
+  const size_t kv = (size_t)h->K * h->V;
+  HIP_TRY(h, hipMemsetAsync(h->d_n_wk, 0, kv * sizeof(int32_t), h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->d_delta, 0, kv * sizeof(int32_t), h->stream));
+  if (h->N > 0)
+    hipLaunchKernelGGL(count_kernel, dim3(grid_for(h->N, 256)), dim3(256), 0, h->stream, h->d_tok, h->d_z, h->N, h->K, h->d_n_wk);
+  HIP_TRY(h, hipGetLastError());
+  return GGS_OK;
+}
+
+// Phi draw: initial (K8) or per sweep (K6).  Always refreshes n_k.
+int launch_phi(ggs_handle *h, bool initial, bool accumulate_mean) {
+  const int K = h->K, V = h->V;
+  hipLaunchKernelGGL(phi_magnitude_kernel, dim3((K + 63) / 64), dim3(64), 0, h->stream, h->d_n_wk, K, V, h->beta, h->d_mag, h->d_n_k);
+  PhiGammaParams gp{};
+  gp.n_wk = h->d_n_wk; gp.mag = h->d_mag; gp.phiT = h->d_phiT; gp.status = h->d_status;
+  gp.seed = h->seed; gp.iteration = (uint32_t)h->iteration;
+  gp.purpose = initial ? GGS_PURPOSE_INIT_PHI : GGS_PURPOSE_PHI;
+  gp.K = K; gp.Kp = h->Kp; gp.V = V; gp.beta = h->beta;
+  // Dirichlet(int size, double beta): magnitude = V*beta, partition = 1.0/V
+  gp.prior_pm = (1.0 / (double)V) * ((double)V * h->beta);
+  gp.initial = initial ? 1 : 0;
+  const int64_t kv = (int64_t)K * V;
+  hipLaunchKernelGGL(phi_gamma_kernel, dim3(grid_for(kv, 256, 2)), dim3(256), 0, h->stream, gp);
+  hipLaunchKernelGGL(phi_total_kernel, dim3((K + 63) / 64), dim3(64), 0, h->stream, h->d_phiT, K, h->Kp, V, h->d_tot);
+  hipLaunchKernelGGL(phi_normalise_kernel, dim3(grid_for(kv, 256, 2)), dim3(256), 0, h->stream, h->d_phiT, h->d_tot, K, h->Kp, V,
+                     accumulate_mean ? h->d_phi_mean : nullptr);
+  HIP_TRY(h, hipGetLastError());
+  h->have_phi = true;
+  return GGS_OK;
+}
+
+int launch_theta(ggs_handle *h) {
+  if (h->D == 0) return GGS_OK;
+  ThetaParams tp{};
+  tp.doc_ptr = h->d_doc_ptr; tp.z = h->d_z; tp.alpha = h->d_alpha; tp.theta = h->d_theta; tp.status = h->d_status;
+  tp.num_docs = h->D; tp.doc_base = h->doc_base; tp.seed = h->seed; tp.iteration = (uint32_t)h->iteration;
+  tp.K = h->K; tp.docs_per_block = h->theta_docs_per_block;
+  const int64_t grid = (h->D + h->theta_docs_per_block - 1) / h->theta_docs_per_block;
+  hipLaunchKernelGGL(theta_kernel<kThetaBlock>, dim3((unsigned)grid), dim3(kThetaBlock), h->theta_lds, h->stream, tp);
+  HIP_TRY(h, hipGetLastError());
+  return GGS_OK;
+}
+
+int launch_z(ggs_handle *h) {
+  if (h->C == 0) return GGS_OK;
+  ZParams zp{};
+  zp.tok = h->d_tok; zp.z = h->d_z; zp.chunk_start = h->d_chunk_start; zp.chunk_doc = h->d_chunk_doc; zp.chunk_len = h->d_chunk_len;
+  zp.theta = h->d_theta; zp.phiT = h->d_phiT; zp.delta = h->d_delta; zp.status = h->d_status;
+  zp.tok_base = h->tok_base; zp.seed = h->seed; zp.iteration = (uint32_t)h->iteration;
+  zp.K = h->K; zp.Kp = h->Kp; zp.pitch16 = h->pitch16;
+  hipLaunchKernelGGL(z_kernel, dim3((unsigned)h->C), dim3(64), h->z_lds, h->stream, zp);
+  HIP_TRY(h, hipGetLastError());
+  return GGS_OK;
+}
+
+int launch_merge(ggs_handle *h) {
+  const int64_t kv = (int64_t)h->K * h->V;
+  hipLaunchKernelGGL(merge_kernel, dim3(grid_for(kv, 256, 4)), dim3(256), 0, h->stream, h->d_n_wk, h->d_delta, kv, h->d_status);
+  HIP_TRY(h, hipGetLastError());
+  return GGS_OK;
+}
+
+bool sample_phi_this_iteration(const ggs_handle *h) {  // UPLDA:1350-1352
+  return h->phi_burn_in > 0 && h->iteration > h->phi_burn_in && (h->iteration % h->phi_thin) == 0;
+}
+
+// java.util.Random(seed).nextInt(bound), n times (JDK 8 javadoc algorithm: 48-bit LCG,
+// next(31), power-of-two shortcut, modulo rejection loop otherwise).
+void java_lcg_next_ints(int32_t seed, int32_t bound, int64_t n, int32_t *out) {
+  constexpr uint64_t kMult = 0x5DEECE66DULL, kMask = (1ULL << 48) - 1;
+  uint64_t s = ((uint64_t)(int64_t)seed ^ kMult) & kMask;
+  auto next31 = [&]() { s = (s * kMult + 0xBULL) & kMask; return (int32_t)(s >> 17); };
+  const int32_t m = bound - 1;
+  for (int64_t i = 0; i < n; ++i) {
+    int32_t r = next31();
+    if ((bound & m) == 0) r = (int32_t)(((int64_t)bound * (int64_t)r) >> 31);
+    else
+      for (int32_t u = r;; u = next31()) {
+        r = u % bound;
+        if ((int32_t)((uint32_t)u - (uint32_t)r + (uint32_t)m) >= 0) break;
+      }
+    out[i] = r;
+  }
+}
+
+int require_ready(ggs_handle *h, bool need_phi) {
+  if (!h) return GGS_ERR_BAD_ARG;
+  if (!h->have_corpus) return set_err(h, GGS_ERR_STATE, "no corpus: call ggs_set_corpus first");
+  if (need_phi && !h->have_phi) return set_err(h, GGS_ERR_STATE, "no Phi: call ggs_init_phi / ggs_set_z / ggs_set_phi first");
+  return bind_device(h);
+}
+
+int z_phase(ggs_handle *h) {
+  int rc;
+  HIP_TRY(h, hipEventRecord(h->ev.e[0], h->stream));
+  if ((rc = launch_theta(h))) return rc;
+  HIP_TRY(h, hipEventRecord(h->ev.e[1], h->stream));
+  if ((rc = launch_z(h))) return rc;
+  HIP_TRY(h, hipEventRecord(h->ev.e[2], h->stream));
+  return GGS_OK;
+}
+
+int finish_sweep(ggs_handle *h, bool with_phi) {
+  int rc;
+  HIP_TRY(h, hipEventRecord(h->ev.e[3], h->stream));
+  if ((rc = launch_merge(h))) return rc;
+  HIP_TRY(h, hipEventRecord(h->ev.e[4], h->stream));
+  bool acc = false;
+  if (with_phi) {
+    acc = (h->flags & GGS_FLAG_SAVE_PHI_MEAN) && sample_phi_this_iteration(h);
+    if ((rc = launch_phi(h, false, acc))) return rc;
+  }
+  HIP_TRY(h, hipEventRecord(h->ev.e[5], h->stream));
+  if ((rc = check_status(h))) return rc;   // synchronises the stream
+  if (acc) h->n_sampled_phi++;             // GGS:168-170
+  float ms = 0;
+  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev.e[0], h->ev.e[1])); h->tm.theta_ms += ms;
+  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev.e[1], h->ev.e[2])); h->tm.z_ms += ms;
+  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev.e[3], h->ev.e[4])); h->tm.merge_ms += ms;
+  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev.e[4], h->ev.e[5])); h->tm.phi_ms += ms;
+  h->tm.sweeps += 1;
+  h->tm.tokens_sampled += h->N;
+  if (h->flags & GGS_FLAG_PARANOID) return ggs_check_invariants(h);
+  return GGS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ggs_abi_version(void) { return GGS_ABI_VERSION; }
+
+const char *ggs_last_error(const ggs_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+int ggs_create(const ggs_config *cfg, ggs_handle **out) {
+  if (!cfg || !out) return GGS_ERR_BAD_ARG;
+  *out = nullptr;
+  if (cfg->struct_size != (int32_t)sizeof(ggs_config)) return GGS_ERR_BAD_ARG;
+  if (cfg->num_topics <= 0 || cfg->num_types <= 0 || !(cfg->beta > 0)) return GGS_ERR_BAD_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || cfg->device_id < 0 || cfg->device_id >= ndev) return GGS_ERR_HIP;
+  ggs_handle *h = new (std::nothrow) ggs_handle();
+  if (!h) return GGS_ERR_HIP;
+  h->K = cfg->num_topics; h->V = cfg->num_types; h->device = cfg->device_id;
+  h->Kp = (h->K + 1) & ~1;
+  h->pitch16 = (h->Kp / 2) | 1;             // odd number of 16-byte units per LDS row
+  h->beta = cfg->beta; h->seed = cfg->seed; h->flags = cfg->flags;
+  h->phi_burn_in = cfg->phi_burn_in; h->phi_thin = cfg->phi_mean_thin > 0 ? cfg->phi_mean_thin : 1;
+  h->alpha.assign(h->K, cfg->alpha_scalar);
+  if (cfg->alpha) std::copy(cfg->alpha, cfg->alpha + h->K, h->alpha.begin());
+  for (double a : h->alpha)
+    if (!(a > 0)) { delete h; return GGS_ERR_BAD_ARG; }
+
+  int rc = GGS_OK;
+  auto bail = [&](int code) { ggs_destroy(h); return code; };
+  if (hipSetDevice(h->device) != hipSuccess) return bail(GGS_ERR_HIP);
+  // LDS budgets
+  h->z_lds = 64 * h->pitch16 * 16;
+  if (h->z_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);   // K > ~1270 needs the K-sliced kernel (not in this round)
+  {
+    int B = 64;
+    auto lds_of = [&](int b) { const int bp = b | 1; return (int)((size_t)h->K * bp * 12 + (size_t)b * 20); };
+    while (B > 1 && lds_of(B) > 64 * 1024) B >>= 1;
+    if (lds_of(B) > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);
+    h->theta_docs_per_block = B; h->theta_lds = lds_of(B);
+  }
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(z_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, h->z_lds) != hipSuccess ||
+      hipFuncSetAttribute(reinterpret_cast<const void *>(theta_kernel<kThetaBlock>), hipFuncAttributeMaxDynamicSharedMemorySize, h->theta_lds) != hipSuccess)
+    return bail(GGS_ERR_HIP);
+  const size_t kv = (size_t)h->K * h->V;
+  if ((rc = dev_alloc(h, &h->d_alpha, h->K)) || (rc = dev_alloc(h, &h->d_phiT, (size_t)h->V * h->Kp)) ||
+      (rc = dev_alloc(h, &h->d_mag, h->K)) || (rc = dev_alloc(h, &h->d_tot, h->K)) || (rc = dev_alloc(h, &h->d_n_wk, kv)) ||
+      (rc = dev_alloc(h, &h->d_delta, kv)) || (rc = dev_alloc(h, &h->d_n_k, h->K)) || (rc = dev_alloc(h, &h->d_status, 4)))
+    return bail(rc);
+  if ((h->flags & GGS_FLAG_SAVE_PHI_MEAN) && (rc = dev_alloc(h, &h->d_phi_mean, kv))) return bail(rc);
+  if (hipMemcpy(h->d_alpha, h->alpha.data(), sizeof(double) * h->K, hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset(h->d_phiT, 0, sizeof(double) * (size_t)h->V * h->Kp) != hipSuccess ||
+      hipMemset(h->d_n_wk, 0, sizeof(int32_t) * kv) != hipSuccess || hipMemset(h->d_delta, 0, sizeof(int32_t) * kv) != hipSuccess ||
+      hipMemset(h->d_n_k, 0, sizeof(int32_t) * h->K) != hipSuccess || hipMemset(h->d_status, 0, 16) != hipSuccess ||
+      (h->d_phi_mean && hipMemset(h->d_phi_mean, 0, sizeof(double) * kv) != hipSuccess))
+    return bail(GGS_ERR_HIP);
+  for (auto &e : h->ev.e)
+    if (hipEventCreate(&e) != hipSuccess) return bail(GGS_ERR_HIP);
+  h->ev.ok = true;
+  *out = h;
+  return GGS_OK;
+}
+
+void ggs_destroy(ggs_handle *h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  (void)hipDeviceSynchronize();
+  void *bufs[] = {h->d_doc_ptr, h->d_chunk_start, h->d_tok, h->d_z, h->d_chunk_doc, h->d_chunk_len, h->d_alpha, h->d_theta,
+                  h->d_phiT, h->d_mag, h->d_tot, h->d_phi_mean, h->d_n_wk, h->delta_external ? nullptr : h->d_delta, h->d_n_k,
+                  h->d_status, h->d_scratch};
+  for (void *b : bufs)
+    if (b) (void)hipFree(b);
+  if (h->ev.ok)
+    for (auto &e : h->ev.e) (void)hipEventDestroy(e);
+  delete h;
+}
+
+int ggs_set_stream(ggs_handle *h, void *hip_stream) {
+  if (!h) return GGS_ERR_BAD_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->stream = reinterpret_cast<hipStream_t>(hip_stream);
+  return GGS_OK;
+}
+
+int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32_t *tokens, int64_t doc_base, int64_t tok_base) {
+  if (!h || D < 0 || !doc_ptr || doc_base < 0 || tok_base < 0) return set_err(h, GGS_ERR_BAD_ARG, "bad corpus arguments");
+  if (doc_ptr[0] != 0) return set_err(h, GGS_ERR_BAD_ARG, "doc_ptr[0] must be 0");
+  for (int64_t d = 0; d < D; ++d)
+    if (doc_ptr[d + 1] < doc_ptr[d]) return set_err(h, GGS_ERR_BAD_ARG, "doc_ptr must be non-decreasing");
+  const int64_t N = doc_ptr[D];
+  if (N > 0 && !tokens) return set_err(h, GGS_ERR_BAD_ARG, "tokens is null");
+  if (N >= (int64_t)1 << 31 || D >= (int64_t)1 << 31) return set_err(h, GGS_ERR_UNSUPPORTED, "more than 2^31-1 tokens or documents per device");
+  for (int64_t i = 0; i < N; ++i)
+    if (tokens[i] < 0 || tokens[i] >= h->V) return set_err(h, GGS_ERR_BAD_ARG, "token id outside [0, num_types)");
+  int rc = bind_device(h);
+  if (rc) return rc;
+
+  // z-kernel work items: each document is cut into ceil(len/64) near-equal chunks.
+  std::vector<int64_t> cstart;
+  std::vector<int32_t> cdoc, clen;
+  cstart.reserve((size_t)(N / 48 + D)); cdoc.reserve(cstart.capacity()); clen.reserve(cstart.capacity());
+  for (int64_t d = 0; d < D; ++d) {
+    const int64_t len = doc_ptr[d + 1] - doc_ptr[d];
+    if (len == 0) continue;
+    const int64_t n = (len + 63) / 64, base = len / n, rem = len % n;
+    int64_t s = doc_ptr[d];
+    for (int64_t j = 0; j < n; ++j) {
+      const int64_t l = base + (j < rem ? 1 : 0);
+      cstart.push_back(s); cdoc.push_back((int32_t)d); clen.push_back((int32_t)l);
+      s += l;
+    }
+  }
+  h->D = D; h->N = N; h->C = (int64_t)cstart.size(); h->doc_base = doc_base; h->tok_base = tok_base;
+  if ((rc = dev_alloc(h, &h->d_doc_ptr, (size_t)D + 1)) || (rc = dev_alloc(h, &h->d_tok, (size_t)N)) || (rc = dev_alloc(h, &h->d_z, (size_t)N)) ||
+      (rc = dev_alloc(h, &h->d_theta, (size_t)D * h->K)) || (rc = dev_alloc(h, &h->d_chunk_start, (size_t)h->C)) ||
+      (rc = dev_alloc(h, &h->d_chunk_doc, (size_t)h->C)) || (rc = dev_alloc(h, &h->d_chunk_len, (size_t)h->C)))
+    return rc;
+  HIP_TRY(h, hipMemcpy(h->d_doc_ptr, doc_ptr, sizeof(int64_t) * ((size_t)D + 1), hipMemcpyHostToDevice));
+  if (N) HIP_TRY(h, hipMemcpy(h->d_tok, tokens, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemset(h->d_z, 0, sizeof(int32_t) * std::max<size_t>((size_t)N, 1)));
+  HIP_TRY(h, hipMemset(h->d_theta, 0, sizeof(double) * std::max<size_t>((size_t)D * h->K, 1)));
+  if (h->C) {
+    HIP_TRY(h, hipMemcpy(h->d_chunk_start, cstart.data(), sizeof(int64_t) * cstart.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_chunk_doc, cdoc.data(), sizeof(int32_t) * cdoc.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_chunk_len, clen.data(), sizeof(int32_t) * clen.size(), hipMemcpyHostToDevice));
+  }
+  h->have_corpus = true; h->have_phi = false; h->in_sweep = false; h->global_tokens = -1;
+  return GGS_OK;
+}
+
+int ggs_init_z_java_lcg(ggs_handle *h, int32_t seed) {
+  int rc = require_ready(h, false);
+  if (rc) return rc;
+  if (h->tok_base != 0) return set_err(h, GGS_ERR_STATE, "java-LCG init is one sequential stream: only valid with tok_base == 0");
+  // One sequential stream, so it runs on the host exactly once at start-up.
+  std::vector<int32_t> z((size_t)h->N);
+  java_lcg_next_ints(seed, h->K, h->N, z.data());
+  if (h->N) HIP_TRY(h, hipMemcpyAsync(h->d_z, z.data(), sizeof(int32_t) * (size_t)h->N, hipMemcpyHostToDevice, h->stream));
+  if ((rc = launch_count_rebuild(h))) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return GGS_OK;
+}
+
+int ggs_set_z(ggs_handle *h, const int32_t *z, int32_t redraw_phi) {
+  int rc = require_ready(h, false);
+  if (rc) return rc;
+  if (h->N > 0 && !z) return set_err(h, GGS_ERR_BAD_ARG, "z is null");
+  for (int64_t i = 0; i < h->N; ++i)
+    if (z[i] < 0 || z[i] >= h->K) return set_err(h, GGS_ERR_BAD_ARG, "topic indicator outside [0, num_topics)");
+  if (h->N) HIP_TRY(h, hipMemcpyAsync(h->d_z, z, sizeof(int32_t) * (size_t)h->N, hipMemcpyHostToDevice, h->stream));
+  if ((rc = launch_count_rebuild(h))) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (redraw_phi) return ggs_init_phi(h);
+  return GGS_OK;
+}
+
+int ggs_init_phi(ggs_handle *h) {
+  int rc = require_ready(h, false);
+  if (rc) return rc;
+  if ((rc = launch_phi(h, true, false))) return rc;
+  return check_status(h);
+}
+
+int ggs_set_iteration(ggs_handle *h, int32_t it) { if (!h) return GGS_ERR_BAD_ARG; h->iteration = it; return GGS_OK; }
+int ggs_get_iteration(const ggs_handle *h, int32_t *it) { if (!h || !it) return GGS_ERR_BAD_ARG; *it = h->iteration; return GGS_OK; }
+
+int ggs_sweep_begin(ggs_handle *h) {
+  int rc = require_ready(h, true);
+  if (rc) return rc;
+  if (h->in_sweep) return set_err(h, GGS_ERR_STATE, "ggs_sweep_begin called twice without ggs_sweep_end");
+  h->iteration += 1;                                   // currentIteration = iteration, UPLDA:646
+  if ((rc = z_phase(h))) return rc;
+  h->in_sweep = true;
+  return GGS_OK;
+}
+
+int ggs_sweep_end(ggs_handle *h) {
+  int rc = require_ready(h, true);
+  if (rc) return rc;
+  if (!h->in_sweep) return set_err(h, GGS_ERR_STATE, "ggs_sweep_end without ggs_sweep_begin");
+  h->in_sweep = false;
+  return finish_sweep(h, true);
+}
+
+int ggs_sweep(ggs_handle *h, int32_t n_sweeps) {
+  for (int32_t i = 0; i < n_sweeps; ++i) {
+    int rc = ggs_sweep_begin(h);
+    if (rc) return rc;
+    if ((rc = ggs_sweep_end(h))) return rc;
+  }
+  return GGS_OK;
+}
+
+int ggs_sample_z_given_phi(ggs_handle *h, int32_t n_sweeps) {
+  int rc = require_ready(h, true);
+  if (rc) return rc;
+  if (h->in_sweep) return set_err(h, GGS_ERR_STATE, "inside a split sweep");
+  for (int32_t i = 0; i < n_sweeps; ++i) {
+    h->iteration += 1;                                 // UPLDA:980
+    if ((rc = z_phase(h))) return rc;
+    if ((rc = finish_sweep(h, false))) return rc;
+  }
+  // tokensPerTopic follows the merged counts
+  hipLaunchKernelGGL(phi_magnitude_kernel, dim3((h->K + 63) / 64), dim3(64), 0, h->stream, h->d_n_wk, h->K, h->V, h->beta, h->d_mag, h->d_n_k);
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return GGS_OK;
+}
+
+int ggs_delta_device_ptr(ggs_handle *h, void **dev_ptr, int64_t *num_elems) {
+  if (!h || !dev_ptr || !num_elems) return GGS_ERR_BAD_ARG;
+  *dev_ptr = h->d_delta; *num_elems = (int64_t)h->K * h->V;
+  return GGS_OK;
+}
+
+int ggs_counts_device_ptr(ggs_handle *h, void **dev_ptr, int64_t *num_elems) {
+  if (!h || !dev_ptr || !num_elems) return GGS_ERR_BAD_ARG;
+  *dev_ptr = h->d_n_wk; *num_elems = (int64_t)h->K * h->V;
+  return GGS_OK;
+}
+
+int ggs_set_global_token_count(ggs_handle *h, int64_t n_tokens) {
+  if (!h || n_tokens < 0) return GGS_ERR_BAD_ARG;
+  h->global_tokens = n_tokens;
+  return GGS_OK;
+}
+
+int ggs_use_external_delta(ggs_handle *h, void *dev_ptr) {
+  if (!h || !dev_ptr) return GGS_ERR_BAD_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  if (h->in_sweep) return set_err(h, GGS_ERR_STATE, "inside a split sweep");
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (!h->delta_external && h->d_delta) (void)hipFree(h->d_delta);
+  h->d_delta = static_cast<int32_t *>(dev_ptr);
+  h->delta_external = true;
+  return GGS_OK;
+}
+
+static int copy_out(ggs_handle *h, void *dst, const void *src, size_t bytes) {
+  if (!bytes) return GGS_OK;
+  HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return GGS_OK;
+}
+
+int ggs_get_delta(ggs_handle *h, int32_t *delta) {
+  if (!h || !delta) return GGS_ERR_BAD_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  return copy_out(h, delta, h->d_delta, sizeof(int32_t) * (size_t)h->K * h->V);
+}
+int ggs_set_delta(ggs_handle *h, const int32_t *delta) {
+  if (!h || !delta) return GGS_ERR_BAD_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipMemcpyAsync(h->d_delta, delta, sizeof(int32_t) * (size_t)h->K * h->V, hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  return GGS_OK;
+}
+
+int ggs_synchronize(ggs_handle *h) {
+  if (!h) return GGS_ERR_BAD_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  return check_status(h);
+}
+
+int ggs_get_z(ggs_handle *h, int32_t *z) {
+  int rc = require_ready(h, false);
+  if (rc) return rc;
+  if (h->N > 0 && !z) return GGS_ERR_BAD_ARG;
+  return copy_out(h, z, h->d_z, sizeof(int32_t) * (size_t)h->N);
+}
+int ggs_get_type_topic_counts(ggs_handle *h, int32_t *n_wk) {
+  if (!h || !n_wk) return GGS_ERR_BAD_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  return copy_out(h, n_wk, h->d_n_wk, sizeof(int32_t) * (size_t)h->K * h->V);
+}
+int ggs_get_topic_totals(ggs_handle *h, int32_t *n_k) {
+  if (!h || !n_k) return GGS_ERR_BAD_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  // n_k is refreshed by every Phi draw; recompute here so the getter is valid right after set_z(redraw=0)
+  hipLaunchKernelGGL(phi_magnitude_kernel, dim3((h->K + 63) / 64), dim3(64), 0, h->stream, h->d_n_wk, h->K, h->V, h->beta, h->d_mag, h->d_n_k);
+  return copy_out(h, n_k, h->d_n_k, sizeof(int32_t) * (size_t)h->K);
+}
+
+static int phi_out(ggs_handle *h, const double *src_T, int32_t pitch, double *dst, double scale) {
+  const size_t kv = (size_t)h->K * h->V;
+  int rc = ensure_scratch(h, kv * sizeof(double));
+  if (rc) return rc;
+  hipLaunchKernelGGL(phiT_to_phi_kernel, dim3(grid_for((int64_t)kv, 256)), dim3(256), 0, h->stream, src_T, static_cast<double *>(h->d_scratch),
+                     h->K, pitch, h->V, scale);
+  HIP_TRY(h, hipGetLastError());
+  return copy_out(h, dst, h->d_scratch, kv * sizeof(double));
+}
+int ggs_get_phi(ggs_handle *h, double *phi) {
+  if (!h || !phi) return GGS_ERR_BAD_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  return phi_out(h, h->d_phiT, h->Kp, phi, 1.0);
+}
+int ggs_set_phi(ggs_handle *h, const double *phi) {
+  if (!h || !phi) return GGS_ERR_BAD_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  const size_t kv = (size_t)h->K * h->V;
+  if ((rc = ensure_scratch(h, kv * sizeof(double)))) return rc;
+  HIP_TRY(h, hipMemcpyAsync(h->d_scratch, phi, kv * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  hipLaunchKernelGGL(phi_to_phiT_kernel, dim3(grid_for((int64_t)kv, 256)), dim3(256), 0, h->stream, static_cast<const double *>(h->d_scratch),
+                     h->d_phiT, h->K, h->Kp, h->V);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  h->have_phi = true;
+  return GGS_OK;
+}
+int ggs_get_phi_mean(ggs_handle *h, double *phi_mean, int32_t *n_sampled) {
+  if (!h || !n_sampled) return GGS_ERR_BAD_ARG;
+  *n_sampled = h->n_sampled_phi;
+  if (h->n_sampled_phi == 0 || !h->d_phi_mean) return GGS_OK;   // Java returns null (UPLDA:1955-1958)
+  if (!phi_mean) return GGS_ERR_BAD_ARG;
+  int rc = bind_device(h);
+  if (rc) return rc;
+  return phi_out(h, h->d_phi_mean, h->K, phi_mean, (double)h->n_sampled_phi);
+}
+int ggs_get_theta(ggs_handle *h, int64_t doc_begin, int64_t doc_end, double *theta) {
+  int rc = require_ready(h, false);
+  if (rc) return rc;
+  if (doc_begin < 0 || doc_end > h->D || doc_begin > doc_end || (!theta && doc_end > doc_begin)) return set_err(h, GGS_ERR_BAD_ARG, "bad document range");
+  return copy_out(h, theta, h->d_theta + (size_t)doc_begin * h->K, sizeof(double) * (size_t)(doc_end - doc_begin) * h->K);
+}
+int ggs_get_doc_topic_counts(ggs_handle *h, int64_t doc_begin, int64_t doc_end, int32_t *n_dk) {
+  int rc = require_ready(h, false);
+  if (rc) return rc;
+  if (doc_begin < 0 || doc_end > h->D || doc_begin > doc_end || (!n_dk && doc_end > doc_begin)) return set_err(h, GGS_ERR_BAD_ARG, "bad document range");
+  const int64_t nd = doc_end - doc_begin;
+  if (nd == 0) return GGS_OK;
+  const size_t bytes = (size_t)nd * h->K * sizeof(int32_t);
+  if ((rc = ensure_scratch(h, bytes))) return rc;
+  HIP_TRY(h, hipMemsetAsync(h->d_scratch, 0, bytes, h->stream));
+  hipLaunchKernelGGL(doc_topic_kernel, dim3((unsigned)nd), dim3(64), 0, h->stream, h->d_doc_ptr, h->d_z, doc_begin, h->K, static_cast<int32_t *>(h->d_scratch));
+  HIP_TRY(h, hipGetLastError());
+  return copy_out(h, n_dk, h->d_scratch, bytes);
+}
+int ggs_get_timings(ggs_handle *h, ggs_timings *out) { if (!h || !out) return GGS_ERR_BAD_ARG; *out = h->tm; return GGS_OK; }
+int ggs_reset_timings(ggs_handle *h) { if (!h) return GGS_ERR_BAD_ARG; h->tm = ggs_timings{}; return GGS_OK; }
+
+int ggs_check_invariants(ggs_handle *h) {
+  int rc = require_ready(h, false);
+  if (rc) return rc;
+  const int K = h->K;
+  const size_t bytes = 16 + sizeof(int32_t) * (size_t)K;
+  if ((rc = ensure_scratch(h, bytes))) return rc;
+  auto *d_total = static_cast<unsigned long long *>(h->d_scratch);
+  auto *d_flags = reinterpret_cast<uint32_t *>(static_cast<char *>(h->d_scratch) + 8);
+  auto *d_col = reinterpret_cast<int32_t *>(static_cast<char *>(h->d_scratch) + 16);
+  HIP_TRY(h, hipMemsetAsync(h->d_scratch, 0, bytes, h->stream));
+  const int64_t kv = (int64_t)K * h->V;
+  hipLaunchKernelGGL(invariants_kernel, dim3(grid_for(kv, 256)), dim3(256), 0, h->stream, h->d_n_wk, h->d_delta, kv, K, d_total, d_col, d_flags);
+  hipLaunchKernelGGL(phi_magnitude_kernel, dim3((K + 63) / 64), dim3(64), 0, h->stream, h->d_n_wk, K, h->V, h->beta, h->d_mag, h->d_n_k);
+  HIP_TRY(h, hipGetLastError());
+  std::vector<unsigned char> host(bytes);
+  std::vector<int32_t> nk((size_t)K);
+  if ((rc = copy_out(h, host.data(), h->d_scratch, bytes))) return rc;
+  if ((rc = copy_out(h, nk.data(), h->d_n_k, sizeof(int32_t) * (size_t)K))) return rc;
+  unsigned long long total; uint32_t fl;
+  std::memcpy(&total, host.data(), 8); std::memcpy(&fl, host.data() + 8, 4);
+  const int32_t *col = reinterpret_cast<const int32_t *>(host.data() + 16);
+  if (fl & 1u) return set_err(h, GGS_ERR_INVARIANT, "negative type-topic count");
+  if (fl & 2u) return set_err(h, GGS_ERR_INVARIANT, "non-zero delta after updateCounts");
+  if ((int64_t)total != (h->global_tokens >= 0 ? h->global_tokens : h->N)) return set_err(h, GGS_ERR_INVARIANT, "type-topic counts do not sum to the corpus size");
+  for (int k = 0; k < K; ++k)
+    if (col[k] != nk[(size_t)k]) return set_err(h, GGS_ERR_INVARIANT, "column sum differs from tokensPerTopic");
+  return GGS_OK;
+}
+
+int ggs_get_launch_info(ggs_handle *h, int64_t *num_chunks, int32_t *lds_bytes_z, int32_t *docs_per_block_theta) {
+  if (!h) return GGS_ERR_BAD_ARG;
+  if (num_chunks) *num_chunks = h->C;
+  if (lds_bytes_z) *lds_bytes_z = h->z_lds;
+  if (docs_per_block_theta) *docs_per_block_theta = h->theta_docs_per_block;
+  return GGS_OK;
+}
+
+int ggs_java_lcg_next_ints(int32_t seed, int32_t bound, int64_t n, int32_t *out) {
+  if (bound <= 0 || n < 0 || (n > 0 && !out)) return GGS_ERR_BAD_ARG;
+  java_lcg_next_ints(seed, bound, n, out);
+  return GGS_OK;
+}
+
+// ---- primitives for the parity tests ---------------------------------------------
+namespace {
+struct TmpDev {
+  std::vector<void *> p;
+  ~TmpDev() { for (void *q : p) if (q) (void)hipFree(q); }
+  void *get(size_t bytes) { void *q = nullptr; if (hipMalloc(&q, std::max<size_t>(bytes, 16)) != hipSuccess) return nullptr; p.push_back(q); return q; }
+};
+}  // namespace
+
+int ggs_debug_philox(int32_t device_id, int64_t n, const uint32_t *ctr, const uint32_t *key, uint32_t *out) {
+  if (n <= 0 || !ctr || !key || !out || hipSetDevice(device_id) != hipSuccess) return GGS_ERR_BAD_ARG;
+  TmpDev t;
+  auto *dc = static_cast<uint32_t *>(t.get(n * 16)); auto *dk = static_cast<uint32_t *>(t.get(n * 8)); auto *dou = static_cast<uint32_t *>(t.get(n * 16));
+  if (!dc || !dk || !dou) return GGS_ERR_HIP;
+  if (hipMemcpy(dc, ctr, n * 16, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dk, key, n * 8, hipMemcpyHostToDevice) != hipSuccess) return GGS_ERR_HIP;
+  hipLaunchKernelGGL(debug_philox_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, n, dc, dk, dou);
+  if (hipMemcpy(out, dou, n * 16, hipMemcpyDeviceToHost) != hipSuccess) return GGS_ERR_HIP;
+  return GGS_OK;
+}
+
+int ggs_debug_math(int32_t device_id, int32_t op, int64_t n, const double *x, const double *y, double *out) {
+  if (n <= 0 || !x || !out || hipSetDevice(device_id) != hipSuccess) return GGS_ERR_BAD_ARG;
+  TmpDev t;
+  auto *dx = static_cast<double *>(t.get(n * 8)); auto *dy = static_cast<double *>(t.get(n * 8)); auto *dou = static_cast<double *>(t.get(n * 8));
+  if (!dx || !dy || !dou) return GGS_ERR_HIP;
+  if (hipMemcpy(dx, x, n * 8, hipMemcpyHostToDevice) != hipSuccess) return GGS_ERR_HIP;
+  if (hipMemcpy(dy, y ? y : x, n * 8, hipMemcpyHostToDevice) != hipSuccess) return GGS_ERR_HIP;
+  hipLaunchKernelGGL(debug_math_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, op, n, dx, dy, dou);
+  if (hipMemcpy(out, dou, n * 8, hipMemcpyDeviceToHost) != hipSuccess) return GGS_ERR_HIP;
+  return GGS_OK;
+}
+
+int ggs_debug_draw(int32_t device_id, int32_t kind, uint64_t seed, uint32_t iteration, uint32_t purpose, uint64_t elem0, int64_t n,
+                   const double *shape, double *out, int32_t *status) {
+  if (n <= 0 || !out || (kind == 2 && !shape) || hipSetDevice(device_id) != hipSuccess) return GGS_ERR_BAD_ARG;
+  TmpDev t;
+  auto *ds = static_cast<double *>(t.get(n * 8)); auto *dou = static_cast<double *>(t.get(n * 8)); auto *dst = static_cast<uint32_t *>(t.get(16));
+  if (!ds || !dou || !dst) return GGS_ERR_HIP;
+  if (shape && hipMemcpy(ds, shape, n * 8, hipMemcpyHostToDevice) != hipSuccess) return GGS_ERR_HIP;
+  if (hipMemset(dst, 0, 16) != hipSuccess) return GGS_ERR_HIP;
+  hipLaunchKernelGGL(debug_draw_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, kind, seed, iteration, purpose, elem0, n, ds, dou, dst);
+  uint32_t st = 0;
+  if (hipMemcpy(out, dou, n * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&st, dst, 4, hipMemcpyDeviceToHost) != hipSuccess) return GGS_ERR_HIP;
+  if (status) *status = (int32_t)st;
+  return GGS_OK;
+}
+
+}  // extern "C"

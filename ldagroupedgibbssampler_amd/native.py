@@ -1,0 +1,249 @@
+"""Thin numpy wrapper over the C-ABI (include/ggs_hip.h); one object = one ggs_handle."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+OK = 0
+ERR_NEGATIVE_COUNT, ERR_INVALID_TOPIC, ERR_RNG_EXHAUSTED, ERR_BAD_ARG = 1, 2, 3, 4
+ERR_HIP, ERR_STATE, ERR_UNSUPPORTED, ERR_INVARIANT = 5, 6, 7, 8
+FLAG_PARANOID, FLAG_SAVE_PHI_MEAN = 1, 2
+PURPOSE_Z, PURPOSE_THETA, PURPOSE_PHI, PURPOSE_INIT_PHI = 1, 2, 3, 4
+
+
+class GGSError(RuntimeError):
+    """A non-zero return of the C-ABI.  ERR_INVALID_TOPIC / ERR_NEGATIVE_COUNT are the
+    IllegalStateExceptions of LDAGroupedGibbsSampler.java:84-85,116-118; ERR_BAD_ARG the
+    IllegalArgumentExceptions."""
+
+    def __init__(self, code, msg):
+        super().__init__("ggs error %d: %s" % (code, msg))
+        self.code = code
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _ip(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int32))
+
+
+def _lp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+class GGSHandle:
+    def __init__(self, num_topics, num_types, alpha, beta, seed, device_id=0, flags=0, phi_burn_in=0, phi_mean_thin=1):
+        self._L = _lib.load()
+        self.K, self.V = int(num_topics), int(num_types)
+        self.D = self.N = 0
+        cfg = _lib.GGSConfig()
+        cfg.struct_size = C.sizeof(_lib.GGSConfig)
+        cfg.num_topics, cfg.num_types, cfg.device_id = self.K, self.V, int(device_id)
+        alpha = np.asarray(alpha, np.float64)
+        self._alpha = None
+        if alpha.ndim == 0:
+            cfg.alpha = None
+            cfg.alpha_scalar = float(alpha)
+        else:
+            self._alpha = np.ascontiguousarray(alpha)
+            if self._alpha.size != self.K:
+                raise ValueError("alpha must have num_topics entries")
+            cfg.alpha = _dp(self._alpha)
+        cfg.beta = float(beta)
+        cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        cfg.flags, cfg.phi_burn_in, cfg.phi_mean_thin = int(flags), int(phi_burn_in), int(phi_mean_thin)
+        h = C.c_void_p()
+        rc = self._L.ggs_create(C.byref(cfg), C.byref(h))
+        if rc:
+            raise GGSError(rc, "ggs_create failed")
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.ggs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise GGSError(rc, self._L.ggs_last_error(self._h).decode())
+
+    # ---- corpus / state ----
+    def set_stream(self, stream_ptr):
+        self._chk(self._L.ggs_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def set_corpus(self, doc_ptr, tokens, doc_base=0, tok_base=0):
+        doc_ptr = np.ascontiguousarray(doc_ptr, np.int64)
+        tokens = np.ascontiguousarray(tokens, np.int32)
+        self._chk(self._L.ggs_set_corpus(self._h, doc_ptr.size - 1, _lp(doc_ptr), _ip(tokens), int(doc_base), int(tok_base)))
+        self.D, self.N = doc_ptr.size - 1, int(doc_ptr[-1])
+
+    def init_z_java_lcg(self, seed):
+        self._chk(self._L.ggs_init_z_java_lcg(self._h, int(seed)))
+
+    def set_z(self, z, redraw_phi=True):
+        z = np.ascontiguousarray(z, np.int32)
+        if z.size != self.N:
+            raise ValueError("z must have one entry per token")
+        self._chk(self._L.ggs_set_z(self._h, _ip(z), int(bool(redraw_phi))))
+
+    def init_phi(self):
+        self._chk(self._L.ggs_init_phi(self._h))
+
+    def set_iteration(self, it):
+        self._chk(self._L.ggs_set_iteration(self._h, int(it)))
+
+    @property
+    def iteration(self):
+        it = C.c_int32()
+        self._chk(self._L.ggs_get_iteration(self._h, C.byref(it)))
+        return it.value
+
+    # ---- sweeps ----
+    def sweep(self, n=1):
+        self._chk(self._L.ggs_sweep(self._h, int(n)))
+
+    def sweep_begin(self):
+        self._chk(self._L.ggs_sweep_begin(self._h))
+
+    def sweep_end(self):
+        self._chk(self._L.ggs_sweep_end(self._h))
+
+    def sample_z_given_phi(self, n=1):
+        self._chk(self._L.ggs_sample_z_given_phi(self._h, int(n)))
+
+    def synchronize(self):
+        self._chk(self._L.ggs_synchronize(self._h))
+
+    def delta_device_ptr(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self._L.ggs_delta_device_ptr(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def counts_device_ptr(self):
+        p, n = C.c_void_p(), C.c_int64()
+        self._chk(self._L.ggs_counts_device_ptr(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def use_external_delta(self, dev_ptr):
+        self._chk(self._L.ggs_use_external_delta(self._h, C.c_void_p(dev_ptr)))
+
+    def set_global_token_count(self, n):
+        self._chk(self._L.ggs_set_global_token_count(self._h, int(n)))
+
+    def get_delta(self):
+        out = np.empty((self.V, self.K), np.int32)
+        self._chk(self._L.ggs_get_delta(self._h, _ip(out)))
+        return out
+
+    def set_delta(self, d):
+        d = np.ascontiguousarray(d, np.int32)
+        assert d.shape == (self.V, self.K)
+        self._chk(self._L.ggs_set_delta(self._h, _ip(d)))
+
+    # ---- getters ----
+    def get_z(self):
+        out = np.empty(self.N, np.int32)
+        self._chk(self._L.ggs_get_z(self._h, _ip(out)))
+        return out
+
+    def get_type_topic_counts(self):
+        out = np.empty((self.V, self.K), np.int32)
+        self._chk(self._L.ggs_get_type_topic_counts(self._h, _ip(out)))
+        return out
+
+    def get_topic_totals(self):
+        out = np.empty(self.K, np.int32)
+        self._chk(self._L.ggs_get_topic_totals(self._h, _ip(out)))
+        return out
+
+    def get_phi(self):
+        out = np.empty((self.K, self.V), np.float64)
+        self._chk(self._L.ggs_get_phi(self._h, _dp(out)))
+        return out
+
+    def set_phi(self, phi):
+        phi = np.ascontiguousarray(phi, np.float64)
+        if phi.shape != (self.K, self.V):
+            raise ValueError("phi must be [K][V]")
+        self._chk(self._L.ggs_set_phi(self._h, _dp(phi)))
+
+    def get_phi_mean(self):
+        out = np.empty((self.K, self.V), np.float64)
+        n = C.c_int32()
+        self._chk(self._L.ggs_get_phi_mean(self._h, _dp(out), C.byref(n)))
+        return (out, n.value) if n.value else (None, 0)
+
+    def get_theta(self, doc_begin=0, doc_end=None):
+        doc_end = self.D if doc_end is None else doc_end
+        out = np.empty((doc_end - doc_begin, self.K), np.float64)
+        self._chk(self._L.ggs_get_theta(self._h, doc_begin, doc_end, _dp(out)))
+        return out
+
+    def get_doc_topic_counts(self, doc_begin=0, doc_end=None):
+        doc_end = self.D if doc_end is None else doc_end
+        out = np.empty((doc_end - doc_begin, self.K), np.int32)
+        self._chk(self._L.ggs_get_doc_topic_counts(self._h, doc_begin, doc_end, _ip(out)))
+        return out
+
+    def get_timings(self):
+        t = _lib.GGSTimings()
+        self._chk(self._L.ggs_get_timings(self._h, C.byref(t)))
+        return {k: getattr(t, k) for k, _ in t._fields_}
+
+    def reset_timings(self):
+        self._chk(self._L.ggs_reset_timings(self._h))
+
+    def check_invariants(self):
+        self._chk(self._L.ggs_check_invariants(self._h))
+
+    def launch_info(self):
+        c, l, b = C.c_int64(), C.c_int32(), C.c_int32()
+        self._chk(self._L.ggs_get_launch_info(self._h, C.byref(c), C.byref(l), C.byref(b)))
+        return {"num_chunks": c.value, "lds_bytes_z": l.value, "docs_per_block_theta": b.value}
+
+
+# ---- primitives (parity tests) ----
+def debug_philox(ctr, key, device_id=0):
+    L = _lib.load()
+    ctr = np.ascontiguousarray(ctr, np.uint32).reshape(-1, 4)
+    key = np.ascontiguousarray(key, np.uint32).reshape(-1, 2)
+    out = np.empty_like(ctr)
+    up = C.POINTER(C.c_uint32)
+    rc = L.ggs_debug_philox(device_id, ctr.shape[0], ctr.ctypes.data_as(up), key.ctypes.data_as(up), out.ctypes.data_as(up))
+    if rc:
+        raise GGSError(rc, "ggs_debug_philox")
+    return out
+
+
+def debug_math(op, x, y=None, device_id=0):
+    L = _lib.load()
+    x = np.ascontiguousarray(x, np.float64)
+    y = x if y is None else np.ascontiguousarray(y, np.float64)
+    out = np.empty_like(x)
+    rc = L.ggs_debug_math(device_id, {"log": 0, "pow": 1, "sqrt": 2, "div": 3}[op], x.size, _dp(x), _dp(y), _dp(out))
+    if rc:
+        raise GGSError(rc, "ggs_debug_math")
+    return out
+
+
+def debug_draw(kind, seed, iteration, purpose, elem0, n=None, shape=None, device_id=0):
+    L = _lib.load()
+    if shape is not None:
+        shape = np.ascontiguousarray(shape, np.float64)
+        n = shape.size
+    out = np.empty(n, np.float64)
+    st = C.c_int32()
+    rc = L.ggs_debug_draw(device_id, {"uniform": 0, "gaussian": 1, "gamma": 2}[kind], seed, iteration, purpose, elem0, n,
+                          _dp(shape) if shape is not None else None, _dp(out), C.byref(st))
+    if rc:
+        raise GGSError(rc, "ggs_debug_draw")
+    return out, st.value

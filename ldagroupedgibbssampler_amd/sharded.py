@@ -1,0 +1,96 @@
+"""Doc-sharded Grouped Gibbs sweep: one process per GPU, torch.distributed for the exchange.
+
+Given (theta, Phi) every z is conditionally independent and theta_d depends on document d
+alone, so contiguous document shards (the even-split rule of
+randomscan/document/EvenSplitBatchBuilder.java:30-44) sample exactly what one GPU would:
+every shard keys its Philox streams by GLOBAL token / document index.  Per sweep there is
+ONE exchange, where the Java code merges its thread-shared AtomicInteger deltas
+(UPLDA:1107-1221; the ADLDA analogue is sumTypeTopicCounts, ADLDA.java:302): a sum
+all-reduce of the int32 [V][K] delta buffer (RCCL on GPUs).  Phi is then re-drawn on every
+rank from identical counts and identical Philox keys, hence bit-identical without a
+broadcast.
+
+The engine is injected: the product passes ``native.GGSHandle`` (HIP); the CPU tests pass
+an oracle-backed engine to exercise exactly this orchestration over gloo.
+"""
+import numpy as np
+
+from .corpus import even_split
+
+
+class _DevPtr:
+    """Exposes a raw device pointer through __cuda_array_interface__ so torch can view it."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
+
+def wrap_device_int32(ptr, n, device=None):
+    import torch
+    dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+    return torch.as_tensor(_DevPtr(ptr, n, "<i4"), device=dev)
+
+
+class TorchHipExchange:
+    """Sum all-reduce of device-resident int32 buffers owned by libggs_hip (RCCL when the
+    process group backend is nccl)."""
+
+    def __init__(self, handle, group=None):
+        import torch.distributed as dist
+        self.dist, self.group = dist, group
+        self.delta = wrap_device_int32(*handle.delta_device_ptr())
+        self.counts = wrap_device_int32(*handle.counts_device_ptr())
+
+    def allreduce_delta(self):
+        self.dist.all_reduce(self.delta, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    def allreduce_counts(self):
+        self.dist.all_reduce(self.counts, op=self.dist.ReduceOp.SUM, group=self.group)
+
+
+class ShardedGGS:
+    """One rank's view of a doc-sharded sampler.
+
+    engine      object with the GGSHandle method names (set_corpus, set_z, init_phi,
+                sweep_begin, sweep_end, set_global_token_count, get_z, ...)
+    exchange    object with allreduce_delta() / allreduce_counts() acting on the engine's
+                delta / count buffers
+    """
+
+    def __init__(self, engine, exchange_factory, corpus, rank, world_size):
+        self.engine, self.rank, self.world = engine, int(rank), int(world_size)
+        self.bounds = even_split(corpus.num_docs, self.world)
+        sub, self.doc_base, self.tok_base = corpus.shard(self.bounds[self.rank], self.bounds[self.rank + 1])
+        self.local = sub
+        self.global_tokens = corpus.num_tokens
+        engine.set_corpus(sub.doc_ptr, sub.tokens, self.doc_base, self.tok_base)
+        engine.set_global_token_count(self.global_tokens)
+        self.exchange = exchange_factory(engine)
+
+    def set_z_global(self, z_global):
+        """Start-up: every rank takes its slice of the corpus-wide z (e.g. the seeded
+        java.util.Random initialisation, which is one sequential stream and therefore
+        computed once), builds local counts, sum-all-reduces them, draws the initial Phi."""
+        z_local = np.ascontiguousarray(z_global[self.tok_base:self.tok_base + self.local.num_tokens], np.int32)
+        self.engine.set_z(z_local, redraw_phi=False)
+        self.exchange.allreduce_counts()
+        self.engine.init_phi()
+
+    def sweep(self, n=1):
+        for _ in range(n):
+            self.engine.sweep_begin()
+            self.exchange.allreduce_delta()
+            self.engine.sweep_end()
+
+
+def java_lcg_initial_z(num_tokens, num_topics, seed):
+    """z0 = java.util.Random(seed).nextInt(K) per token in (doc, position) order
+    (UPLDA:398-406,458-460), computed on the host once for a sharded start-up."""
+    import ctypes as C
+
+    from . import _lib
+    z = np.empty(int(num_tokens), np.int32)
+    rc = _lib.load().ggs_java_lcg_next_ints(int(seed), int(num_topics), z.size, z.ctypes.data_as(C.POINTER(C.c_int32)))
+    if rc:
+        raise ValueError("ggs_java_lcg_next_ints rc=%d" % rc)
+    return z

@@ -1,0 +1,841 @@
+/*
+ * ggs_oracle.c -- CPU ORACLE (test infrastructure; see ggs_oracle.h header).
+ *
+ * Plain C restatement of the reference's Grouped-Gibbs arithmetic.  Build with
+ *   gcc -O2 -std=c11 -ffp-contract=off -fno-fast-math -fopenmp
+ * (-ffp-contract=off matters: every product and sum below must round exactly
+ * once, as the JVM's strict double arithmetic does).
+ *
+ * Reference paths are relative to src/main/java/cc/mallet/ in the reference
+ * checkout.  "GGS" = topics/LDAGroupedGibbsSampler.java, "UPLDA" =
+ * topics/UncollapsedParallelLDA.java, "MSLDA" = topics/ModifiedSimpleLDA.java.
+ *
+ * Third-party arithmetic that is NOT in the reference tree and is restated from
+ * its published algorithm:
+ *   - java.util.Random (JDK 8 spec): 48-bit LCG, nextInt(bound), nextDouble,
+ *     nextGaussian (polar method using StrictMath.log/sqrt).
+ *   - StrictMath.log / StrictMath.pow = fdlibm 5.3 e_log.c / e_pow.c.
+ *   - cc.mallet.types.Dirichlet (MALLET 2.0.8) constructors:
+ *       Dirichlet(double[] p): magnitude = sum p (in index order),
+ *                              partition[i] = p[i] / magnitude
+ *       Dirichlet(int n, double a): magnitude = n*a, partition[i] = 1.0/n
+ *     so the gamma shape actually used is partition[i]*magnitude, which is
+ *     NOT always bit-equal to p[i].  Call sites: GGS:70,190; UPLDA:1292.
+ *   - Philox4x32-10 (Salmon et al., SC'11; Random123 constants).
+ */
+#include "ggs_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------ */
+/* Philox4x32-10                                                             */
+/* ------------------------------------------------------------------------ */
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+  uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+  uint32_t k0 = key[0], k1 = key[1];
+  for (int r = 0; r < 10; r++) {
+    if (r > 0) { k0 += 0x9E3779B9u; k1 += 0xBB67AE85u; }
+    uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+    uint32_t n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+/* Two 32-bit words -> double in [0,1), built the way java.util.Random.nextDouble
+ * builds it from next(26) and next(27): ((a26 << 27) + b27) * 2^-53. */
+static inline double bits_to_double(uint32_t wa, uint32_t wb) {
+  uint64_t a = wa >> 6, b = wb >> 5;
+  return (double)((a << 27) + b) * 0x1.0p-53;
+}
+
+/* ------------------------------------------------------------------------ */
+/* java.util.Random (used only for the seeded initial z, UPLDA:458-460)      */
+/* ------------------------------------------------------------------------ */
+typedef struct { uint64_t seed; } jrandom;
+static const uint64_t JR_MULT = 0x5DEECE66DULL, JR_MASK = (1ULL << 48) - 1;
+static void jr_init(jrandom *r, int64_t seed) { r->seed = ((uint64_t)seed ^ JR_MULT) & JR_MASK; }
+static int32_t jr_next(jrandom *r, int bits) {
+  r->seed = (r->seed * JR_MULT + 0xBULL) & JR_MASK;
+  return (int32_t)(int64_t)(r->seed >> (48 - bits)); /* (int)(seed >>> (48-bits)) */
+}
+static int32_t jr_next_int_bound(jrandom *r, int32_t bound) {
+  int32_t rr = jr_next(r, 31);
+  int32_t m = bound - 1;
+  if ((bound & m) == 0) {
+    rr = (int32_t)(((int64_t)bound * (int64_t)rr) >> 31);
+  } else {
+    /* for (int u = r; u - (r = u % bound) + m < 0; u = next(31)); with int wrap */
+    int32_t u = rr;
+    for (;;) {
+      rr = u % bound;
+      int32_t t = (int32_t)((uint32_t)u - (uint32_t)rr + (uint32_t)m);
+      if (t >= 0) break;
+      u = jr_next(r, 31);
+    }
+  }
+  return rr;
+}
+static double jr_next_double(jrandom *r) {
+  int64_t a = jr_next(r, 26), b = jr_next(r, 27);
+  return (double)((a << 27) + b) * 0x1.0p-53;
+}
+void orc_jrandom_next_ints(int64_t seed, int32_t bound, int64_t n, int32_t *out) {
+  jrandom r; jr_init(&r, seed);
+  for (int64_t i = 0; i < n; i++) out[i] = jr_next_int_bound(&r, bound);
+}
+void orc_jrandom_next_int_raw(int64_t seed, int64_t n, int32_t *out) {
+  jrandom r; jr_init(&r, seed);
+  for (int64_t i = 0; i < n; i++) out[i] = jr_next(&r, 32);
+}
+void orc_jrandom_next_doubles(int64_t seed, int64_t n, double *out) {
+  jrandom r; jr_init(&r, seed);
+  for (int64_t i = 0; i < n; i++) out[i] = jr_next_double(&r);
+}
+
+/* ------------------------------------------------------------------------ */
+/* fdlibm e_log.c / e_pow.c (what StrictMath.log / StrictMath.pow compute)   */
+/* ------------------------------------------------------------------------ */
+static inline int32_t hi_word(double x) { uint64_t u; memcpy(&u, &x, 8); return (int32_t)(u >> 32); }
+static inline uint32_t lo_word(double x) { uint64_t u; memcpy(&u, &x, 8); return (uint32_t)u; }
+static inline double with_hi(double x, int32_t hi) {
+  uint64_t u; memcpy(&u, &x, 8); u = ((uint64_t)(uint32_t)hi << 32) | (u & 0xffffffffULL);
+  memcpy(&x, &u, 8); return x;
+}
+static inline double with_lo(double x, uint32_t lo) {
+  uint64_t u; memcpy(&u, &x, 8); u = (u & 0xffffffff00000000ULL) | lo;
+  memcpy(&x, &u, 8); return x;
+}
+
+double orc_log(double x) {
+  static const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10,
+                      two54 = 1.80143985094819840000e+16,
+                      Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                      Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                      Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                      Lg7 = 1.479819860511658591e-01;
+  double hfsq, f, s, z, R, w, t1, t2, dk;
+  int32_t k, hx, i, j;
+  uint32_t lx;
+  hx = hi_word(x); lx = lo_word(x);
+  k = 0;
+  if (hx < 0x00100000) {                 /* x < 2**-1022 */
+    if (((hx & 0x7fffffff) | lx) == 0) return -INFINITY; /* log(+-0) = -inf */
+    if (hx < 0) return NAN;              /* log(-#) = NaN */
+    k -= 54; x *= two54;                 /* subnormal: scale up */
+    hx = hi_word(x);
+  }
+  if (hx >= 0x7ff00000) return x + x;
+  k += (hx >> 20) - 1023;
+  hx &= 0x000fffff;
+  i = (hx + 0x95f64) & 0x100000;
+  x = with_hi(x, hx | (i ^ 0x3ff00000)); /* normalize x or x/2 */
+  k += (i >> 20);
+  f = x - 1.0;
+  if ((0x000fffff & (2 + hx)) < 3) {     /* |f| < 2**-20 */
+    if (f == 0.0) {
+      if (k == 0) return 0.0;
+      dk = (double)k; return dk * ln2_hi + dk * ln2_lo;
+    }
+    R = f * f * (0.5 - 0.33333333333333333 * f);
+    if (k == 0) return f - R;
+    dk = (double)k; return dk * ln2_hi - ((R - dk * ln2_lo) - f);
+  }
+  s = f / (2.0 + f);
+  dk = (double)k;
+  z = s * s;
+  i = hx - 0x6147a;
+  w = z * z;
+  j = 0x6b851 - hx;
+  t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+  t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+  i |= j;
+  R = t2 + t1;
+  if (i > 0) {
+    hfsq = 0.5 * f * f;
+    if (k == 0) return f - (hfsq - s * (hfsq + R));
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+  } else {
+    if (k == 0) return f - s * (f - R);
+    return dk * ln2_hi - ((s * (f - R) - dk * ln2_lo) - f);
+  }
+}
+
+/* fdlibm s_scalbn.c, reduced to the finite-input case e_pow.c needs */
+static double fd_scalbn(double x, int n) {
+  static const double two54 = 1.80143985094819840000e+16, twom54 = 5.55111512312578270212e-17,
+                      huge = 1.0e+300, tiny = 1.0e-300;
+  int32_t k, hx = hi_word(x);
+  uint32_t lx = lo_word(x);
+  k = (hx & 0x7ff00000) >> 20;
+  if (k == 0) {
+    if ((lx | (hx & 0x7fffffff)) == 0) return x;
+    x *= two54; hx = hi_word(x);
+    k = ((hx & 0x7ff00000) >> 20) - 54;
+    if (n < -50000) return tiny * x;
+  }
+  if (k == 0x7ff) return x + x;
+  k = k + n;
+  if (k > 0x7fe) return huge * copysign(huge, x);
+  if (k > 0) return with_hi(x, (hx & (int32_t)0x800fffff) | (k << 20));
+  if (k <= -54) {
+    if (n > 50000) return huge * copysign(huge, x);
+    return tiny * copysign(tiny, x);
+  }
+  k += 54;
+  x = with_hi(x, (hx & (int32_t)0x800fffff) | (k << 20));
+  return x * twom54;
+}
+
+/* e_pow.c for the domain the sampler uses: x >= +0 finite, y finite.
+ * (ParallelRandoms.java:66 calls Math.pow(u, 1.0/alpha) with u in [0,1),
+ * alpha in (0,1).)  Negative x, NaN and infinities are outside that domain and
+ * return NaN here. */
+double orc_pow(double x, double y) {
+  static const double bp[2] = {1.0, 1.5},
+      dp_h[2] = {0.0, 5.84962487220764160156e-01}, dp_l[2] = {0.0, 1.35003920212974897128e-08},
+      two53 = 9007199254740992.0, huge = 1.0e300, tiny = 1.0e-300,
+      L1 = 5.99999999999994648725e-01, L2 = 4.28571428578550184252e-01,
+      L3 = 3.33333329818377432918e-01, L4 = 2.72728123808534006489e-01,
+      L5 = 2.30660745775561754067e-01, L6 = 2.06975017800338417784e-01,
+      P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03,
+      P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06,
+      P5 = 4.13813679705723846039e-08,
+      lg2 = 6.93147180559945286227e-01, lg2_h = 6.93147182464599609375e-01,
+      lg2_l = -1.90465429995776804525e-09, ovt = 8.0085662595372944372e-0017,
+      cp = 9.61796693925975554329e-01, cp_h = 9.61796700954437255859e-01,
+      cp_l = -7.02846165095275826516e-09, ivln2 = 1.44269504088896338700e+00,
+      ivln2_h = 1.44269502162933349609e+00, ivln2_l = 1.92596299112661746887e-08;
+  double z, ax, z_h, z_l, p_h, p_l, y1, t1, t2, r, t, u, v, w;
+  int32_t i, j, k, n, hx, hy, ix, iy;
+  uint32_t lx, ly;
+  hx = hi_word(x); lx = lo_word(x);
+  hy = hi_word(y); ly = lo_word(y);
+  ix = hx & 0x7fffffff; iy = hy & 0x7fffffff;
+  if ((iy | ly) == 0) return 1.0;                     /* x**0 = 1 */
+  if (hx < 0 || ix >= 0x7ff00000 || iy >= 0x7ff00000) return NAN; /* outside domain */
+  if ((ix | lx) == 0) return (hy < 0) ? INFINITY : 0.0; /* (+0)**y */
+  if (ix == 0x3ff00000 && lx == 0) return 1.0;        /* 1**y */
+  if (hy == 0x3ff00000 && ly == 0) return x;          /* x**1 */
+  ax = x;
+  if (iy > 0x41e00000) {                              /* |y| > 2**31 */
+    if (iy > 0x43f00000) {                            /* |y| > 2**64: must o/uflow */
+      if (ix <= 0x3fefffff) return (hy < 0) ? huge * huge : tiny * tiny;
+      if (ix >= 0x3ff00000) return (hy > 0) ? huge * huge : tiny * tiny;
+    }
+    if (ix < 0x3fefffff) return (hy < 0) ? huge * huge : tiny * tiny;
+    if (ix > 0x3ff00000) return (hy > 0) ? huge * huge : tiny * tiny;
+    t = ax - 1.0;                                     /* |1-x| tiny */
+    w = (t * t) * (0.5 - t * (0.3333333333333333333333 - t * 0.25));
+    u = ivln2_h * t;
+    v = t * ivln2_l - w * ivln2;
+    t1 = u + v;
+    t1 = with_lo(t1, 0);
+    t2 = v - (t1 - u);
+  } else {
+    double ss, s2, s_h, s_l, t_h, t_l;
+    n = 0;
+    if (ix < 0x00100000) { ax *= two53; n -= 53; ix = hi_word(ax); }
+    n += ((ix) >> 20) - 0x3ff;
+    j = ix & 0x000fffff;
+    ix = j | 0x3ff00000;
+    if (j <= 0x3988E) k = 0;
+    else if (j < 0xBB67A) k = 1;
+    else { k = 0; n += 1; ix -= 0x00100000; }
+    ax = with_hi(ax, ix);
+    u = ax - bp[k];
+    v = 1.0 / (ax + bp[k]);
+    ss = u * v;
+    s_h = ss;
+    s_h = with_lo(s_h, 0);
+    t_h = 0.0;
+    t_h = with_hi(t_h, ((ix >> 1) | 0x20000000) + 0x00080000 + (k << 18));
+    t_l = ax - (t_h - bp[k]);
+    s_l = v * ((u - s_h * t_h) - s_h * t_l);
+    s2 = ss * ss;
+    r = s2 * s2 * (L1 + s2 * (L2 + s2 * (L3 + s2 * (L4 + s2 * (L5 + s2 * L6)))));
+    r += s_l * (s_h + ss);
+    s2 = s_h * s_h;
+    t_h = 3.0 + s2 + r;
+    t_h = with_lo(t_h, 0);
+    t_l = r - ((t_h - 3.0) - s2);
+    u = s_h * t_h;
+    v = s_l * t_h + t_l * ss;
+    p_h = u + v;
+    p_h = with_lo(p_h, 0);
+    p_l = v - (p_h - u);
+    z_h = cp_h * p_h;
+    z_l = cp_l * p_h + p_l * cp + dp_l[k];
+    t = (double)n;
+    t1 = (((z_h + z_l) + dp_h[k]) + t);
+    t1 = with_lo(t1, 0);
+    t2 = z_l - (((t1 - t) - dp_h[k]) - z_h);
+  }
+  y1 = y;
+  y1 = with_lo(y1, 0);
+  p_l = (y - y1) * t1 + y * t2;
+  p_h = y1 * t1;
+  z = p_l + p_h;
+  j = hi_word(z); i = (int32_t)lo_word(z);
+  if (j >= 0x40900000) {                              /* z >= 1024 */
+    if (((j - 0x40900000) | i) != 0) return huge * huge;
+    if (p_l + ovt > z - p_h) return huge * huge;
+  } else if ((j & 0x7fffffff) >= 0x4090cc00) {        /* z <= -1075 */
+    if (((j - (int32_t)0xc090cc00) | i) != 0) return tiny * tiny;
+    if (p_l <= z - p_h) return tiny * tiny;
+  }
+  i = j & 0x7fffffff;
+  k = (i >> 20) - 0x3ff;
+  n = 0;
+  if (i > 0x3fe00000) {                               /* |z| > 0.5: n = [z+0.5] */
+    n = j + (0x00100000 >> (k + 1));
+    k = ((n & 0x7fffffff) >> 20) - 0x3ff;
+    t = 0.0;
+    t = with_hi(t, n & ~(0x000fffff >> k));
+    n = ((n & 0x000fffff) | 0x00100000) >> (20 - k);
+    if (j < 0) n = -n;
+    p_h -= t;
+  }
+  t = p_l + p_h;
+  t = with_lo(t, 0);
+  u = t * lg2_h;
+  v = (p_l - (t - p_h)) * lg2 + t * lg2_l;
+  z = u + v;
+  w = v - (z - u);
+  t = z * z;
+  t1 = z - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+  r = (z * t1) / (t1 - 2.0) - (w + z * w);
+  z = 1.0 - (r - z);
+  j = hi_word(z);
+  j += (int32_t)((uint32_t)n << 20);
+  if ((j >> 20) <= 0) z = fd_scalbn(z, n);            /* subnormal output */
+  else z = with_hi(z, j);
+  return z;
+}
+
+void orc_log_array(int64_t n, const double *x, double *out) {
+  for (int64_t i = 0; i < n; i++) out[i] = orc_log(x[i]);
+}
+void orc_pow_array(int64_t n, const double *x, const double *y, double *out) {
+  for (int64_t i = 0; i < n; i++) out[i] = orc_pow(x[i], y[i]);
+}
+
+/* ------------------------------------------------------------------------ */
+/* Per-draw random stream with java.util.Random's nextDouble / nextGaussian  */
+/* semantics on top of Philox blocks                                          */
+/* ------------------------------------------------------------------------ */
+typedef struct {
+  uint32_t key[2];
+  uint32_t ctr0, ctr1, ctr2_base, ctr3;
+  uint32_t pos;         /* doubles consumed so far */
+  int32_t cached_block; /* -1 = none */
+  double buf[2];
+  int have_next_gaussian;
+  double next_gaussian;
+  int exhausted;
+} draw_rng;
+
+static void draw_init(draw_rng *r, uint64_t seed, uint32_t iter, uint32_t purpose, uint64_t elem) {
+  r->key[0] = (uint32_t)seed; r->key[1] = (uint32_t)(seed >> 32);
+  r->ctr0 = (uint32_t)elem; r->ctr1 = (uint32_t)(elem >> 32);
+  r->ctr2_base = purpose << 24; r->ctr3 = iter;
+  r->pos = 0; r->cached_block = -1; r->have_next_gaussian = 0; r->next_gaussian = 0.0;
+  r->exhausted = 0;
+}
+static double draw_next_double(draw_rng *r) {
+  uint32_t blk = r->pos >> 1;
+  if (blk >= ORC_MAX_BLOCKS) { r->exhausted = 1; return 0.5; }
+  if ((int32_t)blk != r->cached_block) {
+    uint32_t c[4] = {r->ctr0, r->ctr1, r->ctr2_base | blk, r->ctr3}, o[4];
+    orc_philox4x32_10(c, r->key, o);
+    r->buf[0] = bits_to_double(o[0], o[1]);
+    r->buf[1] = bits_to_double(o[2], o[3]);
+    r->cached_block = (int32_t)blk;
+  }
+  double d = r->buf[r->pos & 1];
+  r->pos++;
+  return d;
+}
+/* java.util.Random.nextGaussian (JDK 8): polar method, second value cached */
+static double draw_next_gaussian(draw_rng *r) {
+  if (r->have_next_gaussian) { r->have_next_gaussian = 0; return r->next_gaussian; }
+  double v1, v2, s;
+  do {
+    v1 = 2 * draw_next_double(r) - 1;
+    v2 = 2 * draw_next_double(r) - 1;
+    s = v1 * v1 + v2 * v2;
+    if (r->exhausted) return 0.0;
+  } while (s >= 1 || s == 0);
+  double multiplier = sqrt(-2 * orc_log(s) / s);
+  r->next_gaussian = v2 * multiplier;
+  r->have_next_gaussian = 1;
+  return v1 * multiplier;
+}
+
+/* ParallelRandoms.java:148-159 prgamma(alpha) */
+static double prgamma(draw_rng *r, double alpha) {
+  double x, v, u;
+  double d = alpha - (1.0 / 3.0);
+  double c = 1.0 / sqrt(9.0 * d);
+  for (;;) {
+    do {
+      x = draw_next_gaussian(r);
+      v = 1.0 + c * x;
+      if (r->exhausted) return NAN;
+    } while (v <= 0.0);
+    v = v * v * v;
+    u = draw_next_double(r);
+    if (u < (1.0 - 0.0331 * (x * x) * (x * x))) return (d * v);
+    if (orc_log(u) < (0.5 * x * x + d * (1.0 - v + orc_log(v)))) return (d * v);
+    if (r->exhausted) return NAN;
+  }
+}
+/* ParallelRandoms.java:60-70 rgamma(alpha, beta=1, lambda=0).  The trailing
+ * "*beta + lambda" with beta=1, lambda=0 is the identity on non-negative
+ * doubles and is kept for the record. */
+static double rgamma(draw_rng *r, double alpha) {
+  if (alpha < 1) {
+    double u = draw_next_double(r);
+    return ((prgamma(r, 1 + alpha) * orc_pow(u, 1.0 / alpha)) * 1.0) + 0.0;
+  }
+  return (prgamma(r, alpha) * 1.0) + 0.0;
+}
+
+void orc_uniform_array(uint64_t seed, uint32_t iter, uint32_t purpose, uint64_t elem0, int64_t n,
+                       double *out) {
+  for (int64_t i = 0; i < n; i++) {
+    draw_rng r; draw_init(&r, seed, iter, purpose, elem0 + (uint64_t)i);
+    out[i] = draw_next_double(&r);
+  }
+}
+void orc_gaussian_array(uint64_t seed, uint32_t iter, uint32_t purpose, uint64_t elem0, int64_t n,
+                        double *out) {
+  for (int64_t i = 0; i < n; i++) {
+    draw_rng r; draw_init(&r, seed, iter, purpose, elem0 + (uint64_t)i);
+    out[i] = draw_next_gaussian(&r);
+  }
+}
+int orc_gamma_array(uint64_t seed, uint32_t iter, uint32_t purpose, uint64_t elem0, int64_t n,
+                    const double *shape, double *out) {
+  int err = ORC_OK;
+  for (int64_t i = 0; i < n; i++) {
+    if (!(shape[i] > 0)) { out[i] = NAN; err = ORC_ERR_BAD_ARG; continue; }
+    draw_rng r; draw_init(&r, seed, iter, purpose, elem0 + (uint64_t)i);
+    out[i] = rgamma(&r, shape[i]);
+    if (r.exhausted) err = ORC_ERR_RNG_EXHAUSTED;
+  }
+  return err;
+}
+
+/* cc.mallet.types.Dirichlet(double[] p) + ParallelDirichlet.nextDistribution()
+ * (ParallelDirichlet.java:46-70).  Element i of the draw uses RNG element
+ * elem0 + i. */
+int orc_dirichlet(uint64_t seed, uint32_t iter, uint32_t purpose, uint64_t elem0, int64_t n,
+                  const double *p, double *out) {
+  double magnitude = 0;
+  for (int64_t i = 0; i < n; i++) magnitude += p[i];
+  int err = ORC_OK;
+  double sum = 0;
+  for (int64_t i = 0; i < n; i++) {
+    double partition = p[i] / magnitude;
+    double a = partition * magnitude;
+    if (!(a > 0)) { out[i] = NAN; err = ORC_ERR_BAD_ARG; continue; }
+    draw_rng r; draw_init(&r, seed, iter, purpose, elem0 + (uint64_t)i);
+    out[i] = rgamma(&r, a);
+    if (r.exhausted) err = ORC_ERR_RNG_EXHAUSTED;
+    sum += out[i];
+  }
+  if (sum != 0) {
+    for (int64_t i = 0; i < n; i++) {
+      out[i] /= sum;
+      if (out[i] <= 0) out[i] = 4.9e-324; /* Double.MIN_VALUE */
+    }
+  }
+  return err;
+}
+
+/* ------------------------------------------------------------------------ */
+/* Sampler state                                                             */
+/* ------------------------------------------------------------------------ */
+struct orc_state {
+  int32_t K, V;
+  int64_t D, N;
+  double *alpha; double beta;
+  uint64_t seed;
+  int64_t doc_base, tok_base;
+  int64_t *doc_ptr; int32_t *tokens; int32_t *z;
+  double *phi;        /* [K][V]  UPLDA:69  */
+  int32_t *n_kw;      /* topicTypeCountMapping [K][V]  UPLDA:108 */
+  int32_t *n_wk;      /* typeTopicCounts [V][K]        MSLDA:73  */
+  int32_t *n_k;       /* tokensPerTopic [K]            MSLDA:74  */
+  int32_t *delta;     /* batchLocalTopicTypeUpdates [K][V] UPLDA:102 */
+  double *theta;      /* thetaMatrix rows [D][K]  GGS:72 */
+  double *phi_mean; int32_t n_sampled_phi;
+  int save_phi_mean, phi_burn_in, phi_thin;
+  int32_t iteration;  /* currentIteration */
+  int threads;
+  jrandom collapsed_rng; int collapsed_rng_ready;
+  char err[256];
+};
+
+static int fail(orc_state *s, int code, const char *msg) {
+#pragma omp critical(orc_err)
+  { if (!s->err[0]) snprintf(s->err, sizeof s->err, "%s", msg); }
+  return code;
+}
+const char *orc_last_error(const orc_state *s) { return s->err; }
+
+orc_state *orc_create(int32_t K, int32_t V, const double *alpha, double beta, uint64_t seed) {
+  if (K <= 0 || V <= 0) return NULL;
+  orc_state *s = calloc(1, sizeof *s);
+  s->K = K; s->V = V; s->beta = beta; s->seed = seed;
+  s->alpha = malloc(sizeof(double) * K);
+  memcpy(s->alpha, alpha, sizeof(double) * K);
+  size_t kv = (size_t)K * V;
+  s->phi = calloc(kv, sizeof(double));
+  s->n_kw = calloc(kv, sizeof(int32_t));
+  s->n_wk = calloc(kv, sizeof(int32_t));
+  s->delta = calloc(kv, sizeof(int32_t));
+  s->n_k = calloc(K, sizeof(int32_t));
+  s->phi_thin = 1; s->threads = 1;
+  return s;
+}
+void orc_destroy(orc_state *s) {
+  if (!s) return;
+  free(s->alpha); free(s->phi); free(s->n_kw); free(s->n_wk); free(s->delta); free(s->n_k);
+  free(s->doc_ptr); free(s->tokens); free(s->z); free(s->theta); free(s->phi_mean);
+  free(s);
+}
+int orc_set_corpus(orc_state *s, int64_t D, const int64_t *doc_ptr, const int32_t *tokens,
+                   int64_t doc_base, int64_t tok_base) {
+  if (D < 0 || doc_ptr[0] != 0) return fail(s, ORC_ERR_BAD_ARG, "bad corpus");
+  int64_t N = doc_ptr[D];
+  for (int64_t i = 0; i < N; i++)
+    if (tokens[i] < 0 || tokens[i] >= s->V) return fail(s, ORC_ERR_BAD_ARG, "token id out of range");
+  free(s->doc_ptr); free(s->tokens); free(s->z); free(s->theta);
+  s->D = D; s->N = N; s->doc_base = doc_base; s->tok_base = tok_base;
+  s->doc_ptr = malloc(sizeof(int64_t) * (D + 1));
+  memcpy(s->doc_ptr, doc_ptr, sizeof(int64_t) * (D + 1));
+  s->tokens = malloc(sizeof(int32_t) * (N ? N : 1));
+  memcpy(s->tokens, tokens, sizeof(int32_t) * N);
+  s->z = calloc(N ? N : 1, sizeof(int32_t));
+  s->theta = calloc((size_t)(D ? D : 1) * s->K, sizeof(double));
+  return ORC_OK;
+}
+void orc_set_phi_mean_gating(orc_state *s, int save, int burn_in, int thin) {
+  s->save_phi_mean = save; s->phi_burn_in = burn_in; s->phi_thin = thin;
+  if (save && !s->phi_mean) s->phi_mean = calloc((size_t)s->K * s->V, sizeof(double));
+}
+void orc_set_threads(orc_state *s, int threads) { s->threads = threads > 0 ? threads : 1; }
+void orc_set_iteration(orc_state *s, int32_t it) { s->iteration = it; }
+int32_t orc_get_iteration(const orc_state *s) { return s->iteration; }
+int64_t orc_num_tokens(const orc_state *s) { return s->N; }
+
+/* UPLDA:471-482 updateTypeTopicCount */
+static int update_type_topic_count(orc_state *s, int32_t type, int32_t topic, int32_t count) {
+  s->n_kw[(size_t)topic * s->V + type] += count;
+  s->n_wk[(size_t)type * s->K + topic] += count;
+  s->n_k[topic] += count;
+  if (s->n_kw[(size_t)topic * s->V + type] < 0) return fail(s, ORC_ERR_NEGATIVE_COUNT, "Negative count for topic");
+  return ORC_OK;
+}
+static void zero_counts(orc_state *s) {
+  size_t kv = (size_t)s->K * s->V;
+  memset(s->n_kw, 0, kv * 4); memset(s->n_wk, 0, kv * 4); memset(s->delta, 0, kv * 4);
+  memset(s->n_k, 0, (size_t)s->K * 4);
+}
+
+/* UPLDA:1287-1294 initialSamplePhi -> MarsagliaSparseDirichlet.nextDistribution(int[])
+ * (MarsagliaSparseDirichlet.java:31-55) built by Dirichlet(int size, double beta):
+ * magnitude = V*beta, partition[i] = 1.0/V. */
+int orc_init_phi(orc_state *s) {
+  int err = ORC_OK;
+  const double magnitude = (double)s->V * s->beta;
+  const double partition = 1.0 / (double)s->V;
+#pragma omp parallel for num_threads(s->threads) schedule(static)
+  for (int32_t k = 0; k < s->K; k++) {
+    double *row = s->phi + (size_t)k * s->V;
+    const int32_t *cnt = s->n_kw + (size_t)k * s->V;
+    double sum = 0;
+    for (int32_t v = 0; v < s->V; v++) {
+      double a = (cnt[v] == 0) ? (partition * magnitude) : ((partition * magnitude) + cnt[v]);
+      draw_rng r; draw_init(&r, s->seed, (uint32_t)s->iteration, ORC_PURPOSE_INIT_PHI, (uint64_t)k * s->V + v);
+      row[v] = (a > 0) ? rgamma(&r, a) : NAN;
+      if (r.exhausted || !(a > 0)) {
+#pragma omp atomic write
+        err = ORC_ERR_RNG_EXHAUSTED;
+      }
+      sum += row[v];
+    }
+    if (sum != 0)
+      for (int32_t v = 0; v < s->V; v++) { row[v] /= sum; if (row[v] <= 0) row[v] = 4.9e-324; }
+  }
+  if (err) return fail(s, err, "gamma draw failed in init phi");
+  return ORC_OK;
+}
+
+/* UPLDA:398-406,458-460: z0 = Randoms(seed).nextInt(K) in (doc, position) order */
+int orc_init_z_java_lcg(orc_state *s, int32_t seed) {
+  if (s->tok_base != 0) return fail(s, ORC_ERR_BAD_ARG, "java-LCG init needs the whole corpus (sequential stream)");
+  zero_counts(s);
+  jrandom r; jr_init(&r, (int64_t)seed);
+  for (int64_t d = 0; d < s->D; d++)
+    for (int64_t i = s->doc_ptr[d]; i < s->doc_ptr[d + 1]; i++) {
+      int32_t topic = jr_next_int_bound(&r, s->K);
+      s->z[i] = topic;
+      int e = update_type_topic_count(s, s->tokens[i], topic, 1);
+      if (e) return e;
+    }
+  return ORC_OK;
+}
+/* UPLDA:1797-1843 setZIndicators */
+int orc_set_z(orc_state *s, const int32_t *z, int redraw_phi) {
+  zero_counts(s);
+  for (int64_t i = 0; i < s->N; i++) {
+    if (z[i] < 0 || z[i] >= s->K) return fail(s, ORC_ERR_BAD_ARG, "z out of range");
+    s->z[i] = z[i];
+    int e = update_type_topic_count(s, s->tokens[i], z[i], 1);
+    if (e) return e;
+  }
+  return redraw_phi ? orc_init_phi(s) : ORC_OK;
+}
+
+/* GGS:47-132 sampleTopicAssignmentsParallel for local doc d */
+static int ggs_doc_step(orc_state *s, int64_t d, int32_t *localTopicCounts, double *thetaParameter,
+                        double *theta, double *topicTermScores) {
+  const int32_t K = s->K, V = s->V;
+  const int64_t b = s->doc_ptr[d], e = s->doc_ptr[d + 1];
+  const int64_t docLength = e - b;
+  if (docLength == 0) return ORC_OK;                          /* GGS:52-53 */
+  const int32_t *tokenSequence = s->tokens + b;
+  int32_t *oneDocTopics = s->z + b;
+  memset(localTopicCounts, 0, sizeof(int32_t) * K);
+  for (int64_t position = 0; position < docLength; position++)  /* GGS:60-63 */
+    localTopicCounts[oneDocTopics[position]]++;
+  for (int32_t topic = 0; topic < K; topic++)                   /* GGS:66-69 */
+    thetaParameter[topic] = localTopicCounts[topic] + s->alpha[topic];
+  int err = orc_dirichlet(s->seed, (uint32_t)s->iteration, ORC_PURPOSE_THETA, /* GGS:70-71 */
+                          (uint64_t)(s->doc_base + d) * (uint64_t)K, K, thetaParameter, theta);
+  if (err) return fail(s, err, "theta draw failed");
+  memcpy(s->theta + (size_t)d * K, theta, sizeof(double) * K);   /* GGS:72 */
+
+  for (int64_t position = 0; position < docLength; position++) { /* GGS:79-130 */
+    int32_t type = tokenSequence[position];
+    int32_t oldTopic = oneDocTopics[position];
+    localTopicCounts[oldTopic]--;
+    if (localTopicCounts[oldTopic] < 0) return fail(s, ORC_ERR_NEGATIVE_COUNT, "Invalid count!");
+#pragma omp atomic
+    s->delta[(size_t)oldTopic * V + type] -= 1;                  /* decrement(), UPLDA:1553-1556 */
+    double sum = 0.0;
+    for (int32_t topic = 0; topic < K; topic++) {                /* GGS:96-101 */
+      double score = theta[topic] * s->phi[(size_t)topic * V + type];
+      topicTermScores[topic] = score;
+      sum += score;
+    }
+    draw_rng r; draw_init(&r, s->seed, (uint32_t)s->iteration, ORC_PURPOSE_Z, (uint64_t)(s->tok_base + b + position));
+    double U = draw_next_double(&r);                             /* GGS:107 */
+    double sample = U * sum;
+    int32_t newTopic = -1;
+    while (sample > 0.0) {                                       /* GGS:110-113 */
+      newTopic++;
+      if (newTopic >= K) break;   /* Java: ArrayIndexOutOfBoundsException */
+      sample -= topicTermScores[newTopic];
+    }
+    if (newTopic < 0 || newTopic >= K) {                         /* GGS:116-118 */
+      /* keep memory safe, then report like the Java throw */
+      newTopic = newTopic < 0 ? 0 : K - 1;
+      oneDocTopics[position] = newTopic;
+      localTopicCounts[newTopic]++;
+#pragma omp atomic
+      s->delta[(size_t)newTopic * V + type] += 1;
+      return fail(s, ORC_ERR_INVALID_TOPIC, "Topic sampled is invalid!");
+    }
+    oneDocTopics[position] = newTopic;
+    localTopicCounts[newTopic]++;
+#pragma omp atomic
+    s->delta[(size_t)newTopic * V + type] += 1;                  /* increment(), UPLDA:1547-1551 */
+  }
+  return ORC_OK;
+}
+
+/* UPLDA:1434-1437 loopOverBatches: the fork-join halving down to
+ * document_sampler_split_limit (100) docs is restated as dynamic chunks of 100
+ * documents; every result is schedule-independent because the RNG is
+ * counter-based. */
+int orc_z_step(orc_state *s) {
+  int err = ORC_OK;
+  const int32_t K = s->K;
+#pragma omp parallel num_threads(s->threads)
+  {
+    /* per-document allocations of GGS:57,66,76 hoisted per thread */
+    int32_t *ltc = malloc(sizeof(int32_t) * K);
+    double *tp = malloc(sizeof(double) * K), *th = malloc(sizeof(double) * K), *sc = malloc(sizeof(double) * K);
+#pragma omp for schedule(dynamic, 100)
+    for (int64_t d = 0; d < s->D; d++) {
+      int e = ggs_doc_step(s, d, ltc, tp, th, sc);
+      if (e) {
+#pragma omp atomic write
+        err = e;
+      }
+    }
+    free(ltc); free(tp); free(th); free(sc);
+  }
+  return err;
+}
+
+/* UPLDA:1107-1138 -> updateTopics :1203-1221 -> ParallelTopicUpdater.call :1158-1182 */
+int orc_update_counts(orc_state *s) {
+  int err = ORC_OK;
+  const int32_t K = s->K, V = s->V;
+  int thr = s->threads < 2 ? s->threads : 2;   /* topicUpdaters pool = 2 threads, UPLDA:1085 */
+#pragma omp parallel for num_threads(thr) schedule(dynamic, 1)
+  for (int32_t topic = 0; topic < K; topic++) {
+    for (int32_t type = 0; type < V; type++) {
+      int32_t dlt = s->delta[(size_t)topic * V + type];
+      if (dlt != 0) {
+        s->delta[(size_t)topic * V + type] = 0;
+        s->n_kw[(size_t)topic * V + type] += dlt;
+        s->n_wk[(size_t)type * K + topic] += dlt;
+        s->n_k[topic] += dlt;
+        if (s->n_kw[(size_t)topic * V + type] < 0) {
+#pragma omp atomic write
+          err = ORC_ERR_NEGATIVE_COUNT;
+        }
+      }
+    }
+  }
+  if (err) return fail(s, err, "Negative count for topic");
+  return ORC_OK;
+}
+
+/* UPLDA:1350-1352 */
+static int sample_phi_this_iteration(const orc_state *s) {
+  return s->phi_burn_in > 0 && s->iteration > s->phi_burn_in && (s->iteration % s->phi_thin) == 0;
+}
+
+/* GGS:139-171 samplePhi + GGS:182-198 loopOverTopics */
+int orc_sample_phi(orc_state *s) {
+  int err = ORC_OK;
+  const int32_t K = s->K, V = s->V;
+  const int accumulate = s->save_phi_mean && sample_phi_this_iteration(s);
+#pragma omp parallel num_threads(s->threads)
+  {
+    double *dirichletParams = malloc(sizeof(double) * V);
+#pragma omp for schedule(dynamic, 1)
+    for (int32_t topic = 0; topic < K; topic++) {
+      const int32_t *relevantTypeTopicCounts = s->n_kw + (size_t)topic * V;
+      for (int32_t type = 0; type < V; type++)
+        dirichletParams[type] = s->beta + relevantTypeTopicCounts[type];
+      int e = orc_dirichlet(s->seed, (uint32_t)s->iteration, ORC_PURPOSE_PHI, (uint64_t)topic * V, V,
+                            dirichletParams, s->phi + (size_t)topic * V);
+      if (e) {
+#pragma omp atomic write
+        err = e;
+      }
+      if (accumulate)
+        for (int32_t v = 0; v < V; v++) s->phi_mean[(size_t)topic * V + v] += s->phi[(size_t)topic * V + v];
+    }
+    free(dirichletParams);
+  }
+  if (accumulate) s->n_sampled_phi++;     /* GGS:168-170 */
+  if (err) return fail(s, err, "phi draw failed");
+  return ORC_OK;
+}
+
+/* UPLDA:645-687: one iteration = loopOverBatches, updateCounts, samplePhi */
+int orc_sweep(orc_state *s, int32_t n_sweeps) {
+  for (int32_t it = 0; it < n_sweeps; it++) {
+    s->iteration++;                       /* currentIteration = iteration, UPLDA:646 */
+    int e = orc_z_step(s);      if (e) return e;
+    e = orc_update_counts(s);   if (e) return e;
+    e = orc_sample_phi(s);      if (e) return e;
+  }
+  return ORC_OK;
+}
+
+/* MSLDA:158-226 sampleTopicsForOneDoc, looped as SerialCollapsedLDA.sample does
+ * (SerialCollapsedLDA.java:159-172): strictly serial, one java.util.Random
+ * stream (MALLET Randoms.nextUniform() is restated as nextDouble(): ASSUMPTION
+ * flagged in SURVEY 8c). */
+int orc_collapsed_sweep(orc_state *s, int32_t seed_if_first, int32_t n_sweeps) {
+  const int32_t K = s->K, V = s->V;
+  if (!s->collapsed_rng_ready) { jr_init(&s->collapsed_rng, (int64_t)seed_if_first); s->collapsed_rng_ready = 1; }
+  int32_t *localTopicCounts = malloc(sizeof(int32_t) * K);
+  double *topicTermScores = malloc(sizeof(double) * K);
+  const double betaSum = s->beta * V;
+  int err = ORC_OK;
+  for (int32_t it = 0; it < n_sweeps && !err; it++) {
+    s->iteration++;
+    for (int64_t d = 0; d < s->D && !err; d++) {
+      const int64_t b = s->doc_ptr[d], docLength = s->doc_ptr[d + 1] - b;
+      memset(localTopicCounts, 0, sizeof(int32_t) * K);
+      for (int64_t p = 0; p < docLength; p++) localTopicCounts[s->z[b + p]]++;
+      for (int64_t p = 0; p < docLength; p++) {
+        int32_t type = s->tokens[b + p], oldTopic = s->z[b + p];
+        int32_t *currentTypeTopicCounts = s->n_wk + (size_t)type * K;
+        localTopicCounts[oldTopic]--;
+        s->n_k[oldTopic]--;
+        currentTypeTopicCounts[oldTopic]--;
+        s->n_kw[(size_t)oldTopic * V + type]--;
+        double sum = 0.0;
+        for (int32_t topic = 0; topic < K; topic++) {
+          double score = (s->alpha[topic] + localTopicCounts[topic]) *
+                         ((s->beta + currentTypeTopicCounts[topic]) / (betaSum + s->n_k[topic]));
+          sum += score;
+          topicTermScores[topic] = score;
+        }
+        double sample = jr_next_double(&s->collapsed_rng) * sum;
+        int32_t newTopic = -1;
+        while (sample > 0.0) { newTopic++; if (newTopic >= K) break; sample -= topicTermScores[newTopic]; }
+        if (newTopic < 0 || newTopic >= K) { err = fail(s, ORC_ERR_INVALID_TOPIC, "SimpleLDA: New topic not sampled."); newTopic = newTopic < 0 ? 0 : K - 1; }
+        s->z[b + p] = newTopic;
+        localTopicCounts[newTopic]++;
+        s->n_k[newTopic]++;
+        currentTypeTopicCounts[newTopic]++;
+        s->n_kw[(size_t)newTopic * V + type]++;
+      }
+    }
+  }
+  free(localTopicCounts); free(topicTermScores);
+  return err;
+}
+
+/* ------------------------------------------------------------------------ */
+/* getters (layouts of the Java getters: MSLDA:464-477, UPLDA:226-234, ...)  */
+/* ------------------------------------------------------------------------ */
+void orc_get_z(const orc_state *s, int32_t *z) { memcpy(z, s->z, sizeof(int32_t) * s->N); }
+void orc_get_type_topic_counts(const orc_state *s, int32_t *o) { memcpy(o, s->n_wk, sizeof(int32_t) * (size_t)s->K * s->V); }
+void orc_get_topic_type_counts(const orc_state *s, int32_t *o) { memcpy(o, s->n_kw, sizeof(int32_t) * (size_t)s->K * s->V); }
+void orc_get_topic_totals(const orc_state *s, int32_t *o) { memcpy(o, s->n_k, sizeof(int32_t) * s->K); }
+void orc_get_delta(const orc_state *s, int32_t *o) {
+  for (int32_t k = 0; k < s->K; k++)
+    for (int32_t v = 0; v < s->V; v++) o[(size_t)v * s->K + k] = s->delta[(size_t)k * s->V + v];
+}
+void orc_add_delta(orc_state *s, const int32_t *d) {
+  for (int32_t k = 0; k < s->K; k++)
+    for (int32_t v = 0; v < s->V; v++) s->delta[(size_t)k * s->V + v] += d[(size_t)v * s->K + k];
+}
+void orc_get_phi(const orc_state *s, double *o) { memcpy(o, s->phi, sizeof(double) * (size_t)s->K * s->V); }
+void orc_set_phi(orc_state *s, const double *p) { memcpy(s->phi, p, sizeof(double) * (size_t)s->K * s->V); }
+int orc_get_phi_mean(const orc_state *s, double *o) {
+  if (s->n_sampled_phi == 0 || !s->phi_mean) return 0;
+  size_t kv = (size_t)s->K * s->V;
+  for (size_t i = 0; i < kv; i++) o[i] = s->phi_mean[i] / s->n_sampled_phi; /* UPLDA:1959-1964 */
+  return s->n_sampled_phi;
+}
+void orc_get_theta(const orc_state *s, double *o) { memcpy(o, s->theta, sizeof(double) * (size_t)s->D * s->K); }
+void orc_get_doc_topic_counts(const orc_state *s, int32_t *o) {
+  memset(o, 0, sizeof(int32_t) * (size_t)s->D * s->K);
+  for (int64_t d = 0; d < s->D; d++)
+    for (int64_t i = s->doc_ptr[d]; i < s->doc_ptr[d + 1]; i++) o[(size_t)d * s->K + s->z[i]]++;
+}

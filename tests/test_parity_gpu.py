@@ -1,0 +1,333 @@
+"""GPU parity: the HIP path (through the C-ABI) against the CPU oracle, bit for bit.
+
+Bar: integer state (z, n_wk, n_k) identical; fp64 state (theta, phi, phi mean) identical
+to the last bit -- the kernels keep the Java operation order and are built with
+-ffp-contract=off, so no tolerance is needed or allowed.
+"""
+import numpy as np
+import pytest
+
+from ldagroupedgibbssampler_amd.corpus import even_split, random_corpus, synthetic_lda_corpus
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float64).view(np.int64)
+
+
+def assert_bit_equal(a, b, what):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape, what
+    if a.dtype.kind == "f":
+        bad = bits(a) != bits(b)
+        # NaN payloads aside, every bit must match
+        assert not bad.any(), "%s: %d of %d differ, first at %s: %r vs %r" % (
+            what, bad.sum(), bad.size, np.argwhere(bad)[0], a[bad][0], b[bad][0])
+    else:
+        assert np.array_equal(a, b), "%s differs in %d places" % (what, (a != b).sum())
+
+
+# ---------------------------------------------------------------- primitives
+def test_philox_device_matches_kat_and_oracle(native, oracle):
+    import json
+    import os
+    kat = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "kat_vectors.json")))
+    for v in kat["philox4x32_10"]:
+        out = native.debug_philox([v["ctr"]], [v["key"]])
+        assert [int(x) for x in out[0]] == v["out"]
+    rng = np.random.default_rng(0)
+    ctr = rng.integers(0, 2**32, (4096, 4), dtype=np.uint64).astype(np.uint32)
+    key = rng.integers(0, 2**32, (4096, 2), dtype=np.uint64).astype(np.uint32)
+    dev = native.debug_philox(ctr, key)
+    for i in range(0, 4096, 257):
+        assert [int(x) for x in dev[i]] == oracle.philox(ctr[i], key[i])
+
+
+def test_strict_math_device_bit_exact(native, oracle):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.random(200000), rng.random(50000) * 1e-9, np.exp(rng.uniform(-700, 700, 100000)),
+                        1 + rng.uniform(-1e-6, 1e-6, 20000), [1.0, 0.5, 2.0, 5e-324, 2.2250738585072014e-308, 1.7976931348623157e308]])
+    assert_bit_equal(native.debug_math("log", x), oracle.log(x), "StrictMath.log")
+    u = np.concatenate([rng.random(300000), [0.0, 1.0 - 2**-53, 2**-53, 0.5]])
+    y = 1.0 / np.concatenate([rng.uniform(1e-6, 1, 300000), [0.3, 0.3, 1e-9, 1e-3]])
+    assert_bit_equal(native.debug_math("pow", u, y), oracle.pow(u, y), "StrictMath.pow")
+    # sqrt and / must be the IEEE correctly rounded results the JVM gets
+    a = np.exp(rng.uniform(-300, 300, 200000))
+    b = np.exp(rng.uniform(-300, 300, 200000))
+    assert_bit_equal(native.debug_math("sqrt", a), np.sqrt(a), "sqrt")
+    assert_bit_equal(native.debug_math("div", a, b), a / b, "division")
+    sub = rng.random(10000) * 1e-310     # subnormal operands and results
+    assert_bit_equal(native.debug_math("div", sub, np.full(10000, 3.0)), sub / 3.0, "subnormal division")
+
+
+def test_draw_streams_bit_exact(native, oracle):
+    seed, it = 0xDEADBEEFCAFEF00D, 7
+    n = 100000
+    dev, st = native.debug_draw("uniform", seed, it, native.PURPOSE_Z, 2**40 + 5, n=n)
+    assert st == 0
+    assert_bit_equal(dev, oracle.uniforms(seed, it, oracle.PURPOSE_Z, 2**40 + 5, n), "uniform stream")
+    assert dev.min() >= 0 and dev.max() < 1
+    dev, st = native.debug_draw("gaussian", seed, it, native.PURPOSE_THETA, 123, n=n)
+    assert st == 0
+    assert_bit_equal(dev, oracle.gaussians(seed, it, oracle.PURPOSE_THETA, 123, n), "gaussian stream")
+    rng = np.random.default_rng(2)
+    shape = np.concatenate([rng.uniform(1e-3, 1, 60000), rng.uniform(1, 50, 60000), np.exp(rng.uniform(-14, 10, 60000)),
+                            [1.0, 1e-6, 0.01, 0.1, 5.0, 1e4]])
+    dev, st = native.debug_draw("gamma", seed, it, native.PURPOSE_PHI, 99, shape=shape)
+    assert st == 0
+    assert_bit_equal(dev, oracle.gammas(seed, it, oracle.PURPOSE_PHI, 99, shape), "Marsaglia-Tsang gamma")
+
+
+# ---------------------------------------------------------------- full path
+def make_pair(native, oracle, corpus, K, alpha, beta, seed, flags=0, burn_in=0, thin=1, zseed=None, doc_base=0, tok_base=0):
+    g = native.GGSHandle(K, corpus.num_types, alpha, beta, seed, flags=flags, phi_burn_in=burn_in, phi_mean_thin=thin)
+    o = oracle.OracleSampler(K, corpus.num_types, alpha, beta, seed, threads=4)
+    o.set_phi_mean_gating(bool(flags & native.FLAG_SAVE_PHI_MEAN), burn_in, thin)
+    g.set_corpus(corpus.doc_ptr, corpus.tokens, doc_base, tok_base)
+    o.set_corpus(corpus.doc_ptr, corpus.tokens, doc_base, tok_base)
+    if zseed is not None:
+        g.init_z_java_lcg(zseed)
+        o.init_z_java_lcg(zseed)
+        g.init_phi()
+        o.init_phi()
+    return g, o
+
+
+def compare_state(g, o, tag, theta=True):
+    assert_bit_equal(g.get_z(), o.get_z(), tag + " z")
+    assert_bit_equal(g.get_type_topic_counts(), o.get_type_topic_counts(), tag + " n_wk")
+    assert_bit_equal(g.get_topic_totals(), o.get_topic_totals(), tag + " n_k")
+    assert_bit_equal(g.get_phi(), o.get_phi(), tag + " phi")
+    if theta:
+        assert_bit_equal(g.get_theta(), o.get_theta(), tag + " theta")
+    assert_bit_equal(g.get_doc_topic_counts(), o.get_doc_topic_counts(), tag + " n_dk")
+
+
+@pytest.mark.parametrize("K", [3, 20])
+def test_cats_matches_oracle_and_golden(native, oracle, cats, K):
+    import os
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "cats_ggs_golden.npz"))
+    g, o = make_pair(native, oracle, cats, K, 5.0, 7.0, 2019, flags=native.FLAG_PARANOID, zseed=2019)
+    assert_bit_equal(g.get_z(), gold["K%d_z0" % K], "z0 vs golden")
+    compare_state(g, o, "cats K=%d init" % K, theta=False)
+    for it in range(3):
+        g.sweep(1)
+        o.sweep(1)
+        compare_state(g, o, "cats K=%d sweep %d" % (K, it + 1))
+    assert_bit_equal(g.get_z(), gold["K%d_z3" % K], "z3 vs golden")
+    assert_bit_equal(g.get_topic_totals(), gold["K%d_nk3" % K], "n_k vs golden")
+    assert_bit_equal(g.get_type_topic_counts(), gold["K%d_nwk3" % K], "n_wk vs golden")
+    assert_bit_equal(g.get_theta()[0], gold["K%d_theta3_doc0" % K], "theta doc0 vs golden")
+    assert_bit_equal(g.get_phi()[0, :8], gold["K%d_phi3_row0_head" % K], "phi head vs golden")
+    assert g.iteration == 3
+    g.check_invariants()
+
+
+@pytest.mark.parametrize("K,alpha,beta", [(1, 0.5, 0.1), (2, 0.1, 0.01), (7, 0.1, 0.01), (64, 0.05, 0.01), (65, 1.5, 0.5), (100, 0.1, 0.01),
+                                          (129, 0.1, 0.01)])
+def test_ragged_corpus_with_empty_documents(native, oracle, K, alpha, beta):
+    c = random_corpus(301, 500, 150, seed=K, empty_every=7)   # lengths 0..150: 1-, 2- and 3-chunk documents
+    g, o = make_pair(native, oracle, c, K, alpha, beta, 42 + K, flags=native.FLAG_PARANOID, zseed=K)
+    compare_state(g, o, "ragged K=%d init" % K, theta=False)
+    g.sweep(4)
+    o.sweep(4)
+    compare_state(g, o, "ragged K=%d" % K)
+
+
+def test_asymmetric_alpha_and_tiny_alpha(native, oracle):
+    K = 5
+    alphas = np.array([0.01, 5.0, 0.04, 0.1, 0.000001])    # ModifiedSimpleLDATest.java:12
+    c = random_corpus(64, 80, 40, seed=3)
+    g, o = make_pair(native, oracle, c, K, alphas, 0.01, 5, zseed=11)
+    g.sweep(5)
+    o.sweep(5)
+    compare_state(g, o, "asymmetric alpha")
+    th = g.get_theta()[np.diff(c.doc_ptr) > 0]     # empty documents draw no theta (GGS:52-53)
+    assert (th > 0).all()          # zero draws are clamped to Double.MIN_VALUE, never 0
+    assert (th == 4.9e-324).any()  # ... and alpha = 1e-6 does underflow in this corpus
+
+
+def test_edge_corpora(native, oracle):
+    # one document of one token; all-empty documents; a single long document (many chunks)
+    from ldagroupedgibbssampler_amd.corpus import Corpus
+    for doc_ptr, toks in [([0, 1], [0]), ([0, 0, 0, 0], []), ([0, 1000], list(np.arange(1000) % 11)), ([0, 64, 128, 129], list(np.arange(129) % 11))]:
+        c = Corpus(np.asarray(doc_ptr, np.int64), np.asarray(toks, np.int32), 11)
+        g, o = make_pair(native, oracle, c, 4, 0.3, 0.2, 1, zseed=5)
+        g.sweep(2)
+        o.sweep(2)
+        compare_state(g, o, "edge %r" % (doc_ptr,))
+
+
+def test_synthetic_k100_slice(native, oracle):
+    c = synthetic_lda_corpus(1000, 5000, 200, true_topics=20, seed=2019)
+    g, o = make_pair(native, oracle, c, 100, 0.1, 0.01, 2019, zseed=2019)
+    g.sweep(2)
+    o.set_threads(8)
+    o.sweep(2)
+    compare_state(g, o, "synthetic K=100")
+    t = g.get_timings()
+    assert t["sweeps"] == 2 and t["tokens_sampled"] == 2 * c.num_tokens and t["z_ms"] > 0
+
+
+def test_set_z_and_sample_z_given_phi(native, oracle):
+    c = random_corpus(100, 200, 60, seed=9)
+    K = 10
+    g, o = make_pair(native, oracle, c, K, 0.2, 0.05, 77)
+    z = np.random.default_rng(0).integers(0, K, c.num_tokens).astype(np.int32)
+    g.set_z(z, True)
+    o.set_z(z, True)
+    compare_state(g, o, "after set_z", theta=False)
+    phi = g.get_phi()
+    g.sample_z_given_phi(2)                       # UPLDA:975-1014
+    for _ in range(2):
+        o.set_iteration(o.iteration + 1)
+        o.z_step()
+        o.update_counts()
+    assert_bit_equal(g.get_z(), o.get_z(), "z given phi")
+    assert_bit_equal(g.get_type_topic_counts(), o.get_type_topic_counts(), "counts given phi")
+    assert_bit_equal(g.get_phi(), phi, "phi untouched")
+    assert_bit_equal(g.get_topic_totals(), o.get_topic_totals(), "n_k given phi")
+    # setPhi round trip (UPLDA:1897-1926)
+    p2 = np.random.default_rng(1).dirichlet(np.ones(c.num_types), K)
+    g.set_phi(p2)
+    assert_bit_equal(g.get_phi(), p2, "set_phi/get_phi")
+    o.set_phi(p2)
+    g.sweep(1)
+    o.sweep(1)
+    compare_state(g, o, "after set_phi + sweep")
+
+
+def test_phi_mean_gating(native, oracle):
+    c = random_corpus(80, 120, 50, seed=4)
+    g, o = make_pair(native, oracle, c, 6, 0.3, 0.1, 5, flags=native.FLAG_SAVE_PHI_MEAN, burn_in=2, thin=2, zseed=1)
+    assert g.get_phi_mean() == (None, 0)          # getPhiMeans returns null before any sample, UPLDA:1955-1958
+    g.sweep(8)
+    o.sweep(8)
+    (gm, gn), (om, on) = g.get_phi_mean(), o.get_phi_mean()
+    assert gn == on == 3                          # iterations 4, 6, 8 (> burn_in, % thin == 0)
+    assert_bit_equal(gm, om, "phi mean")
+
+
+def test_sharded_via_torch(native, oracle):
+    """Three doc shards on one GPU, the count/delta exchange done on the device buffers
+    through torch (what ldagroupedgibbssampler_amd.sharded does over RCCL) == one handle ==
+    the oracle: the doc-sharded decomposition is exact, not AD-LDA."""
+    torch = pytest.importorskip("torch")
+    from ldagroupedgibbssampler_amd.sharded import wrap_device_int32
+    c = random_corpus(203, 300, 120, seed=21, empty_every=11)
+    K, alpha, beta, seed = 12, 0.1, 0.01, 99
+    ref, o = make_pair(native, oracle, c, K, alpha, beta, seed, zseed=3)
+    z0 = ref.get_z()
+    bounds = even_split(c.num_docs, 3)
+    shards = []
+    for r in range(3):
+        sub, db, tb = c.shard(bounds[r], bounds[r + 1])
+        h = native.GGSHandle(K, c.num_types, alpha, beta, seed)
+        h.set_corpus(sub.doc_ptr, sub.tokens, db, tb)
+        h.set_global_token_count(c.num_tokens)
+        h.set_z(z0[tb:tb + sub.num_tokens], redraw_phi=False)
+        shards.append((h, tb, sub.num_tokens))
+    counts = [wrap_device_int32(*h.counts_device_ptr()) for h, _, _ in shards]
+    tot = torch.stack(counts).sum(0, dtype=torch.int32)
+    for t in counts:
+        t.copy_(tot)
+    torch.cuda.synchronize()
+    for h, _, _ in shards:
+        h.init_phi()
+    deltas = [wrap_device_int32(*h.delta_device_ptr()) for h, _, _ in shards]
+    for it in range(3):
+        for h, _, _ in shards:
+            h.sweep_begin()
+        for h, _, _ in shards:
+            h.synchronize()
+        tot = torch.stack(deltas).sum(0, dtype=torch.int32)
+        for t in deltas:
+            t.copy_(tot)
+        torch.cuda.synchronize()
+        for h, _, _ in shards:
+            h.sweep_end()
+        ref.sweep(1)
+        o.sweep(1)
+    z = np.concatenate([h.get_z() for h, _, _ in shards])
+    assert_bit_equal(z, ref.get_z(), "sharded z vs one handle")
+    assert_bit_equal(z, o.get_z(), "sharded z vs oracle")
+    for h, _, _ in shards:
+        assert_bit_equal(h.get_type_topic_counts(), o.get_type_topic_counts(), "sharded n_wk")
+        assert_bit_equal(h.get_phi(), o.get_phi(), "sharded phi")
+        h.check_invariants()
+    th = np.concatenate([h.get_theta() for h, _, _ in shards])
+    assert_bit_equal(th, o.get_theta(), "sharded theta")
+
+
+def test_error_behaviour(native):
+    c = random_corpus(10, 20, 10, seed=1)
+    with pytest.raises(native.GGSError) as e:
+        native.GGSHandle(0, 10, 0.1, 0.1, 1)
+    assert e.value.code == native.ERR_BAD_ARG
+    with pytest.raises(native.GGSError):
+        native.GGSHandle(4, 10, -0.1, 0.1, 1)          # alpha must be strictly positive (ParallelRandoms.java:61-63)
+    with pytest.raises(native.GGSError):
+        native.GGSHandle(4, 10, 0.1, 0.0, 1)
+    g = native.GGSHandle(4, 20, 0.1, 0.1, 1)
+    with pytest.raises(native.GGSError) as e:
+        g.sweep(1)
+    assert e.value.code == native.ERR_STATE
+    bad = c.tokens.copy()
+    bad[0] = 20
+    with pytest.raises(native.GGSError) as e:
+        g.set_corpus(c.doc_ptr, bad)
+    assert e.value.code == native.ERR_BAD_ARG
+    g.set_corpus(c.doc_ptr, c.tokens)
+    with pytest.raises(native.GGSError) as e:
+        g.sweep(1)                                     # no Phi yet
+    assert e.value.code == native.ERR_STATE
+    with pytest.raises(native.GGSError) as e:
+        g.set_z(np.full(c.num_tokens, 4, np.int32))
+    assert e.value.code == native.ERR_BAD_ARG
+    g.init_z_java_lcg(1)
+    g.init_phi()
+    with pytest.raises(native.GGSError):
+        g.sweep_end()
+    g.sweep_begin()
+    with pytest.raises(native.GGSError):
+        g.sweep_begin()
+    g.sweep_end()
+    # an all-zero Phi row makes sum == 0 -> newTopic stays -1 -> the Java throw of GGS:116-118
+    g.set_phi(np.zeros((4, 20)))
+    with pytest.raises(native.GGSError) as e:
+        g.sweep(1)
+    assert e.value.code == native.ERR_INVALID_TOPIC
+    assert "Topic sampled is invalid" in str(e.value)
+
+
+# ---------------------------------------------------------------- full size (properties only)
+def test_full_size_properties(native):
+    """BASELINE config 2 shape (D=100k, V=50k, ~20M tokens, K=100): too big for the oracle
+    in seconds, so check what does not depend on size: count invariants after every sweep,
+    z range, theta/phi rows summing to 1, and run-to-run determinism of the whole state."""
+    import hashlib
+    c = synthetic_lda_corpus(100000, 50000, 200, true_topics=100, seed=2019)
+
+    def run():
+        g = native.GGSHandle(100, c.num_types, 0.1, 0.01, 2019, flags=native.FLAG_PARANOID)
+        g.set_corpus(c.doc_ptr, c.tokens)
+        g.init_z_java_lcg(2019)
+        g.init_phi()
+        g.sweep(2)
+        z = g.get_z()
+        nk = g.get_topic_totals()
+        th = g.get_theta(0, 2000)
+        phi = g.get_phi()
+        h = hashlib.sha256(z.tobytes() + nk.tobytes() + phi.tobytes()).hexdigest()
+        g.close()
+        return z, nk, th, phi, h
+
+    z, nk, th, phi, h1 = run()
+    assert z.min() >= 0 and z.max() < 100
+    assert nk.sum() == c.num_tokens
+    assert np.array_equal(np.bincount(z, minlength=100), nk)
+    assert np.allclose(th.sum(1), 1.0, atol=1e-12) and np.allclose(phi.sum(1), 1.0, atol=1e-9)
+    assert (phi > 0).all()
+    *_, h2 = run()
+    assert h1 == h2

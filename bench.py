@@ -1,0 +1,189 @@
+#!/usr/bin/env python3
+"""Benchmark of the Grouped Gibbs sweep on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A "step" is one full sweep of BASELINE.json's configs[1]: synthetic LDA corpus D=100k,
+V=50k, mean 200 tokens/doc (~20M tokens), K=100, alpha=0.1, beta=0.01 -- theta draw +
+z draw + count merge (+ RCCL all-reduce of the deltas when N>1) + Phi re-draw, i.e. what
+UncollapsedParallelLDA.sample does between preZ() and postPhi() (UPLDA:659-687).  The corpus
+is FIXED as N grows (documents are sharded across the ranks), so scaling is "strong".
+Inputs are resident in HBM before the timed region; rank 0 prints ONE JSON line.
+
+N>1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes_per_token(K):
+    """SURVEY.md 8(d) with fp64 Phi (the reference's double[][] phi): one K-row of 8-byte
+    values + token id + z read + z write + two 4-byte read-modify-write count updates."""
+    return 8 * K + 28
+
+
+def cpu_baseline(corpus, K, alpha, beta, seed, z0, sample_docs):
+    """The oracle (a C restatement of the Java GGS sweep, Java layouts kept: phi[K][V],
+    atomic [K][V] deltas, dynamic chunks of 100 documents) on all host cores, on the first
+    `sample_docs` documents with the full vocabulary.  kind = "port": not a JVM run."""
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    sub, _, _ = corpus.shard(0, min(sample_docs, corpus.num_docs))
+    o = O.OracleSampler(K, corpus.num_types, alpha, beta, seed, threads=cores)
+    o.set_corpus(sub.doc_ptr, sub.tokens)
+    o.set_z(z0[:sub.num_tokens], redraw_phi=True)
+    o.sweep(1)                     # warm-up (page in, first-touch)
+    t0 = time.perf_counter()
+    n_sw = 2
+    for _ in range(n_sw):
+        o.set_iteration(o.iteration + 1)
+        t_a = time.perf_counter()
+        o.z_step()
+        t_b = time.perf_counter()
+        o.update_counts()
+        o.sample_phi()
+        t_c = time.perf_counter()
+    dt = time.perf_counter() - t0
+    o.close()
+    return {
+        "value": round(sub.num_tokens * n_sw / dt / 1e6, 3),
+        "unit": "M tokens/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": "first %d docs (%d tokens) of the same corpus, full V=%d and K=%d, %d full sweeps "
+                  "(z step %.2fs + merge/Phi %.2fs in the last one; the K*V Phi draw does not shrink with the sample)"
+                  % (sub.num_docs, sub.num_tokens, corpus.num_types, K, n_sw, t_b - t_a, t_c - t_b),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--docs", type=int, default=100000)
+    ap.add_argument("--types", type=int, default=50000)
+    ap.add_argument("--mean-len", type=int, default=200)
+    ap.add_argument("--topics", type=int, default=100)
+    ap.add_argument("--alpha", type=float, default=0.1)
+    ap.add_argument("--beta", type=float, default=0.01)
+    ap.add_argument("--seed", type=int, default=2019)
+    ap.add_argument("--cpu-sample-docs", type=int, default=100000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch  # device plumbing + torch.distributed (RCCL); imported before libggs_hip so both share one HIP runtime
+
+    from ldagroupedgibbssampler_amd import native
+    from ldagroupedgibbssampler_amd.corpus import synthetic_lda_corpus
+    from ldagroupedgibbssampler_amd.sharded import ShardedGGS, TorchHipExchange, java_lcg_initial_z
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
+        sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        sys.exit("no GPU visible: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    K = args.topics
+    corpus = synthetic_lda_corpus(args.docs, args.types, args.mean_len, true_topics=100, seed=args.seed)
+    z0 = java_lcg_initial_z(corpus.num_tokens, K, args.seed)
+
+    h = native.GGSHandle(K, corpus.num_types, args.alpha, args.beta, args.seed, device_id=local_rank)
+    if world > 1:
+        sh = ShardedGGS(h, TorchHipExchange, corpus, rank, world)
+        sh.set_z_global(z0)
+        step = lambda: sh.sweep(1)  # noqa: E731
+        n_local = sh.local.num_tokens
+    else:
+        h.set_corpus(corpus.doc_ptr, corpus.tokens)
+        h.set_z(z0, redraw_phi=True)
+        step = lambda: h.sweep(1)  # noqa: E731
+        n_local = corpus.num_tokens
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    h.reset_timings()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    tm = h.get_timings()
+    h.check_invariants()
+
+    if rank == 0:
+        btok = algorithmic_bytes_per_token(K)
+        z_ms = tm["z_ms"] / max(tm["sweeps"], 1)            # HIP events on the handle's stream, over the timed region
+        achieved = n_local * btok / (z_ms * 1e-3) / 1e9 if z_ms > 0 else 0.0
+        line = {
+            "metric": "M tokens sampled/sec (whole node) per Gibbs sweep at K=%d" % K,
+            "value": round(corpus.num_tokens * args.steps / dt / 1e6, 3),
+            "unit": "M tokens/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "LDAGroupedGibbsSampler sweep, synthetic LDA corpus D=%d V=%d N=%d tokens K=%d alpha=%g beta=%g seed=%d"
+                            % (corpus.num_docs, corpus.num_types, corpus.num_tokens, K, args.alpha, args.beta, args.seed),
+                "parallelism": "doc-sharded x%d, int32 delta all-reduce per sweep" % world if world > 1 else "1 GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "z_kernel",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "bytes_per_token": btok,
+                "tokens_per_launch": n_local,
+                "avg_launch_ms": round(z_ms, 4),
+            },
+            "phase_ms_per_sweep": {k: round(tm[k] / max(tm["sweeps"], 1), 4) for k in ("theta_ms", "z_ms", "merge_ms", "phi_ms")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(corpus, K, args.alpha, args.beta, args.seed, z0, args.cpu_sample_docs)
+        print(json.dumps(line), flush=True)
+    h.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -108,6 +108,28 @@ def build(force=False):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One process must hold ONE HIP runtime.  The torch wheel ships its own
+    libamdhip64.so (SONAME libamdhip64.so.7, but libtorch_hip asks for it by the unversioned
+    file name), so if libggs_hip.so pulls in /opt/rocm's copy first, a later `import torch`
+    loads a second runtime that sees no GPUs.  Loading torch's copy first makes both
+    resolve to the same SONAME.  Without torch installed (the JNI deployment) this is a no-op
+    and /opt/rocm's runtime is used."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """dlopen libggs_hip.so and type every entry point.  Raises if it is absent:
     the product has no fallback path."""
@@ -118,6 +140,7 @@ def load():
         raise ImportError(
             "libggs_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(needs hipcc); there is no CPU fallback" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)  # AttributeError if the .so lacks a declared symbol

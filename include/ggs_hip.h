@@ -79,7 +79,7 @@ typedef struct ggs_config {
 typedef struct ggs_timings {
   double theta_ms;  /* cumulative: per-document theta draw (GGS:57-72)                         */
   double z_ms;      /* cumulative: token loop (GGS:79-130)                                     */
-  double merge_ms;  /* cumulative: updateCounts (UPLDA:1107-1221)                              */
+  double merge_ms;  /* cumulative: count rebuild, the device form of updateCounts (UPLDA:1107-1221) */
   double phi_ms;    /* cumulative: samplePhi (GGS:139-198)                                     */
   int64_t sweeps;
   int64_t tokens_sampled;
@@ -125,27 +125,26 @@ int ggs_get_iteration(const ggs_handle *h, int32_t *iteration);
  * abort / exec_time / diagnostics loop in the caller. */
 int ggs_sweep(ggs_handle *h, int32_t n_sweeps);
 /* The same, split where a doc-sharded run exchanges counts:
- *   begin = ++iteration, theta draw + z draw -> deltas (UPLDA:660)
- *   [caller sum-all-reduces the delta buffer across shards]
- *   end   = updateCounts + samplePhi (UPLDA:664-687) */
+ *   begin = ++iteration, theta draw + z draw + this shard's counts (UPLDA:660, and the
+ *           local half of updateCounts)
+ *   [caller sum-all-reduces the counts buffer across shards -- see ggs_counts_device_ptr]
+ *   end   = samplePhi on the corpus-wide counts (UPLDA:664-687) */
 int ggs_sweep_begin(ggs_handle *h);
 int ggs_sweep_end(ggs_handle *h);
 /* replaces: sampleZGivenPhi (UPLDA:975-1014): z step + updateCounts, Phi kept */
 int ggs_sample_z_given_phi(ggs_handle *h, int32_t n_sweeps);
-/* Device pointer / element count of the int32 [V][K] delta buffer
- * (batchLocalTopicTypeUpdates, UPLDA:102, transposed) for an in-place RCCL
- * all-reduce by the caller; or let the caller supply the buffer. */
-int ggs_delta_device_ptr(ggs_handle *h, void **dev_ptr, int64_t *num_elems);
-int ggs_use_external_delta(ggs_handle *h, void *dev_ptr /* V*K int32, zeroed */);
-/* Device pointer of the int32 [V][K] type-topic counts (typeTopicCounts, MSLDA:73):
- * a doc-sharded start-up sum-all-reduces it once after ggs_set_z(h, z, 0) and
- * before ggs_init_phi, so every shard holds the corpus-wide counts. */
+/* Device pointer / element count of the int32 [V][K] type-topic counts
+ * (typeTopicCounts, MSLDA:73) -- the ONE buffer a doc-sharded run exchanges.  After
+ * ggs_sweep_begin (and after ggs_set_z(h, z, 0) at start-up) it holds THIS shard's counts;
+ * the caller sum-all-reduces it in place over the shards (RCCL) and then calls ggs_sweep_end
+ * (resp. ggs_init_phi).  This replaces the Java merge of the thread-shared AtomicInteger
+ * deltas (batchLocalTopicTypeUpdates, UPLDA:102,1107-1221; ADLDA's sumTypeTopicCounts,
+ * ADLDA.java:302): n_wk(new) = n_wk(old) + sum of deltas = sum over shards of the local
+ * (word, z) histograms -- the same integers. */
 int ggs_counts_device_ptr(ggs_handle *h, void **dev_ptr, int64_t *num_elems);
 /* Corpus-wide token count (all shards); what ggs_check_invariants expects the
  * counts to sum to.  Defaults to this handle's own token count. */
 int ggs_set_global_token_count(ggs_handle *h, int64_t n_tokens);
-int ggs_get_delta(ggs_handle *h, int32_t *delta /*[V][K]*/);
-int ggs_set_delta(ggs_handle *h, const int32_t *delta /*[V][K]*/);
 /* Block until everything queued on the handle's stream has finished; surfaces
  * device-side error flags (what Java throws from the worker threads). */
 int ggs_synchronize(ggs_handle *h);

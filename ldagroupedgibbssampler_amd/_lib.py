@@ -69,12 +69,8 @@ SIGNATURES = {
     "ggs_sweep_begin": (C.c_int, [_vp]),
     "ggs_sweep_end": (C.c_int, [_vp]),
     "ggs_sample_z_given_phi": (C.c_int, [_vp, C.c_int32]),
-    "ggs_delta_device_ptr": (C.c_int, [_vp, C.POINTER(_vp), _lp]),
-    "ggs_use_external_delta": (C.c_int, [_vp, _vp]),
     "ggs_counts_device_ptr": (C.c_int, [_vp, C.POINTER(_vp), _lp]),
     "ggs_set_global_token_count": (C.c_int, [_vp, C.c_int64]),
-    "ggs_get_delta": (C.c_int, [_vp, _ip]),
-    "ggs_set_delta": (C.c_int, [_vp, _ip]),
     "ggs_synchronize": (C.c_int, [_vp]),
     "ggs_get_z": (C.c_int, [_vp, _ip]),
     "ggs_get_type_topic_counts": (C.c_int, [_vp, _ip]),

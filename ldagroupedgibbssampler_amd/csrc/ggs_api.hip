@@ -6,6 +6,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -35,8 +36,9 @@ struct ggs_handle {
   int32_t flags = 0, phi_burn_in = 0, phi_thin = 1;
   int32_t iteration = 0;
   int32_t n_sampled_phi = 0;
+  int32_t ablate = 0;   // GGS_DEBUG_ABLATE: timing-only experiments, results are wrong on purpose
 
-  int64_t D = 0, N = 0, C = 0, doc_base = 0, tok_base = 0, global_tokens = -1;
+  int64_t D = 0, N = 0, C = 0, S = 0, doc_base = 0, tok_base = 0, global_tokens = -1;
   bool have_corpus = false, have_phi = false, in_sweep = false;
   int32_t theta_docs_per_block = 0, theta_lds = 0, z_lds = 0;
 
@@ -44,9 +46,9 @@ struct ggs_handle {
   // device buffers
   int64_t *d_doc_ptr = nullptr, *d_chunk_start = nullptr;
   int32_t *d_tok = nullptr, *d_z = nullptr, *d_chunk_doc = nullptr, *d_chunk_len = nullptr;
+  int32_t *d_perm = nullptr, *d_seg_word = nullptr, *d_seg_begin = nullptr;
   double *d_alpha = nullptr, *d_theta = nullptr, *d_phiT = nullptr, *d_mag = nullptr, *d_tot = nullptr, *d_phi_mean = nullptr;
-  int32_t *d_n_wk = nullptr, *d_delta = nullptr, *d_n_k = nullptr;
-  bool delta_external = false;
+  int32_t *d_n_wk = nullptr, *d_n_k = nullptr;
   uint32_t *d_status = nullptr;
   void *d_scratch = nullptr;
   size_t scratch_bytes = 0;
@@ -109,12 +111,22 @@ int check_status(ggs_handle *h) {
   return set_err(h, GGS_ERR_RNG_EXHAUSTED, "a gamma rejection loop exceeded GGS_MAX_BLOCKS Philox blocks");
 }
 
+// n_wk = histogram of (word, z) over this handle's tokens (UPLDA:471-474 summed over the corpus).
 int launch_count_rebuild(ggs_handle *h) {
   const size_t kv = (size_t)h->K * h->V;
   HIP_TRY(h, hipMemsetAsync(h->d_n_wk, 0, kv * sizeof(int32_t), h->stream));
-  HIP_TRY(h, hipMemsetAsync(h->d_delta, 0, kv * sizeof(int32_t), h->stream));
-  if (h->N > 0)
-    hipLaunchKernelGGL(count_kernel, dim3(grid_for(h->N, 256)), dim3(256), 0, h->stream, h->d_tok, h->d_z, h->N, h->K, h->d_n_wk);
+  if (h->S > 0) {
+    CountParams cp{};
+    cp.perm = h->d_perm; cp.z = h->d_z; cp.seg_word = h->d_seg_word; cp.seg_begin = h->d_seg_begin; cp.n_wk = h->d_n_wk; cp.K = h->K;
+    hipLaunchKernelGGL(count_sorted_kernel, dim3((unsigned)h->S), dim3(256), (size_t)h->K * sizeof(int32_t), h->stream, cp);
+  }
+  HIP_TRY(h, hipGetLastError());
+  return GGS_OK;
+}
+
+int launch_magnitude(ggs_handle *h) {
+  hipLaunchKernelGGL((column_chain_kernel<int32_t, true>), dim3((h->K + 7) / 8), dim3(256), 0, h->stream, h->d_n_wk, h->K, h->K, h->V, h->beta,
+                     h->d_mag, h->d_n_k);
   HIP_TRY(h, hipGetLastError());
   return GGS_OK;
 }
@@ -122,7 +134,8 @@ int launch_count_rebuild(ggs_handle *h) {
 // Phi draw: initial (K8) or per sweep (K6).  Always refreshes n_k.
 int launch_phi(ggs_handle *h, bool initial, bool accumulate_mean) {
   const int K = h->K, V = h->V;
-  hipLaunchKernelGGL(phi_magnitude_kernel, dim3((K + 63) / 64), dim3(64), 0, h->stream, h->d_n_wk, K, V, h->beta, h->d_mag, h->d_n_k);
+  int rc = launch_magnitude(h);
+  if (rc) return rc;
   PhiGammaParams gp{};
   gp.n_wk = h->d_n_wk; gp.mag = h->d_mag; gp.phiT = h->d_phiT; gp.status = h->d_status;
   gp.seed = h->seed; gp.iteration = (uint32_t)h->iteration;
@@ -133,7 +146,8 @@ int launch_phi(ggs_handle *h, bool initial, bool accumulate_mean) {
   gp.initial = initial ? 1 : 0;
   const int64_t kv = (int64_t)K * V;
   hipLaunchKernelGGL(phi_gamma_kernel, dim3(grid_for(kv, 256, 2)), dim3(256), 0, h->stream, gp);
-  hipLaunchKernelGGL(phi_total_kernel, dim3((K + 63) / 64), dim3(64), 0, h->stream, h->d_phiT, K, h->Kp, V, h->d_tot);
+  hipLaunchKernelGGL((column_chain_kernel<double, false>), dim3((K + 7) / 8), dim3(256), 0, h->stream, h->d_phiT, h->Kp, K, V, 0.0, h->d_tot,
+                     static_cast<int32_t *>(nullptr));
   hipLaunchKernelGGL(phi_normalise_kernel, dim3(grid_for(kv, 256, 2)), dim3(256), 0, h->stream, h->d_phiT, h->d_tot, K, h->Kp, V,
                      accumulate_mean ? h->d_phi_mean : nullptr);
   HIP_TRY(h, hipGetLastError());
@@ -157,17 +171,11 @@ int launch_z(ggs_handle *h) {
   if (h->C == 0) return GGS_OK;
   ZParams zp{};
   zp.tok = h->d_tok; zp.z = h->d_z; zp.chunk_start = h->d_chunk_start; zp.chunk_doc = h->d_chunk_doc; zp.chunk_len = h->d_chunk_len;
-  zp.theta = h->d_theta; zp.phiT = h->d_phiT; zp.delta = h->d_delta; zp.status = h->d_status;
+  zp.theta = h->d_theta; zp.phiT = h->d_phiT; zp.status = h->d_status;
   zp.tok_base = h->tok_base; zp.seed = h->seed; zp.iteration = (uint32_t)h->iteration;
   zp.K = h->K; zp.Kp = h->Kp; zp.pitch16 = h->pitch16;
+  zp.ablate = h->ablate;
   hipLaunchKernelGGL(z_kernel, dim3((unsigned)h->C), dim3(64), h->z_lds, h->stream, zp);
-  HIP_TRY(h, hipGetLastError());
-  return GGS_OK;
-}
-
-int launch_merge(ggs_handle *h) {
-  const int64_t kv = (int64_t)h->K * h->V;
-  hipLaunchKernelGGL(merge_kernel, dim3(grid_for(kv, 256, 4)), dim3(256), 0, h->stream, h->d_n_wk, h->d_delta, kv, h->d_status);
   HIP_TRY(h, hipGetLastError());
   return GGS_OK;
 }
@@ -209,13 +217,13 @@ int z_phase(ggs_handle *h) {
   HIP_TRY(h, hipEventRecord(h->ev.e[1], h->stream));
   if ((rc = launch_z(h))) return rc;
   HIP_TRY(h, hipEventRecord(h->ev.e[2], h->stream));
+  if ((rc = launch_count_rebuild(h))) return rc;   // this shard's counts; summed across shards by the caller
+  HIP_TRY(h, hipEventRecord(h->ev.e[3], h->stream));
   return GGS_OK;
 }
 
 int finish_sweep(ggs_handle *h, bool with_phi) {
   int rc;
-  HIP_TRY(h, hipEventRecord(h->ev.e[3], h->stream));
-  if ((rc = launch_merge(h))) return rc;
   HIP_TRY(h, hipEventRecord(h->ev.e[4], h->stream));
   bool acc = false;
   if (with_phi) {
@@ -228,7 +236,7 @@ int finish_sweep(ggs_handle *h, bool with_phi) {
   float ms = 0;
   HIP_TRY(h, hipEventElapsedTime(&ms, h->ev.e[0], h->ev.e[1])); h->tm.theta_ms += ms;
   HIP_TRY(h, hipEventElapsedTime(&ms, h->ev.e[1], h->ev.e[2])); h->tm.z_ms += ms;
-  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev.e[3], h->ev.e[4])); h->tm.merge_ms += ms;
+  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev.e[2], h->ev.e[3])); h->tm.merge_ms += ms;
   HIP_TRY(h, hipEventElapsedTime(&ms, h->ev.e[4], h->ev.e[5])); h->tm.phi_ms += ms;
   h->tm.sweeps += 1;
   h->tm.tokens_sampled += h->N;
@@ -258,6 +266,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
   h->pitch16 = (h->Kp / 2) | 1;             // odd number of 16-byte units per LDS row
   h->beta = cfg->beta; h->seed = cfg->seed; h->flags = cfg->flags;
   h->phi_burn_in = cfg->phi_burn_in; h->phi_thin = cfg->phi_mean_thin > 0 ? cfg->phi_mean_thin : 1;
+  if (const char *ab = std::getenv("GGS_DEBUG_ABLATE")) h->ablate = std::atoi(ab);
   h->alpha.assign(h->K, cfg->alpha_scalar);
   if (cfg->alpha) std::copy(cfg->alpha, cfg->alpha + h->K, h->alpha.begin());
   for (double a : h->alpha)
@@ -282,12 +291,12 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
   const size_t kv = (size_t)h->K * h->V;
   if ((rc = dev_alloc(h, &h->d_alpha, h->K)) || (rc = dev_alloc(h, &h->d_phiT, (size_t)h->V * h->Kp)) ||
       (rc = dev_alloc(h, &h->d_mag, h->K)) || (rc = dev_alloc(h, &h->d_tot, h->K)) || (rc = dev_alloc(h, &h->d_n_wk, kv)) ||
-      (rc = dev_alloc(h, &h->d_delta, kv)) || (rc = dev_alloc(h, &h->d_n_k, h->K)) || (rc = dev_alloc(h, &h->d_status, 4)))
+      (rc = dev_alloc(h, &h->d_n_k, h->K)) || (rc = dev_alloc(h, &h->d_status, 4)))
     return bail(rc);
   if ((h->flags & GGS_FLAG_SAVE_PHI_MEAN) && (rc = dev_alloc(h, &h->d_phi_mean, kv))) return bail(rc);
   if (hipMemcpy(h->d_alpha, h->alpha.data(), sizeof(double) * h->K, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemset(h->d_phiT, 0, sizeof(double) * (size_t)h->V * h->Kp) != hipSuccess ||
-      hipMemset(h->d_n_wk, 0, sizeof(int32_t) * kv) != hipSuccess || hipMemset(h->d_delta, 0, sizeof(int32_t) * kv) != hipSuccess ||
+      hipMemset(h->d_n_wk, 0, sizeof(int32_t) * kv) != hipSuccess ||
       hipMemset(h->d_n_k, 0, sizeof(int32_t) * h->K) != hipSuccess || hipMemset(h->d_status, 0, 16) != hipSuccess ||
       (h->d_phi_mean && hipMemset(h->d_phi_mean, 0, sizeof(double) * kv) != hipSuccess))
     return bail(GGS_ERR_HIP);
@@ -303,7 +312,7 @@ void ggs_destroy(ggs_handle *h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   void *bufs[] = {h->d_doc_ptr, h->d_chunk_start, h->d_tok, h->d_z, h->d_chunk_doc, h->d_chunk_len, h->d_alpha, h->d_theta,
-                  h->d_phiT, h->d_mag, h->d_tot, h->d_phi_mean, h->d_n_wk, h->delta_external ? nullptr : h->d_delta, h->d_n_k,
+                  h->d_phiT, h->d_mag, h->d_tot, h->d_phi_mean, h->d_n_wk, h->d_n_k, h->d_perm, h->d_seg_word, h->d_seg_begin,
                   h->d_status, h->d_scratch};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -349,11 +358,32 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
       s += l;
     }
   }
-  h->D = D; h->N = N; h->C = (int64_t)cstart.size(); h->doc_base = doc_base; h->tok_base = tok_base;
+  // count-kernel work items: tokens sorted by word (counting sort, stable), each word's run
+  // cut into segments of at most kSegTokens entries.
+  constexpr int64_t kSegTokens = 4096;
+  std::vector<int32_t> perm((size_t)N), seg_word, seg_begin;
+  {
+    std::vector<int64_t> wptr((size_t)h->V + 1, 0);
+    for (int64_t i = 0; i < N; ++i) wptr[(size_t)tokens[i] + 1]++;
+    for (int32_t w = 0; w < h->V; ++w) wptr[(size_t)w + 1] += wptr[(size_t)w];
+    for (int32_t w = 0; w < h->V; ++w)
+      for (int64_t b = wptr[(size_t)w]; b < wptr[(size_t)w + 1]; b += kSegTokens) { seg_word.push_back(w); seg_begin.push_back((int32_t)b); }
+    seg_begin.push_back((int32_t)N);
+    std::vector<int64_t> cur(wptr.begin(), wptr.end() - 1);
+    for (int64_t i = 0; i < N; ++i) perm[(size_t)cur[(size_t)tokens[i]]++] = (int32_t)i;
+    // a segment ends where the next begins, or at the end of its word's run
+    // (seg_begin[s+1] is the next segment's start, which is exactly that)
+  }
+  h->D = D; h->N = N; h->C = (int64_t)cstart.size(); h->S = (int64_t)seg_word.size(); h->doc_base = doc_base; h->tok_base = tok_base;
   if ((rc = dev_alloc(h, &h->d_doc_ptr, (size_t)D + 1)) || (rc = dev_alloc(h, &h->d_tok, (size_t)N)) || (rc = dev_alloc(h, &h->d_z, (size_t)N)) ||
       (rc = dev_alloc(h, &h->d_theta, (size_t)D * h->K)) || (rc = dev_alloc(h, &h->d_chunk_start, (size_t)h->C)) ||
-      (rc = dev_alloc(h, &h->d_chunk_doc, (size_t)h->C)) || (rc = dev_alloc(h, &h->d_chunk_len, (size_t)h->C)))
+      (rc = dev_alloc(h, &h->d_chunk_doc, (size_t)h->C)) || (rc = dev_alloc(h, &h->d_chunk_len, (size_t)h->C)) ||
+      (rc = dev_alloc(h, &h->d_perm, (size_t)N)) || (rc = dev_alloc(h, &h->d_seg_word, (size_t)h->S)) ||
+      (rc = dev_alloc(h, &h->d_seg_begin, (size_t)h->S + 1)))
     return rc;
+  if (N) HIP_TRY(h, hipMemcpy(h->d_perm, perm.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice));
+  if (h->S) HIP_TRY(h, hipMemcpy(h->d_seg_word, seg_word.data(), sizeof(int32_t) * seg_word.size(), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(h->d_seg_begin, seg_begin.data(), sizeof(int32_t) * seg_begin.size(), hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(h->d_doc_ptr, doc_ptr, sizeof(int64_t) * ((size_t)D + 1), hipMemcpyHostToDevice));
   if (N) HIP_TRY(h, hipMemcpy(h->d_tok, tokens, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemset(h->d_z, 0, sizeof(int32_t) * std::max<size_t>((size_t)N, 1)));
@@ -439,15 +469,9 @@ int ggs_sample_z_given_phi(ggs_handle *h, int32_t n_sweeps) {
     if ((rc = z_phase(h))) return rc;
     if ((rc = finish_sweep(h, false))) return rc;
   }
-  // tokensPerTopic follows the merged counts
-  hipLaunchKernelGGL(phi_magnitude_kernel, dim3((h->K + 63) / 64), dim3(64), 0, h->stream, h->d_n_wk, h->K, h->V, h->beta, h->d_mag, h->d_n_k);
+  // tokensPerTopic follows the rebuilt counts
+  if ((rc = launch_magnitude(h))) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  return GGS_OK;
-}
-
-int ggs_delta_device_ptr(ggs_handle *h, void **dev_ptr, int64_t *num_elems) {
-  if (!h || !dev_ptr || !num_elems) return GGS_ERR_BAD_ARG;
-  *dev_ptr = h->d_delta; *num_elems = (int64_t)h->K * h->V;
   return GGS_OK;
 }
 
@@ -463,36 +487,9 @@ int ggs_set_global_token_count(ggs_handle *h, int64_t n_tokens) {
   return GGS_OK;
 }
 
-int ggs_use_external_delta(ggs_handle *h, void *dev_ptr) {
-  if (!h || !dev_ptr) return GGS_ERR_BAD_ARG;
-  int rc = bind_device(h);
-  if (rc) return rc;
-  if (h->in_sweep) return set_err(h, GGS_ERR_STATE, "inside a split sweep");
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  if (!h->delta_external && h->d_delta) (void)hipFree(h->d_delta);
-  h->d_delta = static_cast<int32_t *>(dev_ptr);
-  h->delta_external = true;
-  return GGS_OK;
-}
-
 static int copy_out(ggs_handle *h, void *dst, const void *src, size_t bytes) {
   if (!bytes) return GGS_OK;
   HIP_TRY(h, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  return GGS_OK;
-}
-
-int ggs_get_delta(ggs_handle *h, int32_t *delta) {
-  if (!h || !delta) return GGS_ERR_BAD_ARG;
-  int rc = bind_device(h);
-  if (rc) return rc;
-  return copy_out(h, delta, h->d_delta, sizeof(int32_t) * (size_t)h->K * h->V);
-}
-int ggs_set_delta(ggs_handle *h, const int32_t *delta) {
-  if (!h || !delta) return GGS_ERR_BAD_ARG;
-  int rc = bind_device(h);
-  if (rc) return rc;
-  HIP_TRY(h, hipMemcpyAsync(h->d_delta, delta, sizeof(int32_t) * (size_t)h->K * h->V, hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return GGS_OK;
 }
@@ -521,7 +518,7 @@ int ggs_get_topic_totals(ggs_handle *h, int32_t *n_k) {
   int rc = bind_device(h);
   if (rc) return rc;
   // n_k is refreshed by every Phi draw; recompute here so the getter is valid right after set_z(redraw=0)
-  hipLaunchKernelGGL(phi_magnitude_kernel, dim3((h->K + 63) / 64), dim3(64), 0, h->stream, h->d_n_wk, h->K, h->V, h->beta, h->d_mag, h->d_n_k);
+  if ((rc = launch_magnitude(h))) return rc;
   return copy_out(h, n_k, h->d_n_k, sizeof(int32_t) * (size_t)h->K);
 }
 
@@ -596,9 +593,9 @@ int ggs_check_invariants(ggs_handle *h) {
   auto *d_col = reinterpret_cast<int32_t *>(static_cast<char *>(h->d_scratch) + 16);
   HIP_TRY(h, hipMemsetAsync(h->d_scratch, 0, bytes, h->stream));
   const int64_t kv = (int64_t)K * h->V;
-  hipLaunchKernelGGL(invariants_kernel, dim3(grid_for(kv, 256)), dim3(256), 0, h->stream, h->d_n_wk, h->d_delta, kv, K, d_total, d_col, d_flags);
-  hipLaunchKernelGGL(phi_magnitude_kernel, dim3((K + 63) / 64), dim3(64), 0, h->stream, h->d_n_wk, K, h->V, h->beta, h->d_mag, h->d_n_k);
+  hipLaunchKernelGGL(invariants_kernel, dim3(grid_for(kv, 256)), dim3(256), 0, h->stream, h->d_n_wk, kv, K, d_total, d_col, d_flags);
   HIP_TRY(h, hipGetLastError());
+  if ((rc = launch_magnitude(h))) return rc;
   std::vector<unsigned char> host(bytes);
   std::vector<int32_t> nk((size_t)K);
   if ((rc = copy_out(h, host.data(), h->d_scratch, bytes))) return rc;
@@ -607,7 +604,6 @@ int ggs_check_invariants(ggs_handle *h) {
   std::memcpy(&total, host.data(), 8); std::memcpy(&fl, host.data() + 8, 4);
   const int32_t *col = reinterpret_cast<const int32_t *>(host.data() + 16);
   if (fl & 1u) return set_err(h, GGS_ERR_INVARIANT, "negative type-topic count");
-  if (fl & 2u) return set_err(h, GGS_ERR_INVARIANT, "non-zero delta after updateCounts");
   if ((int64_t)total != (h->global_tokens >= 0 ? h->global_tokens : h->N)) return set_err(h, GGS_ERR_INVARIANT, "type-topic counts do not sum to the corpus size");
   for (int k = 0; k < K; ++k)
     if (col[k] != nk[(size_t)k]) return set_err(h, GGS_ERR_INVARIANT, "column sum differs from tokensPerTopic");

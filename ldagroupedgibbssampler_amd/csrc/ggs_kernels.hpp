@@ -4,17 +4,25 @@
 //   tok[N]            int32   word ids, CSR order
 //   z[N]              int32   topic assignments
 //   chunk_*[C]                z-kernel work items: <=64 consecutive tokens of ONE document
+//   perm[N]           int32   token indices sorted by word id (built once on the host)
+//   seg_*[S]                  count-kernel work items: <=4096 consecutive entries of perm
+//                             that all carry the same word
 //   theta[D][K]       fp64    thetaMatrix rows (GGS:72)
 //   phiT[V][Kp]       fp64    TRANSPOSE of the Java phi[K][V] (UPLDA:69), row pitch Kp = K
 //                             rounded up to even, so one token reads one contiguous row
 //   n_wk[V][K]        int32   typeTopicCounts layout (MSLDA:73)
-//   delta[V][K]       int32   batchLocalTopicTypeUpdates (UPLDA:102), transposed
 //   n_k[K]            int32   tokensPerTopic
 //
 // Java keeps every running sum sequential in index order (sum += ...), and so do
 // these kernels: wherever the reference adds K or V doubles one after another, ONE
 // lane walks them in that order.  Parallelism comes from doing many such walks side
 // by side (one lane per token / document / topic), never from re-associating a sum.
+//
+// The reference's AtomicInteger delta matrix + merge (UPLDA:1547-1557, 1107-1221) exists to
+// let JVM threads share counts; its net effect per sweep is n_wk = histogram of (word, z).
+// Integer sums do not depend on order, so the device rebuilds that histogram from z with a
+// word-sorted segmented pass (count_sorted_kernel) instead of 2 contended global atomics per
+// token: identical counts, no hot-word serialisation.
 #pragma once
 #include "ggs_device_math.hpp"
 
@@ -125,14 +133,14 @@ __global__ __launch_bounds__(BLOCK) void theta_kernel(ThetaParams p) {
 }
 
 // ------------------------------------------------------------------------------
-// K3+K4: the token loop (GGS:79-130).  One wave = one chunk of <=64 tokens of one
+// K3: the token loop (GGS:79-130).  One wave = one chunk of <=64 tokens of one
 // document; lane t owns token t.
-//   stage   the wave copies the chunk's phiT rows HBM -> LDS with 16-byte,
-//           fully coalesced loads (a row is Kp*8 contiguous bytes)
+//   stage   the wave copies the chunk's phiT rows HBM -> LDS by LDS-DMA, fully coalesced
+//           (a row is Kp*8 contiguous bytes)
 //   pass 1  lane t: sum = sum_k theta[k]*phi[k][w_t], k ascending (GGS:96-101)
 //   draw    U from Philox (GGS:107), sample = U*sum
 //   pass 2  lane t: the "while (sample > 0) sample -= score[++k]" walk (GGS:108-113)
-//   update  z store; -1/+1 on delta[w][old/new] (GGS:93,129 -> UPLDA:1547-1557)
+//   store   z (the count updates of GGS:93,129 are rebuilt by count_sorted_kernel)
 // LDS row pitch = pitch16*16 bytes with pitch16 odd, so the 16-byte per-lane reads
 // of passes 1-2 (lane t reads row t) are bank-conflict free.
 // ------------------------------------------------------------------------------
@@ -144,15 +152,22 @@ struct ZParams {
   const int32_t *chunk_len;
   const double *theta;
   const double *phiT;
-  int32_t *delta;
   uint32_t *status;
   int64_t tok_base;
   uint64_t seed;
   uint32_t iteration;
   int32_t K, Kp, pitch16;
+  int32_t ablate;   // timing-only experiments (env GGS_DEBUG_ABLATE): 2 no walk, 4 no staging, 8 no sum pass
 };
 
 struct alignas(16) D2 { double a, b; };
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef __attribute__((address_space(1))) const void glb_cvoid_t;
+// theta is written by the previous kernel and only read here; reading it through the
+// constant address space makes every wave-uniform access a scalar (SMEM) load whatever the
+// alias analysis thinks of the LDS-DMA intrinsic.
+typedef __attribute__((address_space(4))) const double const_double_t;
 
 __global__ __launch_bounds__(64) void z_kernel(ZParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -163,48 +178,52 @@ __global__ __launch_bounds__(64) void z_kernel(ZParams p) {
   const int doc = p.chunk_doc[c];
   const int K = p.K, Kp = p.Kp;
   const int upr = Kp >> 1;                 // 16-byte units per phi row
-  const int pitch = p.pitch16 * 16;        // LDS row pitch, bytes
+  const int p16 = p.pitch16;               // 16-byte units per LDS row (odd; = upr or upr + 1 pad unit)
+  const int pitch = p16 * 16;              // LDS row pitch, bytes
 
-  int w = 0, old_topic = 0;
-  if (lane < len) { w = p.tok[start + lane]; old_topic = p.z[start + lane]; }
+  int w = 0;
+  if (lane < len) w = p.tok[start + lane];
 
-  // ---- stage rows: unit u = (row, col), row-major over the chunk ----
-  {
-    const int total = len * upr;
-    int row = lane / upr, col = lane - row * upr;
-    const int drow = 64 / upr, dcol = 64 - drow * upr;
-    constexpr int UNR = 8;
-    for (int base = 0; base < total; base += 64 * UNR) {   // wave-uniform trip count: every lane takes part in the shuffles
-      D2 v[UNR];
-      int dst[UNR];
-#pragma unroll
-      for (int j = 0; j < UNR; ++j) {
-        const int u = base + 64 * j + lane;
-        const int wr = __shfl(w, row < 64 ? row : 63);
-        dst[j] = (u < total) ? row * pitch + col * 16 : -1;
-        if (u < total) v[j] = *reinterpret_cast<const D2 *>(p.phiT + (size_t)wr * Kp + 2 * col);
-        row += drow; col += dcol;
-        if (col >= upr) { col -= upr; ++row; }
-      }
-#pragma unroll
-      for (int j = 0; j < UNR; ++j)
-        if (dst[j] >= 0) *reinterpret_cast<D2 *>(smem + dst[j]) = v[j];
+  // ---- stage the chunk's phiT rows HBM -> LDS with LDS-DMA (global_load_lds_dwordx4).
+  // One wave-instruction fills 64 consecutive 16-byte LDS units (1 KiB); unit u of the tile
+  // is (row u / p16, col u % p16), so the LDS image is row-major with pitch p16 and every
+  // lane's SOURCE address picks the matching 16 bytes of its row.  The pad unit (col == upr)
+  // and units past the chunk re-read a valid address; nobody reads those LDS bytes.
+  if (!(p.ablate & 4)) {
+    const int total = len * p16;
+    int row = lane / p16, col = lane - row * p16;
+    const int drow = 64 / p16, dcol = 64 - drow * p16;
+    const unsigned char *phib = reinterpret_cast<const unsigned char *>(p.phiT);
+    const size_t rowbytes = (size_t)Kp * 8;
+    for (int base = 0; base < total; base += 64) {   // wave-uniform trip count: every lane takes part in the shuffle
+      const int wr = __shfl(w, row < 64 ? row : 63);
+      const int cc = col < upr ? col : 0;
+      const unsigned char *src = phib + (size_t)wr * rowbytes + (size_t)cc * 16;
+      __builtin_amdgcn_global_load_lds((glb_cvoid_t *)src, (lds_void_t *)(smem + (size_t)base * 16), 16, 0, 0);
+      row += drow; col += dcol;
+      if (col >= p16) { col -= p16; ++row; }
     }
   }
+  // LDS-DMA completion is tracked by vmcnt and the compiler does not know the LDS reads
+  // below depend on it.  (No "memory" clobber: it would turn the scalar theta loads into
+  // vector loads.)
+  asm volatile("s_waitcnt vmcnt(0)");
   __syncthreads();
 
   if (lane < len) {
-    const double *__restrict__ th = p.theta + (size_t)doc * K;   // wave-uniform row
+    const const_double_t *th = (const const_double_t *)(p.theta + (size_t)doc * K);   // wave-uniform row -> scalar loads
     const unsigned char *rowp = smem + lane * pitch;
     const int Ke = K & ~1;
     double sum = 0.0;
-    for (int k = 0; k < Ke; k += 2) {
-      const D2 ph = *reinterpret_cast<const D2 *>(rowp + k * 8);
-      const double s0 = th[k] * ph.a;
-      sum += s0;
-      const double s1 = th[k + 1] * ph.b;
-      sum += s1;
-    }
+    if (p.ablate & 8) sum = 1.0;
+    else
+      for (int k = 0; k < Ke; k += 2) {
+        const D2 ph = *reinterpret_cast<const D2 *>(rowp + k * 8);
+        const double s0 = th[k] * ph.a;
+        sum += s0;
+        const double s1 = th[k + 1] * ph.b;
+        sum += s1;
+      }
     if (K & 1) { const double s0 = th[K - 1] * *reinterpret_cast<const double *>(rowp + (K - 1) * 8); sum += s0; }
 
     const U4 o = philox4x32_10((uint32_t)((uint64_t)(p.tok_base + start + lane)),
@@ -212,81 +231,157 @@ __global__ __launch_bounds__(64) void z_kernel(ZParams p) {
                                (uint32_t)GGS_PURPOSE_Z << 24, p.iteration, (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
     const double U = u53(o.x, o.y);
     double sample = U * sum;
-    int new_topic = -1;
-    for (int k = 0; k < K; ++k) {
-      if (!(sample > 0.0)) break;
-      new_topic = k;
-      sample -= th[k] * *reinterpret_cast<const double *>(rowp + k * 8);
+    // The walk of GGS:108-113,  newTopic = -1; while (sample > 0) { newTopic++; sample -= score[newTopic]; }
+    // in counting form: scores are >= 0, so once sample <= 0 it stays <= 0 and
+    // newTopic + 1 == #{k : sample before subtracting score[k] was > 0}.  The subtraction
+    // itself is the same sequential fp64 chain; the wave leaves when no lane is still > 0.
+    int cnt = 0, k = 0;
+    bool live = !(p.ablate & 2);
+    if (!live) { cnt = 1 + (int)(U * K); sample = 0.0; }
+    for (; live && k + 8 <= K; k += 8) {
+      const D2 q0 = *reinterpret_cast<const D2 *>(rowp + k * 8);
+      const D2 q1 = *reinterpret_cast<const D2 *>(rowp + k * 8 + 16);
+      const D2 q2 = *reinterpret_cast<const D2 *>(rowp + k * 8 + 32);
+      const D2 q3 = *reinterpret_cast<const D2 *>(rowp + k * 8 + 48);
+      cnt += (sample > 0.0); sample -= th[k + 0] * q0.a;
+      cnt += (sample > 0.0); sample -= th[k + 1] * q0.b;
+      cnt += (sample > 0.0); sample -= th[k + 2] * q1.a;
+      cnt += (sample > 0.0); sample -= th[k + 3] * q1.b;
+      cnt += (sample > 0.0); sample -= th[k + 4] * q2.a;
+      cnt += (sample > 0.0); sample -= th[k + 5] * q2.b;
+      cnt += (sample > 0.0); sample -= th[k + 6] * q3.a;
+      cnt += (sample > 0.0); sample -= th[k + 7] * q3.b;
+      live = __any(sample > 0.0);
     }
-    if (new_topic < 0 || sample > 0.0) {        // GGS:116-118 (and running past K)
+    if (live)
+      for (; k < K; ++k) {
+        cnt += (sample > 0.0);
+        sample -= th[k] * *reinterpret_cast<const double *>(rowp + k * 8);
+      }
+    int new_topic = cnt - 1;
+    if (new_topic < 0 || sample > 0.0) {        // GGS:116-118 (and the index past K Java would throw on)
       atomicOr(p.status, ST_INVALID_TOPIC);
       new_topic = new_topic < 0 ? 0 : K - 1;
     }
     p.z[start + lane] = new_topic;
-    if (new_topic != old_topic) {
-      atomicAdd(&p.delta[(size_t)w * K + old_topic], -1);
-      atomicAdd(&p.delta[(size_t)w * K + new_topic], 1);
-    }
   }
 }
 
 // ------------------------------------------------------------------------------
-// K5: updateCounts (UPLDA:1158-1182): n_wk += delta, delta = 0, negative check.
+// K4+K5: type-topic counts.  One workgroup = one segment = up to 4096 consecutive entries
+// of the word-sorted token permutation, all with the same word w: topic histogram in LDS,
+// then K integer adds onto row w (n_wk is zeroed before the launch; several segments of a
+// frequent word add to the same row).  Short segments (rare words) add straight to HBM.
 // ------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void merge_kernel(int32_t *n_wk, int32_t *delta, int64_t n, uint32_t *status) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
-  for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += stride) {
-    if (i + 4 <= n) {
-      int4 d = *reinterpret_cast<int4 *>(delta + i);
-      if ((d.x | d.y | d.z | d.w) != 0) {
-        int4 c = *reinterpret_cast<int4 *>(n_wk + i);
-        c.x += d.x; c.y += d.y; c.z += d.z; c.w += d.w;
-        if ((c.x | c.y | c.z | c.w) < 0) atomicOr(status, ST_NEGATIVE_COUNT);
-        *reinterpret_cast<int4 *>(n_wk + i) = c;
-        *reinterpret_cast<int4 *>(delta + i) = make_int4(0, 0, 0, 0);
-      }
-    } else {
-      for (int64_t j = i; j < n; ++j) {
-        const int32_t d = delta[j];
-        if (d) { const int32_t c = n_wk[j] + d; n_wk[j] = c; delta[j] = 0; if (c < 0) atomicOr(status, ST_NEGATIVE_COUNT); }
-      }
-    }
-  }
-}
+struct CountParams {
+  const int32_t *perm;       // token indices sorted by word
+  const int32_t *z;
+  const int32_t *seg_word;   // [S]
+  const int32_t *seg_begin;  // [S+1] offsets into perm
+  int32_t *n_wk;
+  int32_t K;
+};
 
-// count rebuild for set_z / init (UPLDA:471-474, 1821-1825)
-__global__ __launch_bounds__(256) void count_kernel(const int32_t *tok, const int32_t *z, int64_t n, int32_t K, int32_t *n_wk) {
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
-    atomicAdd(&n_wk[(size_t)tok[i] * K + z[i]], 1);
+__global__ __launch_bounds__(256) void count_sorted_kernel(CountParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  int32_t *hist = reinterpret_cast<int32_t *>(smem);
+  const int seg = blockIdx.x, tid = threadIdx.x, K = p.K;
+  const int beg = p.seg_begin[seg], end = p.seg_begin[seg + 1];
+  int32_t *row = p.n_wk + (size_t)p.seg_word[seg] * K;
+  if (end - beg <= 256) {                    // wave-uniform per block
+    if (beg + tid < end) atomicAdd(&row[p.z[p.perm[beg + tid]]], 1);
+    return;
+  }
+  for (int k = tid; k < K; k += 256) hist[k] = 0;
+  __syncthreads();
+  int i = beg + tid;
+  for (; i + 768 < end; i += 1024) {
+    const int t0 = p.perm[i], t1 = p.perm[i + 256], t2 = p.perm[i + 512], t3 = p.perm[i + 768];
+    const int k0 = p.z[t0], k1 = p.z[t1], k2 = p.z[t2], k3 = p.z[t3];
+    atomicAdd(&hist[k0], 1); atomicAdd(&hist[k1], 1); atomicAdd(&hist[k2], 1); atomicAdd(&hist[k3], 1);
+  }
+  for (; i < end; i += 256) atomicAdd(&hist[p.z[p.perm[i]]], 1);
+  __syncthreads();
+  for (int k = tid; k < K; k += 256) {
+    const int32_t cnt = hist[k];
+    if (cnt) atomicAdd(&row[k], cnt);
+  }
 }
 
 // ------------------------------------------------------------------------------
 // K6/K8: Phi draw (GGS:182-198 / MarsagliaSparseDirichlet.java:31-55).
-//   phi_magnitude  lane per topic: magnitude_k = sum_v (beta + n_kv), v ascending;
-//                  also tokensPerTopic n_k = sum_v n_kv
-//   phi_gamma      lane per (v,k): Gamma(partition*magnitude) -> phiT (unnormalised)
-//   phi_total      lane per topic: sum_v gamma, v ascending
-//   phi_normalise  lane per (v,k): divide, clamp, optional running phiMean +=
+//   column_chain<int32,true>   magnitude_k = sum_v (beta + n_kv), v ascending (the
+//                              Dirichlet(double[]) constructor); also tokensPerTopic
+//   phi_gamma                  lane per (v,k): Gamma(partition*magnitude) -> phiT (unnormalised)
+//   column_chain<double,false> sum_v gamma, v ascending (ParallelDirichlet.java:53-57)
+//   phi_normalise              lane per (v,k): divide, clamp, optional running phiMean +=
+//
+// column_chain: a sum over V in index order is one dependent fp64 add chain per topic --
+// it cannot be split, only fed.  One workgroup owns 8 adjacent topics (a 64-byte / 32-byte
+// slice of every row); all 256 threads stream [1024 rows x 8 topics] tiles through a
+// double-buffered LDS ring with plain coalesced loads while 8 lanes of wave 0 walk the
+// previous tile row by row.  K/8 workgroups keep K/8 CUs' worth of loads in flight.
 // ------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void phi_magnitude_kernel(const int32_t *n_wk, int32_t K, int32_t V, double beta,
-                                                           double *mag, int32_t *n_k) {
-  const int k = blockIdx.x * 64 + threadIdx.x;
-  if (k >= K) return;
-  double m = 0;
+template <typename T, bool MAGNITUDE>
+__global__ __launch_bounds__(256) void column_chain_kernel(const T *src, int32_t pitch, int32_t K, int32_t V, double beta,
+                                                           double *out_sum, int32_t *out_nk) {
+  constexpr int TPB = 8, ROWS = 1024, PER_THREAD = ROWS * TPB / 256;
+  __shared__ T buf[2][ROWS * TPB];
+  const int tid = threadIdx.x;
+  const int k0 = blockIdx.x * TPB;
+  const int t = tid & 7, r0 = tid >> 3;             // element (row r0 + 32 j, topic t)
+  const bool kvalid = k0 + t < K;
+  const T *col = src + k0 + t;
+
+  T regs[PER_THREAD];
+  auto load_tile = [&](int v0) {
+#pragma unroll
+    for (int j = 0; j < PER_THREAD; ++j) {
+      const int v = v0 + r0 + 32 * j;
+      regs[j] = (kvalid && v < V) ? col[(size_t)v * pitch] : T(0);
+    }
+  };
+  auto store_tile = [&](int b) {
+#pragma unroll
+    for (int j = 0; j < PER_THREAD; ++j) buf[b][(r0 + 32 * j) * TPB + t] = regs[j];
+  };
+
+  double acc = 0;
   int32_t nk = 0;
-  const int32_t *col = n_wk + k;
-  int v = 0;
-  for (; v + 8 <= V; v += 8) {
-    int32_t c[8];
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  int b = 0;
+  for (int v0 = 0; v0 < V; v0 += ROWS, b ^= 1) {
+    const bool more = v0 + ROWS < V;
+    if (more) load_tile(v0 + ROWS);                 // in flight while the chain below runs
+    if (tid < TPB) {
+      const int rows = min(ROWS, V - v0);
+      const T *bp = &buf[b][tid];
+      int r = 0;
+      for (; r + 8 <= rows; r += 8) {
+        T x[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) c[j] = col[(size_t)(v + j) * K];
+        for (int j = 0; j < 8; ++j) x[j] = bp[(r + j) * TPB];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { m += beta + (double)c[j]; nk += c[j]; }
+        for (int j = 0; j < 8; ++j) {
+          if (MAGNITUDE) { acc += beta + (double)x[j]; nk += (int32_t)x[j]; }   // GGS:188 then Dirichlet(double[]) magnitude
+          else acc += (double)x[j];
+        }
+      }
+      for (; r < rows; ++r) {
+        const T x = bp[r * TPB];
+        if (MAGNITUDE) { acc += beta + (double)x; nk += (int32_t)x; }
+        else acc += (double)x;
+      }
+    }
+    if (more) store_tile(b ^ 1);
+    __syncthreads();
   }
-  for (; v < V; ++v) { const int32_t c = col[(size_t)v * K]; m += beta + (double)c; nk += c; }
-  mag[k] = m;
-  n_k[k] = nk;
+  if (tid < TPB && k0 + tid < K) {
+    out_sum[k0 + tid] = acc;
+    if (MAGNITUDE) out_nk[k0 + tid] = nk;
+  }
 }
 
 struct PhiGammaParams {
@@ -327,23 +422,6 @@ __global__ __launch_bounds__(256) void phi_gamma_kernel(PhiGammaParams p) {
     }
     p.phiT[(size_t)v * p.Kp + k] = g;
   }
-}
-
-__global__ __launch_bounds__(64) void phi_total_kernel(const double *phiT, int32_t K, int32_t Kp, int32_t V, double *tot) {
-  const int k = blockIdx.x * 64 + threadIdx.x;
-  if (k >= K) return;
-  double s = 0;
-  const double *col = phiT + k;
-  int v = 0;
-  for (; v + 8 <= V; v += 8) {
-    double g[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) g[j] = col[(size_t)(v + j) * Kp];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) s += g[j];
-  }
-  for (; v < V; ++v) s += col[(size_t)v * Kp];
-  tot[k] = s;
 }
 
 __global__ __launch_bounds__(256) void phi_normalise_kernel(double *phiT, const double *tot, int32_t K, int32_t Kp, int32_t V,
@@ -389,15 +467,14 @@ __global__ __launch_bounds__(64) void doc_topic_kernel(const int64_t *doc_ptr, c
   for (int64_t i = doc_ptr[d] + threadIdx.x; i < doc_ptr[d + 1]; i += 64) atomicAdd(&row[z[i]], 1);
 }
 
-// paranoid invariants (UPLDA:299-338): counts >= 0, column sums == n_k, total == N, deltas all zero
-__global__ __launch_bounds__(256) void invariants_kernel(const int32_t *n_wk, const int32_t *delta, int64_t n, int32_t K,
-                                                         unsigned long long *total, int32_t *colsum, uint32_t *flags) {
+// paranoid invariants (UPLDA:299-338): counts >= 0, column sums == n_k, total == N
+__global__ __launch_bounds__(256) void invariants_kernel(const int32_t *n_wk, int64_t n, int32_t K, unsigned long long *total,
+                                                         int32_t *colsum, uint32_t *flags) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   unsigned long long t = 0;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int32_t c = n_wk[i];
     if (c < 0) atomicOr(flags, 1u);
-    if (delta[i] != 0) atomicOr(flags, 2u);
     if (c) { t += (unsigned long long)c; atomicAdd(&colsum[i % K], c); }
   }
   if (t) atomicAdd(total, t);

@@ -123,31 +123,13 @@ class GGSHandle:
     def synchronize(self):
         self._chk(self._L.ggs_synchronize(self._h))
 
-    def delta_device_ptr(self):
-        p, n = C.c_void_p(), C.c_int64()
-        self._chk(self._L.ggs_delta_device_ptr(self._h, C.byref(p), C.byref(n)))
-        return p.value, n.value
-
     def counts_device_ptr(self):
         p, n = C.c_void_p(), C.c_int64()
         self._chk(self._L.ggs_counts_device_ptr(self._h, C.byref(p), C.byref(n)))
         return p.value, n.value
 
-    def use_external_delta(self, dev_ptr):
-        self._chk(self._L.ggs_use_external_delta(self._h, C.c_void_p(dev_ptr)))
-
     def set_global_token_count(self, n):
         self._chk(self._L.ggs_set_global_token_count(self._h, int(n)))
-
-    def get_delta(self):
-        out = np.empty((self.V, self.K), np.int32)
-        self._chk(self._L.ggs_get_delta(self._h, _ip(out)))
-        return out
-
-    def set_delta(self, d):
-        d = np.ascontiguousarray(d, np.int32)
-        assert d.shape == (self.V, self.K)
-        self._chk(self._L.ggs_set_delta(self._h, _ip(d)))
 
     # ---- getters ----
     def get_z(self):

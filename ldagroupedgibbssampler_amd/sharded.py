@@ -6,7 +6,8 @@ randomscan/document/EvenSplitBatchBuilder.java:30-44) sample exactly what one GP
 every shard keys its Philox streams by GLOBAL token / document index.  Per sweep there is
 ONE exchange, where the Java code merges its thread-shared AtomicInteger deltas
 (UPLDA:1107-1221; the ADLDA analogue is sumTypeTopicCounts, ADLDA.java:302): a sum
-all-reduce of the int32 [V][K] delta buffer (RCCL on GPUs).  Phi is then re-drawn on every
+all-reduce of the int32 [V][K] count buffer -- each shard's local (word, z) histogram --
+(RCCL on GPUs).  Phi is then re-drawn on every
 rank from identical counts and identical Philox keys, hence bit-identical without a
 broadcast.
 
@@ -38,14 +39,12 @@ class TorchHipExchange:
     def __init__(self, handle, group=None):
         import torch.distributed as dist
         self.dist, self.group = dist, group
-        self.delta = wrap_device_int32(*handle.delta_device_ptr())
         self.counts = wrap_device_int32(*handle.counts_device_ptr())
 
-    def allreduce_delta(self):
-        self.dist.all_reduce(self.delta, op=self.dist.ReduceOp.SUM, group=self.group)
-
-    def allreduce_counts(self):
+    def allreduce_sweep(self):
         self.dist.all_reduce(self.counts, op=self.dist.ReduceOp.SUM, group=self.group)
+
+    allreduce_startup = allreduce_sweep
 
 
 class ShardedGGS:
@@ -53,8 +52,8 @@ class ShardedGGS:
 
     engine      object with the GGSHandle method names (set_corpus, set_z, init_phi,
                 sweep_begin, sweep_end, set_global_token_count, get_z, ...)
-    exchange    object with allreduce_delta() / allreduce_counts() acting on the engine's
-                delta / count buffers
+    exchange    object with allreduce_startup() / allreduce_sweep() acting on whatever the
+                engine exchanges (the HIP engine: its count buffer, both times)
     """
 
     def __init__(self, engine, exchange_factory, corpus, rank, world_size):
@@ -73,13 +72,13 @@ class ShardedGGS:
         computed once), builds local counts, sum-all-reduces them, draws the initial Phi."""
         z_local = np.ascontiguousarray(z_global[self.tok_base:self.tok_base + self.local.num_tokens], np.int32)
         self.engine.set_z(z_local, redraw_phi=False)
-        self.exchange.allreduce_counts()
+        self.exchange.allreduce_startup()
         self.engine.init_phi()
 
     def sweep(self, n=1):
         for _ in range(n):
             self.engine.sweep_begin()
-            self.exchange.allreduce_delta()
+            self.exchange.allreduce_sweep()
             self.engine.sweep_end()
 
 

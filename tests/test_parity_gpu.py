@@ -235,14 +235,13 @@ def test_sharded_via_torch(native, oracle):
     torch.cuda.synchronize()
     for h, _, _ in shards:
         h.init_phi()
-    deltas = [wrap_device_int32(*h.delta_device_ptr()) for h, _, _ in shards]
     for it in range(3):
         for h, _, _ in shards:
-            h.sweep_begin()
+            h.sweep_begin()          # leaves THIS shard's (word, z) histogram in its count buffer
         for h, _, _ in shards:
             h.synchronize()
-        tot = torch.stack(deltas).sum(0, dtype=torch.int32)
-        for t in deltas:
+        tot = torch.stack(counts).sum(0, dtype=torch.int32)
+        for t in counts:
             t.copy_(tot)
         torch.cuda.synchronize()
         for h, _, _ in shards:

@@ -40,7 +40,7 @@ struct ggs_handle {
 
   int64_t D = 0, N = 0, C = 0, S = 0, doc_base = 0, tok_base = 0, global_tokens = -1;
   bool have_corpus = false, have_phi = false, in_sweep = false;
-  int32_t theta_docs_per_block = 0, theta_lds = 0, z_lds = 0;
+  int32_t theta_docs_per_block = 0, theta_lds = 0, z_lds = 0, z_tile_tokens = 0, z_waves_per_cu = 0, num_cus = 0;
 
   hipStream_t stream = nullptr;
   // device buffers
@@ -173,9 +173,18 @@ int launch_z(ggs_handle *h) {
   zp.tok = h->d_tok; zp.z = h->d_z; zp.chunk_start = h->d_chunk_start; zp.chunk_doc = h->d_chunk_doc; zp.chunk_len = h->d_chunk_len;
   zp.theta = h->d_theta; zp.phiT = h->d_phiT; zp.status = h->d_status;
   zp.tok_base = h->tok_base; zp.seed = h->seed; zp.iteration = (uint32_t)h->iteration;
-  zp.K = h->K; zp.Kp = h->Kp; zp.pitch16 = h->pitch16;
+  zp.K = h->K; zp.Kp = h->Kp; zp.pitch16 = h->pitch16; zp.tile_tokens = h->z_tile_tokens;
+  zp.num_chunks = h->C;
   zp.ablate = h->ablate;
-  hipLaunchKernelGGL(z_kernel, dim3((unsigned)h->C), dim3(64), h->z_lds, h->stream, zp);
+  // persistent waves: as many single-wave workgroups as stay resident, each strides the chunk table
+  const dim3 grid((unsigned)std::min<int64_t>(h->C, (int64_t)h->num_cus * h->z_waves_per_cu)), block(64);
+  const int nt = (h->K + 63) / 64;
+  if (nt <= 1) hipLaunchKernelGGL(z_kernel<1>, grid, block, h->z_lds, h->stream, zp);
+  else if (nt <= 2) hipLaunchKernelGGL(z_kernel<2>, grid, block, h->z_lds, h->stream, zp);
+  else if (nt <= 4) hipLaunchKernelGGL(z_kernel<4>, grid, block, h->z_lds, h->stream, zp);
+  else if (nt <= 8) hipLaunchKernelGGL(z_kernel<8>, grid, block, h->z_lds, h->stream, zp);
+  else if (nt <= 16) hipLaunchKernelGGL(z_kernel<16>, grid, block, h->z_lds, h->stream, zp);
+  else hipLaunchKernelGGL(z_kernel<20>, grid, block, h->z_lds, h->stream, zp);
   HIP_TRY(h, hipGetLastError());
   return GGS_OK;
 }
@@ -275,9 +284,31 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
   int rc = GGS_OK;
   auto bail = [&](int code) { ggs_destroy(h); return code; };
   if (hipSetDevice(h->device) != hipSuccess) return bail(GGS_ERR_HIP);
-  // LDS budgets
-  h->z_lds = 64 * h->pitch16 * 16;
-  if (h->z_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);   // K > ~1270 needs the K-sliced kernel (not in this round)
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, h->device) != hipSuccess) return bail(GGS_ERR_HIP);
+    h->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  // LDS budget of the z kernel: a tile of T token rows + one theta row per wave.  The waves
+  // are persistent and stride the chunk table statically, so the grid must not exceed what
+  // is truly co-resident: measured on MI355X, LDS is handed out in granules (6 x 26,912 B
+  // do not fit a CU although the occupancy API says they do), so residency is computed
+  // with the request rounded up to 2 KiB.  T is the largest tile that still lets 6
+  // single-wave workgroups share a CU -- the passes are latency chains, so waves in flight
+  // matter more than lanes in use -- but at least 8 rows.
+  {
+    constexpr int kGranule = 2048;
+    auto alloc_of = [&](int bytes) { return (bytes + kGranule - 1) / kGranule * kGranule; };
+    const int pitch = h->pitch16 * 16, thbytes = ((h->Kp * 8 + 15) / 16) * 16;
+    int T = (kMaxLdsBytes / 6 / kGranule * kGranule - thbytes) / pitch;
+    if (const char *e = std::getenv("GGS_DEBUG_TILE")) T = std::atoi(e);
+    T = std::max(8, std::min(64, T));
+    h->z_tile_tokens = T;
+    h->z_lds = T * pitch + thbytes;
+    if (h->z_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);   // K > ~2400 needs a K-sliced kernel (not in this round)
+    h->z_waves_per_cu = std::max(1, std::min(8, kMaxLdsBytes / alloc_of(h->z_lds)));
+    if (const char *e = std::getenv("GGS_DEBUG_WPC")) h->z_waves_per_cu = std::max(1, std::atoi(e));
+  }
   {
     int B = 64;
     auto lds_of = [&](int b) { const int bp = b | 1; return (int)((size_t)h->K * bp * 12 + (size_t)b * 20); };
@@ -285,8 +316,12 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     if (lds_of(B) > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);
     h->theta_docs_per_block = B; h->theta_lds = lds_of(B);
   }
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(z_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, h->z_lds) != hipSuccess ||
-      hipFuncSetAttribute(reinterpret_cast<const void *>(theta_kernel<kThetaBlock>), hipFuncAttributeMaxDynamicSharedMemorySize, h->theta_lds) != hipSuccess)
+  const void *zk[] = {reinterpret_cast<const void *>(z_kernel<1>), reinterpret_cast<const void *>(z_kernel<2>),
+                      reinterpret_cast<const void *>(z_kernel<4>), reinterpret_cast<const void *>(z_kernel<8>),
+                      reinterpret_cast<const void *>(z_kernel<16>), reinterpret_cast<const void *>(z_kernel<20>)};
+  for (const void *f : zk)
+    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, h->z_lds) != hipSuccess) return bail(GGS_ERR_HIP);
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(theta_kernel<kThetaBlock>), hipFuncAttributeMaxDynamicSharedMemorySize, h->theta_lds) != hipSuccess)
     return bail(GGS_ERR_HIP);
   const size_t kv = (size_t)h->K * h->V;
   if ((rc = dev_alloc(h, &h->d_alpha, h->K)) || (rc = dev_alloc(h, &h->d_phiT, (size_t)h->V * h->Kp)) ||
@@ -343,14 +378,14 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
   int rc = bind_device(h);
   if (rc) return rc;
 
-  // z-kernel work items: each document is cut into ceil(len/64) near-equal chunks.
+  // z-kernel work items: each document is cut into ceil(len/T) near-equal chunks of <= T tokens.
   std::vector<int64_t> cstart;
   std::vector<int32_t> cdoc, clen;
   cstart.reserve((size_t)(N / 48 + D)); cdoc.reserve(cstart.capacity()); clen.reserve(cstart.capacity());
   for (int64_t d = 0; d < D; ++d) {
     const int64_t len = doc_ptr[d + 1] - doc_ptr[d];
     if (len == 0) continue;
-    const int64_t n = (len + 63) / 64, base = len / n, rem = len % n;
+    const int64_t T = h->z_tile_tokens, n = (len + T - 1) / T, base = len / n, rem = len % n;
     int64_t s = doc_ptr[d];
     for (int64_t j = 0; j < n; ++j) {
       const int64_t l = base + (j < rem ? 1 : 0);

@@ -132,140 +132,7 @@ __global__ __launch_bounds__(BLOCK) void theta_kernel(ThetaParams p) {
   }
 }
 
-// ------------------------------------------------------------------------------
-// K3: the token loop (GGS:79-130).  One wave = one chunk of <=64 tokens of one
-// document; lane t owns token t.
-//   stage   the wave copies the chunk's phiT rows HBM -> LDS by LDS-DMA, fully coalesced
-//           (a row is Kp*8 contiguous bytes)
-//   pass 1  lane t: sum = sum_k theta[k]*phi[k][w_t], k ascending (GGS:96-101)
-//   draw    U from Philox (GGS:107), sample = U*sum
-//   pass 2  lane t: the "while (sample > 0) sample -= score[++k]" walk (GGS:108-113)
-//   store   z (the count updates of GGS:93,129 are rebuilt by count_sorted_kernel)
-// LDS row pitch = pitch16*16 bytes with pitch16 odd, so the 16-byte per-lane reads
-// of passes 1-2 (lane t reads row t) are bank-conflict free.
-// ------------------------------------------------------------------------------
-struct ZParams {
-  const int32_t *tok;
-  int32_t *z;
-  const int64_t *chunk_start;  // local token index of the chunk's first token
-  const int32_t *chunk_doc;    // local document index
-  const int32_t *chunk_len;
-  const double *theta;
-  const double *phiT;
-  uint32_t *status;
-  int64_t tok_base;
-  uint64_t seed;
-  uint32_t iteration;
-  int32_t K, Kp, pitch16;
-  int32_t ablate;   // timing-only experiments (env GGS_DEBUG_ABLATE): 2 no walk, 4 no staging, 8 no sum pass
-};
-
-struct alignas(16) D2 { double a, b; };
-
-typedef __attribute__((address_space(3))) void lds_void_t;
-typedef __attribute__((address_space(1))) const void glb_cvoid_t;
-// theta is written by the previous kernel and only read here; reading it through the
-// constant address space makes every wave-uniform access a scalar (SMEM) load whatever the
-// alias analysis thinks of the LDS-DMA intrinsic.
-typedef __attribute__((address_space(4))) const double const_double_t;
-
-__global__ __launch_bounds__(64) void z_kernel(ZParams p) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int lane = threadIdx.x;
-  const int64_t c = blockIdx.x;
-  const int64_t start = p.chunk_start[c];
-  const int len = p.chunk_len[c];
-  const int doc = p.chunk_doc[c];
-  const int K = p.K, Kp = p.Kp;
-  const int upr = Kp >> 1;                 // 16-byte units per phi row
-  const int p16 = p.pitch16;               // 16-byte units per LDS row (odd; = upr or upr + 1 pad unit)
-  const int pitch = p16 * 16;              // LDS row pitch, bytes
-
-  int w = 0;
-  if (lane < len) w = p.tok[start + lane];
-
-  // ---- stage the chunk's phiT rows HBM -> LDS with LDS-DMA (global_load_lds_dwordx4).
-  // One wave-instruction fills 64 consecutive 16-byte LDS units (1 KiB); unit u of the tile
-  // is (row u / p16, col u % p16), so the LDS image is row-major with pitch p16 and every
-  // lane's SOURCE address picks the matching 16 bytes of its row.  The pad unit (col == upr)
-  // and units past the chunk re-read a valid address; nobody reads those LDS bytes.
-  if (!(p.ablate & 4)) {
-    const int total = len * p16;
-    int row = lane / p16, col = lane - row * p16;
-    const int drow = 64 / p16, dcol = 64 - drow * p16;
-    const unsigned char *phib = reinterpret_cast<const unsigned char *>(p.phiT);
-    const size_t rowbytes = (size_t)Kp * 8;
-    for (int base = 0; base < total; base += 64) {   // wave-uniform trip count: every lane takes part in the shuffle
-      const int wr = __shfl(w, row < 64 ? row : 63);
-      const int cc = col < upr ? col : 0;
-      const unsigned char *src = phib + (size_t)wr * rowbytes + (size_t)cc * 16;
-      __builtin_amdgcn_global_load_lds((glb_cvoid_t *)src, (lds_void_t *)(smem + (size_t)base * 16), 16, 0, 0);
-      row += drow; col += dcol;
-      if (col >= p16) { col -= p16; ++row; }
-    }
-  }
-  // LDS-DMA completion is tracked by vmcnt and the compiler does not know the LDS reads
-  // below depend on it.  (No "memory" clobber: it would turn the scalar theta loads into
-  // vector loads.)
-  asm volatile("s_waitcnt vmcnt(0)");
-  __syncthreads();
-
-  if (lane < len) {
-    const const_double_t *th = (const const_double_t *)(p.theta + (size_t)doc * K);   // wave-uniform row -> scalar loads
-    const unsigned char *rowp = smem + lane * pitch;
-    const int Ke = K & ~1;
-    double sum = 0.0;
-    if (p.ablate & 8) sum = 1.0;
-    else
-      for (int k = 0; k < Ke; k += 2) {
-        const D2 ph = *reinterpret_cast<const D2 *>(rowp + k * 8);
-        const double s0 = th[k] * ph.a;
-        sum += s0;
-        const double s1 = th[k + 1] * ph.b;
-        sum += s1;
-      }
-    if (K & 1) { const double s0 = th[K - 1] * *reinterpret_cast<const double *>(rowp + (K - 1) * 8); sum += s0; }
-
-    const U4 o = philox4x32_10((uint32_t)((uint64_t)(p.tok_base + start + lane)),
-                               (uint32_t)((uint64_t)(p.tok_base + start + lane) >> 32),
-                               (uint32_t)GGS_PURPOSE_Z << 24, p.iteration, (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
-    const double U = u53(o.x, o.y);
-    double sample = U * sum;
-    // The walk of GGS:108-113,  newTopic = -1; while (sample > 0) { newTopic++; sample -= score[newTopic]; }
-    // in counting form: scores are >= 0, so once sample <= 0 it stays <= 0 and
-    // newTopic + 1 == #{k : sample before subtracting score[k] was > 0}.  The subtraction
-    // itself is the same sequential fp64 chain; the wave leaves when no lane is still > 0.
-    int cnt = 0, k = 0;
-    bool live = !(p.ablate & 2);
-    if (!live) { cnt = 1 + (int)(U * K); sample = 0.0; }
-    for (; live && k + 8 <= K; k += 8) {
-      const D2 q0 = *reinterpret_cast<const D2 *>(rowp + k * 8);
-      const D2 q1 = *reinterpret_cast<const D2 *>(rowp + k * 8 + 16);
-      const D2 q2 = *reinterpret_cast<const D2 *>(rowp + k * 8 + 32);
-      const D2 q3 = *reinterpret_cast<const D2 *>(rowp + k * 8 + 48);
-      cnt += (sample > 0.0); sample -= th[k + 0] * q0.a;
-      cnt += (sample > 0.0); sample -= th[k + 1] * q0.b;
-      cnt += (sample > 0.0); sample -= th[k + 2] * q1.a;
-      cnt += (sample > 0.0); sample -= th[k + 3] * q1.b;
-      cnt += (sample > 0.0); sample -= th[k + 4] * q2.a;
-      cnt += (sample > 0.0); sample -= th[k + 5] * q2.b;
-      cnt += (sample > 0.0); sample -= th[k + 6] * q3.a;
-      cnt += (sample > 0.0); sample -= th[k + 7] * q3.b;
-      live = __any(sample > 0.0);
-    }
-    if (live)
-      for (; k < K; ++k) {
-        cnt += (sample > 0.0);
-        sample -= th[k] * *reinterpret_cast<const double *>(rowp + k * 8);
-      }
-    int new_topic = cnt - 1;
-    if (new_topic < 0 || sample > 0.0) {        // GGS:116-118 (and the index past K Java would throw on)
-      atomicOr(p.status, ST_INVALID_TOPIC);
-      new_topic = new_topic < 0 ? 0 : K - 1;
-    }
-    p.z[start + lane] = new_topic;
-  }
-}
+// K3, the token loop (GGS:79-130), lives in ggs_z_kernel.hpp.
 
 // ------------------------------------------------------------------------------
 // K4+K5: type-topic counts.  One workgroup = one segment = up to 4096 consecutive entries
@@ -330,15 +197,16 @@ __global__ __launch_bounds__(256) void column_chain_kernel(const T *src, int32_t
   const int tid = threadIdx.x;
   const int k0 = blockIdx.x * TPB;
   const int t = tid & 7, r0 = tid >> 3;             // element (row r0 + 32 j, topic t)
-  const bool kvalid = k0 + t < K;
-  const T *col = src + k0 + t;
+  // Loads are unconditional (addresses clamped into the matrix) so that all PER_THREAD of
+  // them are in flight together; rows >= V and topics >= K are loaded but never consumed.
+  const T *col = src + min(k0 + t, K - 1);
 
   T regs[PER_THREAD];
   auto load_tile = [&](int v0) {
 #pragma unroll
     for (int j = 0; j < PER_THREAD; ++j) {
-      const int v = v0 + r0 + 32 * j;
-      regs[j] = (kvalid && v < V) ? col[(size_t)v * pitch] : T(0);
+      const int v = min(v0 + r0 + 32 * j, V - 1);
+      regs[j] = col[(size_t)v * pitch];
     }
   };
   auto store_tile = [&](int b) {
@@ -359,14 +227,24 @@ __global__ __launch_bounds__(256) void column_chain_kernel(const T *src, int32_t
       const int rows = min(ROWS, V - v0);
       const T *bp = &buf[b][tid];
       int r = 0;
-      for (; r + 8 <= rows; r += 8) {
-        T x[8];
+      if (rows >= 16) {
+        // 16 rows per step; the LDS reads of the next 16 are issued before this step's
+        // dependent add chain runs (the tile has ROWS rows allocated, so reading ahead of
+        // `rows` stays inside the buffer and is never added)
+        T x[16], y[16];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = bp[(r + j) * TPB];
+        for (int j = 0; j < 16; ++j) x[j] = bp[j * TPB];
+        for (; r + 16 <= rows; r += 16) {
+          const int rn = (r + 32 <= ROWS) ? r + 16 : r;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if (MAGNITUDE) { acc += beta + (double)x[j]; nk += (int32_t)x[j]; }   // GGS:188 then Dirichlet(double[]) magnitude
-          else acc += (double)x[j];
+          for (int j = 0; j < 16; ++j) y[j] = bp[(rn + j) * TPB];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            if (MAGNITUDE) { acc += beta + (double)x[j]; nk += (int32_t)x[j]; }   // GGS:188 then Dirichlet(double[]) magnitude
+            else acc += (double)x[j];
+          }
+#pragma unroll
+          for (int j = 0; j < 16; ++j) x[j] = y[j];
         }
       }
       for (; r < rows; ++r) {
@@ -516,3 +394,5 @@ __global__ void debug_draw_kernel(int kind, uint64_t seed, uint32_t iteration, u
 }
 
 }  // namespace ggs
+
+#include "ggs_z_kernel.hpp"

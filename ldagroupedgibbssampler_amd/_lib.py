@@ -93,7 +93,7 @@ SIGNATURES = {
 
 def build(force=False):
     """Compile libggs_hip.so in-tree (hipcc --offload-arch=gfx950)."""
-    srcs = [os.path.join(CSRC, f) for f in ("ggs_api.hip", "ggs_kernels.hpp", "ggs_z_kernel.hpp", "ggs_device_math.hpp")] + [HEADER_PATH]
+    srcs = [os.path.join(CSRC, f) for f in ("ggs_api.hip", "ggs_kernels.hpp", "ggs_z_kernel.hpp", "ggs_z_sliced.hpp", "ggs_device_math.hpp")] + [HEADER_PATH]
     if (not force and os.path.exists(LIB_PATH)
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
         return LIB_PATH

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "ggs_kernels.hpp"
+#include "ggs_z_sliced.hpp"
 
 using namespace ggs;
 
@@ -41,6 +42,7 @@ struct ggs_handle {
   int64_t D = 0, N = 0, C = 0, S = 0, doc_base = 0, tok_base = 0, global_tokens = -1;
   bool have_corpus = false, have_phi = false, in_sweep = false;
   int32_t theta_docs_per_block = 0, theta_lds = 0, z_lds = 0, z_tile_tokens = 0, z_waves_per_cu = 0, num_cus = 0;
+  bool z_sliced = false;   // scores-in-registers kernel (K <= kSlicedMaxTopics)
 
   hipStream_t stream = nullptr;
   // device buffers
@@ -126,7 +128,10 @@ int launch_count_rebuild(ggs_handle *h) {
 
 int launch_magnitude(ggs_handle *h) {
   hipLaunchKernelGGL((column_chain_kernel<int32_t, true>), dim3((h->K + 7) / 8), dim3(256), 0, h->stream, h->d_n_wk, h->K, h->K, h->V, h->beta,
-                     h->d_mag, h->d_n_k);
+                     h->d_mag);
+  HIP_TRY(h, hipMemsetAsync(h->d_n_k, 0, sizeof(int32_t) * (size_t)h->K, h->stream));
+  hipLaunchKernelGGL(topic_totals_kernel, dim3(grid_for((int64_t)h->K * h->V, 256, 16)), dim3(256), (size_t)h->K * sizeof(int32_t), h->stream, h->d_n_wk,
+                     h->K, h->V, h->d_n_k);
   HIP_TRY(h, hipGetLastError());
   return GGS_OK;
 }
@@ -146,8 +151,7 @@ int launch_phi(ggs_handle *h, bool initial, bool accumulate_mean) {
   gp.initial = initial ? 1 : 0;
   const int64_t kv = (int64_t)K * V;
   hipLaunchKernelGGL(phi_gamma_kernel, dim3(grid_for(kv, 256, 2)), dim3(256), 0, h->stream, gp);
-  hipLaunchKernelGGL((column_chain_kernel<double, false>), dim3((K + 7) / 8), dim3(256), 0, h->stream, h->d_phiT, h->Kp, K, V, 0.0, h->d_tot,
-                     static_cast<int32_t *>(nullptr));
+  hipLaunchKernelGGL((column_chain_kernel<double, false>), dim3((K + 7) / 8), dim3(256), 0, h->stream, h->d_phiT, h->Kp, K, V, 0.0, h->d_tot);
   hipLaunchKernelGGL(phi_normalise_kernel, dim3(grid_for(kv, 256, 2)), dim3(256), 0, h->stream, h->d_phiT, h->d_tot, K, h->Kp, V,
                      accumulate_mean ? h->d_phi_mean : nullptr);
   HIP_TRY(h, hipGetLastError());
@@ -167,6 +171,36 @@ int launch_theta(ggs_handle *h) {
   return GGS_OK;
 }
 
+// z_sliced_kernel<KMAX> for KMAX = K rounded up to a multiple of 8
+const void *sliced_kernel_for(int K) {
+  switch ((K + 7) / 8) {
+    case 1: return reinterpret_cast<const void *>(z_sliced_kernel<8>);
+    case 2: return reinterpret_cast<const void *>(z_sliced_kernel<16>);
+    case 3: return reinterpret_cast<const void *>(z_sliced_kernel<24>);
+    case 4: return reinterpret_cast<const void *>(z_sliced_kernel<32>);
+    case 5: return reinterpret_cast<const void *>(z_sliced_kernel<40>);
+    case 6: return reinterpret_cast<const void *>(z_sliced_kernel<48>);
+    case 7: return reinterpret_cast<const void *>(z_sliced_kernel<56>);
+    case 8: return reinterpret_cast<const void *>(z_sliced_kernel<64>);
+    case 9: return reinterpret_cast<const void *>(z_sliced_kernel<72>);
+    case 10: return reinterpret_cast<const void *>(z_sliced_kernel<80>);
+    case 11: return reinterpret_cast<const void *>(z_sliced_kernel<88>);
+    case 12: return reinterpret_cast<const void *>(z_sliced_kernel<96>);
+    case 13: return reinterpret_cast<const void *>(z_sliced_kernel<104>);
+    case 14: return reinterpret_cast<const void *>(z_sliced_kernel<112>);
+    case 15: return reinterpret_cast<const void *>(z_sliced_kernel<120>);
+    case 16: return reinterpret_cast<const void *>(z_sliced_kernel<128>);
+    case 17: return reinterpret_cast<const void *>(z_sliced_kernel<136>);
+    case 18: return reinterpret_cast<const void *>(z_sliced_kernel<144>);
+    case 19: return reinterpret_cast<const void *>(z_sliced_kernel<152>);
+    case 20: return reinterpret_cast<const void *>(z_sliced_kernel<160>);
+    case 21: return reinterpret_cast<const void *>(z_sliced_kernel<168>);
+    case 22: return reinterpret_cast<const void *>(z_sliced_kernel<176>);
+    case 23: return reinterpret_cast<const void *>(z_sliced_kernel<184>);
+    default: return reinterpret_cast<const void *>(z_sliced_kernel<192>);
+  }
+}
+
 int launch_z(ggs_handle *h) {
   if (h->C == 0) return GGS_OK;
   ZParams zp{};
@@ -179,7 +213,10 @@ int launch_z(ggs_handle *h) {
   // persistent waves: as many single-wave workgroups as stay resident, each strides the chunk table
   const dim3 grid((unsigned)std::min<int64_t>(h->C, (int64_t)h->num_cus * h->z_waves_per_cu)), block(64);
   const int nt = (h->K + 63) / 64;
-  if (nt <= 1) hipLaunchKernelGGL(z_kernel<1>, grid, block, h->z_lds, h->stream, zp);
+  if (h->z_sliced) {
+    void *args[] = {&zp};
+    HIP_TRY(h, hipLaunchKernel(sliced_kernel_for(h->K), grid, block, args, (size_t)h->z_lds, h->stream));
+  } else if (nt <= 1) hipLaunchKernelGGL(z_kernel<1>, grid, block, h->z_lds, h->stream, zp);
   else if (nt <= 2) hipLaunchKernelGGL(z_kernel<2>, grid, block, h->z_lds, h->stream, zp);
   else if (nt <= 4) hipLaunchKernelGGL(z_kernel<4>, grid, block, h->z_lds, h->stream, zp);
   else if (nt <= 8) hipLaunchKernelGGL(z_kernel<8>, grid, block, h->z_lds, h->stream, zp);
@@ -300,6 +337,16 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     constexpr int kGranule = 2048;
     auto alloc_of = [&](int bytes) { return (bytes + kGranule - 1) / kGranule * kGranule; };
     const int pitch = h->pitch16 * 16, thbytes = ((h->Kp * 8 + 15) / 16) * 16;
+    h->z_sliced = h->K <= kSlicedMaxTopics;
+    if (const char *e = std::getenv("GGS_DEBUG_ZKERNEL")) h->z_sliced = h->z_sliced && std::atoi(e) != 0;
+    if (h->z_sliced) {
+      // 64-token chunks, a 2-slot ring of 32-topic slices + the theta row; one wave per SIMD
+      // (the score registers take most of the 512-entry file)
+      h->z_tile_tokens = 64;
+      h->z_lds = 2 * kSliceBytes + ((h->K + 7) / 8) * 64;   // ring + theta row zero-padded to KMAX
+      h->z_waves_per_cu = std::min(4, kMaxLdsBytes / alloc_of(h->z_lds));
+      if (const char *e = std::getenv("GGS_DEBUG_WPC")) h->z_waves_per_cu = std::max(1, std::atoi(e));
+    } else {
     int T = (kMaxLdsBytes / 6 / kGranule * kGranule - thbytes) / pitch;
     if (const char *e = std::getenv("GGS_DEBUG_TILE")) T = std::atoi(e);
     T = std::max(8, std::min(64, T));
@@ -308,6 +355,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     if (h->z_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);   // K > ~2400 needs a K-sliced kernel (not in this round)
     h->z_waves_per_cu = std::max(1, std::min(8, kMaxLdsBytes / alloc_of(h->z_lds)));
     if (const char *e = std::getenv("GGS_DEBUG_WPC")) h->z_waves_per_cu = std::max(1, std::atoi(e));
+    }
   }
   {
     int B = 64;
@@ -316,11 +364,13 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     if (lds_of(B) > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);
     h->theta_docs_per_block = B; h->theta_lds = lds_of(B);
   }
+  if (h->z_sliced && hipFuncSetAttribute(sliced_kernel_for(h->K), hipFuncAttributeMaxDynamicSharedMemorySize, h->z_lds) != hipSuccess)
+    return bail(GGS_ERR_HIP);
   const void *zk[] = {reinterpret_cast<const void *>(z_kernel<1>), reinterpret_cast<const void *>(z_kernel<2>),
                       reinterpret_cast<const void *>(z_kernel<4>), reinterpret_cast<const void *>(z_kernel<8>),
                       reinterpret_cast<const void *>(z_kernel<16>), reinterpret_cast<const void *>(z_kernel<20>)};
   for (const void *f : zk)
-    if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, h->z_lds) != hipSuccess) return bail(GGS_ERR_HIP);
+    if (!h->z_sliced && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, h->z_lds) != hipSuccess) return bail(GGS_ERR_HIP);
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(theta_kernel<kThetaBlock>), hipFuncAttributeMaxDynamicSharedMemorySize, h->theta_lds) != hipSuccess)
     return bail(GGS_ERR_HIP);
   const size_t kv = (size_t)h->K * h->V;

@@ -191,9 +191,9 @@ __global__ __launch_bounds__(256) void count_sorted_kernel(CountParams p) {
 // ------------------------------------------------------------------------------
 template <typename T, bool MAGNITUDE>
 __global__ __launch_bounds__(256) void column_chain_kernel(const T *src, int32_t pitch, int32_t K, int32_t V, double beta,
-                                                           double *out_sum, int32_t *out_nk) {
+                                                           double *out_sum) {
   constexpr int TPB = 8, ROWS = 1024, PER_THREAD = ROWS * TPB / 256;
-  __shared__ T buf[2][ROWS * TPB];
+  __shared__ double buf[2][ROWS * TPB];
   const int tid = threadIdx.x;
   const int k0 = blockIdx.x * TPB;
   const int t = tid & 7, r0 = tid >> 3;             // element (row r0 + 32 j, topic t)
@@ -209,13 +209,15 @@ __global__ __launch_bounds__(256) void column_chain_kernel(const T *src, int32_t
       regs[j] = col[(size_t)v * pitch];
     }
   };
+  // the per-element part of the sum is done here, in parallel, by all 256 threads:
+  // GGS:188 dirichletParams[type] = beta + count (int -> double, one rounding)
   auto store_tile = [&](int b) {
 #pragma unroll
-    for (int j = 0; j < PER_THREAD; ++j) buf[b][(r0 + 32 * j) * TPB + t] = regs[j];
+    for (int j = 0; j < PER_THREAD; ++j)
+      buf[b][(r0 + 32 * j) * TPB + t] = MAGNITUDE ? (beta + (double)regs[j]) : (double)regs[j];
   };
 
   double acc = 0;
-  int32_t nk = 0;
   load_tile(0);
   store_tile(0);
   __syncthreads();
@@ -225,41 +227,54 @@ __global__ __launch_bounds__(256) void column_chain_kernel(const T *src, int32_t
     if (more) load_tile(v0 + ROWS);                 // in flight while the chain below runs
     if (tid < TPB) {
       const int rows = min(ROWS, V - v0);
-      const T *bp = &buf[b][tid];
+      const double *bp = &buf[b][tid];
       int r = 0;
       if (rows >= 16) {
-        // 16 rows per step; the LDS reads of the next 16 are issued before this step's
-        // dependent add chain runs (the tile has ROWS rows allocated, so reading ahead of
-        // `rows` stays inside the buffer and is never added)
-        T x[16], y[16];
+        // 16 rows per step, two register sets: the LDS reads of the next 16 rows are in flight
+        // while this step's dependent add chain runs.  (The tile has ROWS rows allocated, so
+        // reading ahead of `rows` stays inside the buffer and is never added.)
+        double x[16], y[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) x[j] = bp[j * TPB];
-        for (; r + 16 <= rows; r += 16) {
-          const int rn = (r + 32 <= ROWS) ? r + 16 : r;
+        for (; r + 32 <= rows; r += 32) {
 #pragma unroll
-          for (int j = 0; j < 16; ++j) y[j] = bp[(rn + j) * TPB];
+          for (int j = 0; j < 16; ++j) y[j] = bp[(r + 16 + j) * TPB];
 #pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            if (MAGNITUDE) { acc += beta + (double)x[j]; nk += (int32_t)x[j]; }   // GGS:188 then Dirichlet(double[]) magnitude
-            else acc += (double)x[j];
-          }
+          for (int j = 0; j < 16; ++j) acc += x[j];
+          const int rn = (r + 48 <= ROWS) ? r + 32 : r;
 #pragma unroll
-          for (int j = 0; j < 16; ++j) x[j] = y[j];
+          for (int j = 0; j < 16; ++j) x[j] = bp[(rn + j) * TPB];
+#pragma unroll
+          for (int j = 0; j < 16; ++j) acc += y[j];
+        }
+        if (r + 16 <= rows) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) acc += x[j];
+          r += 16;
         }
       }
-      for (; r < rows; ++r) {
-        const T x = bp[r * TPB];
-        if (MAGNITUDE) { acc += beta + (double)x; nk += (int32_t)x; }
-        else acc += (double)x;
-      }
+      for (; r < rows; ++r) acc += bp[r * TPB];
     }
     if (more) store_tile(b ^ 1);
     __syncthreads();
   }
-  if (tid < TPB && k0 + tid < K) {
-    out_sum[k0 + tid] = acc;
-    if (MAGNITUDE) out_nk[k0 + tid] = nk;
+  if (tid < TPB && k0 + tid < K) out_sum[k0 + tid] = acc;
+}
+
+// tokensPerTopic n_k = sum_v n_wk[v][k]: integers, any order.
+__global__ __launch_bounds__(256) void topic_totals_kernel(const int32_t *n_wk, int32_t K, int32_t V, int32_t *n_k) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  int32_t *part = reinterpret_cast<int32_t *>(smem);             // [K]
+  for (int k = threadIdx.x; k < K; k += 256) part[k] = 0;
+  __syncthreads();
+  const int64_t n = (int64_t)V * K, stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
+    const int32_t c = n_wk[i];
+    if (c) atomicAdd(&part[(int)(i % K)], c);
   }
+  __syncthreads();
+  for (int k = threadIdx.x; k < K; k += 256)
+    if (part[k]) atomicAdd(&n_k[k], part[k]);
 }
 
 struct PhiGammaParams {

@@ -1,0 +1,199 @@
+// ggs_z_sliced.hpp -- K3, the token loop (GGS:79-130), for K <= 32*kSlicedMaxNS topics: the K
+// scores of a token live in REGISTERS, exactly like the Java topicTermScores[] array.
+//
+// Persistent single-wave workgroups stride the chunk table; one chunk = up to 64 consecutive
+// tokens of ONE document, lane t owns token t.  The phiT rows of the chunk are streamed
+// through a 2-slot LDS ring in slices of 32 topics (256 B per row, 16 KiB per slice):
+//
+//   for each slice s:   issue the LDS-DMA of slice s+1 (or slice 0 of the next chunk)
+//                       wait for slice s; score[k] = theta[k]*phi[k][w_t], sum += score[k]
+//                       for its 32 topics, k ascending                       (GGS:96-101)
+//   U from Philox, sample = U*sum                                            (GGS:107-108)
+//   walk: cnt += (sample > 0); sample -= score[k], k ascending               (GGS:109-113)
+//   store z
+//
+// The two fp64 chains per token (sum, then walk) are the reference's sequential chains; the
+// products are computed once and kept, as in the reference.  HBM->LDS traffic is one pass over
+// each row (no second read for the walk), the DMA of the next slice is in flight while this
+// slice is scored, and the next chunk's first slice is in flight during the walk.  Word ids
+// and theta rows are requested two chunks ahead, chunk descriptors three.
+//
+// DMA shape: one global_load_lds_dwordx4 wave-instruction fills 1 KiB = 4 rows x 256 B, lane l
+// -> row 4m + l/16, LDS slot l%16.  Slot j of row r holds source unit (j - r) mod 16 (a per-row
+// rotation chosen through the per-lane SOURCE address), so lane t's 16-byte read of unit u,
+// at slot (u + t) mod 16 of row t, is bank-conflict free across the wave.
+#pragma once
+#include "ggs_z_kernel.hpp"
+
+namespace ggs {
+
+constexpr int kSliceTopics = 32;
+constexpr int kSliceBytes = 64 * 256;     // 64 rows x 32 topics x 8 B
+constexpr int kSlicedMaxTopics = 192;     // 384 score registers (VGPR + AGPR) + working set < 512
+
+// KMAX = K rounded up to a multiple of 8: the size of the score register file.  Topics
+// K..KMAX-1 are scored too, with theta = 0 (the LDS theta row is zero-padded) against finite
+// phi bytes, so they add +0.0 to the sum and subtract 0.0 in the walk: no per-topic guards.
+template <int KMAX>
+__global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
+  constexpr int NS = (KMAX + kSliceTopics - 1) / kSliceTopics;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const int K = p.K, Kp = p.Kp;
+  const int upr = Kp >> 1;                               // 16-byte units per phi row
+  unsigned char *thb = smem + 2 * kSliceBytes;           // theta row, Kp doubles
+  const unsigned char *phib = reinterpret_cast<const unsigned char *>(p.phiT);
+  const size_t rowbytes = (size_t)Kp * 8;
+  const const_i64_t *cstart = (const const_i64_t *)p.chunk_start;
+  const const_i32_t *clen = (const const_i32_t *)p.chunk_len;
+  const const_i32_t *cdoc = (const const_i32_t *)p.chunk_doc;
+  const int64_t stride = gridDim.x;
+  const int64_t C = p.num_chunks;
+  constexpr int NT = (KMAX + 63) / 64;                   // 64-topic slices of a theta row
+
+  const int lrow = lane >> 4, lslot = lane & 15;
+  const unsigned char *my_rows = smem + lane * 256;      // + ring slot base + ((u + lane) & 15) * 16
+
+  // One slice of one chunk: 16 DMA wave-instructions, always all 16 and always with every lane
+  // active (lanes with nothing to fetch re-read the first bytes of phiT), so that the vmcnt
+  // arithmetic below is exact.
+  auto issue_slice = [&](const int s, const int ring, const int (&wl)[16], const int len) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) {
+      const int row = 4 * m + lrow;
+      const int unit = s * 16 + ((lslot - row) & 15);
+      const bool valid = row < len && unit < upr;
+      const unsigned char *src = valid ? phib + (size_t)wl[m] * rowbytes + (size_t)unit * 16 : phib;
+      __builtin_amdgcn_global_load_lds((glb_cvoid_t *)src, (lds_void_t *)(smem + ring * kSliceBytes + m * 1024), 16, 0, 0);
+    }
+  };
+  auto gather_words = [&](const int w, int (&wl)[16]) {
+#pragma unroll
+    for (int m = 0; m < 16; ++m) wl[m] = __shfl(w, 4 * m + lrow);
+  };
+  auto load_theta = [&](const int doc, double (&tv)[NT]) {
+    const double *thg = p.theta + (size_t)doc * K;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) tv[t] = (t * 64 + lane < K) ? thg[t * 64 + lane] : 0.0;
+  };
+
+  // ---- prologue.  Suffix 0 = this chunk, 1 = next, 2 = the one after; descriptors reach to 3.
+  int64_t c = blockIdx.x;
+  if (c >= C) return;
+  int64_t start0 = cstart[c], start1 = 0, start2 = 0, start3 = 0;
+  int len0 = clen[c], len1 = 0, len2 = 0, len3 = 0;
+  int doc0 = cdoc[c], doc1 = 0, doc2 = 0, doc3 = 0;
+  if (c + stride < C) { start1 = cstart[c + stride]; len1 = clen[c + stride]; doc1 = cdoc[c + stride]; }
+  if (c + 2 * stride < C) { start2 = cstart[c + 2 * stride]; len2 = clen[c + 2 * stride]; doc2 = cdoc[c + 2 * stride]; }
+  int w0 = (lane < len0) ? p.tok[start0 + lane] : 0;
+  int w1 = (lane < len1) ? p.tok[start1 + lane] : 0;    // len1 == 0 when there is no next chunk
+  int w2 = 0;
+  double tv0[NT], tv1[NT], tv2[NT];
+  load_theta(doc0, tv0);
+  load_theta(doc1, tv1);                                 // doc1 == 0 (a valid row) when there is no next chunk
+#pragma unroll
+  for (int t = 0; t < NT; ++t) tv2[t] = 0.0;
+  int wl[16];
+  gather_words(w0, wl);
+  int ring = 0;                                          // ring slot that holds (or will hold) slice 0 of this chunk
+  issue_slice(0, ring, wl, len0);
+
+  for (;;) {
+    const bool has1 = c + stride < C, has2 = c + 2 * stride < C;
+    // this chunk's theta row: registers -> LDS (requested two chunks ago)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+      if (t * 64 + lane < KMAX) reinterpret_cast<double *>(thb)[t * 64 + lane] = tv0[t];   // 0.0 beyond K
+
+    double sc[KMAX];
+    double sum = 0.0;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      {
+        const int cur = (ring + s) & 1;
+        // next slice into the other ring slot (its previous contents were scored last step)
+        bool issued = false;
+        if (s + 1 < NS) {
+          issue_slice(s + 1, cur ^ 1, wl, len0);
+          issued = true;
+        } else if (has1) {
+          int wln[16];
+          gather_words(w1, wln);
+          issue_slice(0, cur ^ 1, wln, len1);
+          issued = true;
+        }
+        // LDS-DMA completion is tracked by vmcnt in issue order: all but the 16 youngest done
+        // means slice s has landed.
+        if (issued) asm volatile("s_waitcnt vmcnt(16)");
+        else asm volatile("s_waitcnt vmcnt(0)");
+        __syncthreads();
+        if (lane < len0) {
+          const unsigned char *rb = my_rows + cur * kSliceBytes;
+          const unsigned char *tb = thb + s * kSliceTopics * 8;
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const int k = s * kSliceTopics + 2 * u;
+            if (k + 1 < KMAX) {                          // compile time (KMAX is even)
+              const D2 ph = lds_d2(rb + (((u + lane) & 15) << 4));
+              const D2 th = lds_d2(tb + u * 16);
+              sc[k] = th.a * ph.a;
+              sum += sc[k];
+              sc[k + 1] = th.b * ph.b;
+              sum += sc[k + 1];
+            }
+          }
+        }
+        __syncthreads();                                 // every read of this ring slot is done before it is refilled
+      }
+    }
+    // ring slot of the next chunk's slice 0
+    ring = (ring + NS) & 1;
+
+    // requests for two chunks ahead: they are younger than every DMA above, so they are only
+    // waited for at the next chunk's first slice, after the walk below.
+    if (has2) {
+      if (c + 3 * stride < C) { start3 = cstart[c + 3 * stride]; len3 = clen[c + 3 * stride]; doc3 = cdoc[c + 3 * stride]; }
+      else { start3 = 0; len3 = 0; doc3 = 0; }
+      w2 = (lane < len2) ? p.tok[start2 + lane] : 0;
+      load_theta(doc2, tv2);
+    }
+
+    if (lane < len0) {
+      const uint64_t gtok = (uint64_t)(p.tok_base + start0 + lane);
+      const U4 o = philox4x32_10((uint32_t)gtok, (uint32_t)(gtok >> 32), (uint32_t)GGS_PURPOSE_Z << 24, p.iteration,
+                                 (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
+      const double U = u53(o.x, o.y);
+      double sample = U * sum;
+      // The walk of GGS:108-113 in counting form: scores are >= 0, so once sample <= 0 it stays
+      // <= 0 and newTopic + 1 == #{k : sample before subtracting score[k] was > 0}.
+      int cnt = 0;
+      bool live = true;
+#pragma unroll
+      for (int kb = 0; kb < KMAX; kb += 16) {
+        if (live) {                                      // wave-uniform
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            if (kb + j < KMAX) { cnt += (sample > 0.0); sample -= sc[kb + j]; }
+          live = __any(sample > 0.0);
+        }
+      }
+      int new_topic = cnt - 1;
+      if (new_topic < 0 || sample > 0.0) {               // GGS:116-118 (and the index past K Java would throw on;
+                                                         // only then can cnt have run past K through the padding)
+        atomicOr(p.status, ST_INVALID_TOPIC);
+        new_topic = new_topic < 0 ? 0 : K - 1;
+      }
+      p.z[start0 + lane] = new_topic;
+    }
+    if (!has1) break;
+    c += stride;
+    start0 = start1; len0 = len1; doc0 = doc1; w0 = w1;
+    start1 = start2; len1 = len2; doc1 = doc2; w1 = w2;
+    start2 = start3; len2 = len3; doc2 = doc3;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { tv0[t] = tv1[t]; tv1[t] = tv2[t]; }
+    gather_words(w0, wl);
+  }
+}
+
+}  // namespace ggs

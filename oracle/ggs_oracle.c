@@ -518,6 +518,7 @@ void orc_destroy(orc_state *s) {
 }
 int orc_set_corpus(orc_state *s, int64_t D, const int64_t *doc_ptr, const int32_t *tokens,
                    int64_t doc_base, int64_t tok_base) {
+  s->err[0] = 0;
   if (D < 0 || doc_ptr[0] != 0) return fail(s, ORC_ERR_BAD_ARG, "bad corpus");
   int64_t N = doc_ptr[D];
   for (int64_t i = 0; i < N; i++)
@@ -559,6 +560,7 @@ static void zero_counts(orc_state *s) {
  * (MarsagliaSparseDirichlet.java:31-55) built by Dirichlet(int size, double beta):
  * magnitude = V*beta, partition[i] = 1.0/V. */
 int orc_init_phi(orc_state *s) {
+  s->err[0] = 0;
   int err = ORC_OK;
   const double magnitude = (double)s->V * s->beta;
   const double partition = 1.0 / (double)s->V;
@@ -586,6 +588,7 @@ int orc_init_phi(orc_state *s) {
 
 /* UPLDA:398-406,458-460: z0 = Randoms(seed).nextInt(K) in (doc, position) order */
 int orc_init_z_java_lcg(orc_state *s, int32_t seed) {
+  s->err[0] = 0;
   if (s->tok_base != 0) return fail(s, ORC_ERR_BAD_ARG, "java-LCG init needs the whole corpus (sequential stream)");
   zero_counts(s);
   jrandom r; jr_init(&r, (int64_t)seed);
@@ -600,6 +603,7 @@ int orc_init_z_java_lcg(orc_state *s, int32_t seed) {
 }
 /* UPLDA:1797-1843 setZIndicators */
 int orc_set_z(orc_state *s, const int32_t *z, int redraw_phi) {
+  s->err[0] = 0;
   zero_counts(s);
   for (int64_t i = 0; i < s->N; i++) {
     if (z[i] < 0 || z[i] >= s->K) return fail(s, ORC_ERR_BAD_ARG, "z out of range");
@@ -673,6 +677,7 @@ static int ggs_doc_step(orc_state *s, int64_t d, int32_t *localTopicCounts, doub
  * documents; every result is schedule-independent because the RNG is
  * counter-based. */
 int orc_z_step(orc_state *s) {
+  s->err[0] = 0;
   int err = ORC_OK;
   const int32_t K = s->K;
 #pragma omp parallel num_threads(s->threads)
@@ -695,6 +700,7 @@ int orc_z_step(orc_state *s) {
 
 /* UPLDA:1107-1138 -> updateTopics :1203-1221 -> ParallelTopicUpdater.call :1158-1182 */
 int orc_update_counts(orc_state *s) {
+  s->err[0] = 0;
   int err = ORC_OK;
   const int32_t K = s->K, V = s->V;
   int thr = s->threads < 2 ? s->threads : 2;   /* topicUpdaters pool = 2 threads, UPLDA:1085 */
@@ -725,6 +731,7 @@ static int sample_phi_this_iteration(const orc_state *s) {
 
 /* GGS:139-171 samplePhi + GGS:182-198 loopOverTopics */
 int orc_sample_phi(orc_state *s) {
+  s->err[0] = 0;
   int err = ORC_OK;
   const int32_t K = s->K, V = s->V;
   const int accumulate = s->save_phi_mean && sample_phi_this_iteration(s);
@@ -768,6 +775,7 @@ int orc_sweep(orc_state *s, int32_t n_sweeps) {
  * stream (MALLET Randoms.nextUniform() is restated as nextDouble(): ASSUMPTION
  * flagged in SURVEY 8c). */
 int orc_collapsed_sweep(orc_state *s, int32_t seed_if_first, int32_t n_sweeps) {
+  s->err[0] = 0;
   const int32_t K = s->K, V = s->V;
   if (!s->collapsed_rng_ready) { jr_init(&s->collapsed_rng, (int64_t)seed_if_first); s->collapsed_rng_ready = 1; }
   int32_t *localTopicCounts = malloc(sizeof(int32_t) * K);

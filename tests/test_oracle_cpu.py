@@ -1,0 +1,275 @@
+"""CPU tests of the oracle (oracle/ggs_oracle.c): every layer pinned against what exists.
+
+  * Philox4x32-10          vs the Random123 known-answer vectors
+  * java.util.Random       vs published values (seeds 0 and 42)
+  * fdlibm log / pow       vs libm, <= 1 ulp (fdlibm's own error bound), many points
+  * gamma / Dirichlet      vs scipy distributions (KS), the way the reference's
+                           SparseDirichletDrawTest.java:15-124 pins its samplers
+  * categorical walk       vs exact probabilities (chi-square), MultinomialSampler.java:58-63 pattern
+  * sweep invariants       the checks of UPLDA:299-338 / ParanoidUncollapsedParallelLDA.java:42-55
+  * golden fixtures        tests/golden/cats_ggs_golden.npz (restatement-derived, see make_fixtures.py)
+
+The end-to-end GGS sweep has no Java-produced golden vector (unseedable RNG in the
+reference, no JVM here): against a JVM run its parity is UNPINNED; see DESIGN.md.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from ldagroupedgibbssampler_amd.corpus import random_corpus
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_philox_kat(oracle):
+    kat = json.load(open(os.path.join(GOLD, "kat_vectors.json")))
+    for v in kat["philox4x32_10"]:
+        assert oracle.philox(v["ctr"], v["key"]) == v["out"]
+
+
+def test_java_util_random_kat(oracle):
+    kat = json.load(open(os.path.join(GOLD, "kat_vectors.json")))["java_util_random"]
+    assert list(oracle.jrandom_raw(42, 2)) == kat["nextInt_seed42"]
+    assert list(oracle.jrandom_raw(0, 2)) == kat["nextInt_seed0"]
+    assert list(oracle.jrandom_ints(42, 10, 5)) == kat["nextInt10_seed42"]
+    assert oracle.jrandom_doubles(42, 1)[0] == kat["nextDouble_seed42"][0]
+    # power-of-two bound takes the (bound * next(31)) >> 31 branch
+    r = oracle.jrandom_raw(7, 1000).astype(np.int64) & 0xFFFFFFFF
+    assert np.array_equal(oracle.jrandom_ints(7, 16, 1000), ((r >> 1) * 16) >> 31)
+    z = oracle.jrandom_ints(2019, 100, 200000)
+    assert z.min() == 0 and z.max() == 99
+    assert abs(np.bincount(z, minlength=100) / 2000.0 - 1).max() < 0.12
+
+
+def ulp_diff(a, b):
+    return np.abs(a.view(np.int64) - b.view(np.int64))
+
+
+def test_fdlibm_log_pow_within_one_ulp_of_libm(oracle):
+    rng = np.random.default_rng(1)
+    x = np.concatenate([rng.random(200000), rng.random(50000) * 1e-9, np.exp(rng.uniform(-700, 700, 100000)),
+                        1 + rng.uniform(-1e-6, 1e-6, 20000)])
+    assert ulp_diff(oracle.log(x), np.log(x)).max() <= 1
+    assert oracle.log(np.array([1.0]))[0] == 0.0 and np.isneginf(oracle.log(np.array([0.0]))[0])
+    assert oracle.log(np.array([5e-324]))[0] == np.log(5e-324)          # subnormal path
+    u = rng.random(300000)
+    y = 1.0 / rng.uniform(1e-6, 1, 300000)
+    a, b = oracle.pow(u, y), np.power(u, y)
+    m = b > 1e-300
+    assert ulp_diff(a[m], b[m]).max() <= 1
+    assert np.abs(a[~m] - b[~m]).max() < 1e-300
+    assert oracle.pow(np.array([0.0]), np.array([3.5]))[0] == 0.0 and oracle.pow(np.array([0.3]), np.array([1.0]))[0] == 0.3
+
+
+def test_uniform_and_gaussian_streams(oracle):
+    u = oracle.uniforms(123, 1, oracle.PURPOSE_Z, 0, 200000)
+    assert 0 <= u.min() and u.max() < 1
+    assert np.all(u * 2**53 == np.floor(u * 2**53))                      # 53-bit grid, like nextDouble
+    from scipy import stats
+    assert stats.kstest(u, "uniform").pvalue > 1e-3
+    g = oracle.gaussians(123, 1, oracle.PURPOSE_THETA, 0, 200000)
+    assert stats.kstest(g, "norm").pvalue > 1e-3
+    # distinct (purpose, iteration, element, seed) => distinct streams; same address => same value
+    assert not np.array_equal(u, oracle.uniforms(123, 2, oracle.PURPOSE_Z, 0, 200000))
+    assert not np.array_equal(u, oracle.uniforms(124, 1, oracle.PURPOSE_Z, 0, 200000))
+    assert np.array_equal(u[100:200], oracle.uniforms(123, 1, oracle.PURPOSE_Z, 100, 100))
+
+
+@pytest.mark.parametrize("shape", [0.01, 0.1, 0.5, 1.0, 1.5, 7.0, 250.0])
+def test_gamma_distribution(oracle, shape):
+    from scipy import stats
+    g = oracle.gammas(99, 3, oracle.PURPOSE_PHI, 0, np.full(100000, shape))
+    assert (g >= 0).all()
+    if shape >= 0.1:
+        assert stats.kstest(g, "gamma", args=(shape,)).pvalue > 1e-3
+    assert abs(g.mean() - shape) < 6 * np.sqrt(shape / 100000)
+
+
+def test_dirichlet_matches_scipy_marginals(oracle):
+    from scipy import stats
+    p = np.array([0.3, 2.0, 5.5, 0.05])
+    draws = np.array([oracle.dirichlet(5, 1, oracle.PURPOSE_THETA, 4 * i, p) for i in range(20000)])
+    assert np.allclose(draws.sum(1), 1.0, atol=1e-12)
+    for j in range(4):                                                    # marginal j ~ Beta(p_j, sum - p_j)
+        assert stats.kstest(draws[:, j], "beta", args=(p[j], p.sum() - p[j])).pvalue > 1e-3
+    # zero draws are clamped to Double.MIN_VALUE (ParallelDirichlet.java:63-65), never 0
+    tiny = oracle.dirichlet(5, 1, oracle.PURPOSE_THETA, 0, np.array([1e-6, 1e-6, 50.0]))
+    assert (tiny > 0).all()
+
+
+def test_categorical_walk_chi_square(oracle):
+    """One document, K=5: z | theta, phi drawn by the oracle's walk must follow
+    p_k = theta_k phi_kw / sum (chi-square, as src/test/.../utils/MultinomialSampler.java does)."""
+    from scipy import stats
+    K, V, n = 5, 3, 60000
+    from ldagroupedgibbssampler_amd.corpus import Corpus
+    c = Corpus(np.array([0, n], np.int64), np.zeros(n, np.int32), V)
+    o = oracle.OracleSampler(K, V, 1.0, 0.5, 7)
+    o.set_corpus(c.doc_ptr, c.tokens)
+    o.set_z(np.arange(n, dtype=np.int32) % K, redraw_phi=True)
+    phi = o.get_phi()
+    o.set_iteration(1)
+    o.z_step()
+    theta = o.get_theta()[0]
+    p = theta * phi[:, 0]
+    p /= p.sum()
+    obs = np.bincount(o.get_z(), minlength=K)
+    assert stats.chisquare(obs, p * n).pvalue > 1e-3
+
+
+def test_sweep_invariants_and_delta_bookkeeping(oracle):
+    c = random_corpus(150, 200, 80, seed=2, empty_every=13)
+    K = 9
+    o = oracle.OracleSampler(K, c.num_types, 0.2, 0.05, 11, threads=3)
+    o.set_corpus(c.doc_ptr, c.tokens)
+    o.init_z_java_lcg(5)
+    o.init_phi()
+    for _ in range(4):
+        o.set_iteration(o.iteration + 1)
+        o.z_step()
+        d = o.get_delta()
+        assert d.sum() == 0                                  # every token leaves one cell and enters one
+        o.update_counts()
+        assert (o.get_delta() == 0).all()                    # ParanoidUncollapsedParallelLDA.java:42-55
+        nwk, nkw, nk = o.get_type_topic_counts(), o.get_topic_type_counts(), o.get_topic_totals()
+        assert (nwk >= 0).all() and np.array_equal(nwk, nkw.T)   # both layouts agree, UPLDA:299-338
+        assert nwk.sum() == c.num_tokens and np.array_equal(nwk.sum(0), nk)
+        z = o.get_z()
+        ref = np.zeros_like(nwk)
+        np.add.at(ref, (c.tokens, z), 1)
+        assert np.array_equal(ref, nwk)
+        assert np.array_equal(o.get_doc_topic_counts().sum(1), np.diff(c.doc_ptr))
+        o.sample_phi()
+        phi = o.get_phi()
+        assert np.allclose(phi.sum(1), 1.0, atol=1e-9) and (phi > 0).all()
+    th = o.get_theta()
+    nonempty = np.diff(c.doc_ptr) > 0
+    assert np.allclose(th[nonempty].sum(1), 1.0, atol=1e-12) and (th[~nonempty] == 0).all()   # GGS:52-53
+
+
+def test_threads_do_not_change_results(oracle):
+    c = random_corpus(400, 300, 60, seed=3)
+    outs = []
+    for thr in (1, 4):
+        o = oracle.OracleSampler(12, c.num_types, 0.1, 0.01, 5, threads=thr)
+        o.set_corpus(c.doc_ptr, c.tokens)
+        o.init_z_java_lcg(1)
+        o.init_phi()
+        o.sweep(3)
+        outs.append((o.get_z(), o.get_phi(), o.get_theta()))
+    for a, b in zip(*outs):
+        assert np.array_equal(a.view(np.int64) if a.dtype.kind == "f" else a, b.view(np.int64) if b.dtype.kind == "f" else b)
+
+
+def test_sharded_oracle_equals_whole(oracle):
+    """Doc shards with the delta exchange (sum) reproduce the unsharded run exactly."""
+    from ldagroupedgibbssampler_amd.corpus import even_split
+    c = random_corpus(120, 150, 50, seed=8)
+    K, seed = 7, 21
+    whole = oracle.OracleSampler(K, c.num_types, 0.1, 0.01, seed)
+    whole.set_corpus(c.doc_ptr, c.tokens)
+    whole.init_z_java_lcg(3)
+    whole.init_phi()
+    z0 = whole.get_z()
+    b = even_split(c.num_docs, 3)
+    shards = []
+    for r in range(3):
+        sub, db, tb = c.shard(b[r], b[r + 1])
+        o = oracle.OracleSampler(K, c.num_types, 0.1, 0.01, seed)
+        o.set_corpus(sub.doc_ptr, sub.tokens, db, tb)
+        o.set_z(z0[tb:tb + sub.num_tokens], redraw_phi=False)
+        shards.append(o)
+    tot = sum(o.get_type_topic_counts().astype(np.int64) for o in shards)
+    for o in shards:                                         # start-up all-reduce of the counts
+        o.add_delta((tot - o.get_type_topic_counts()).astype(np.int32))
+        o.update_counts()
+        o.init_phi()
+    for _ in range(3):
+        for o in shards:
+            o.set_iteration(o.iteration + 1)
+            o.z_step()
+        dsum = sum(o.get_delta().astype(np.int64) for o in shards)
+        for o in shards:                                     # per-sweep all-reduce of the deltas
+            o.add_delta((dsum - o.get_delta()).astype(np.int32))
+            o.update_counts()
+            o.sample_phi()
+        whole.sweep(1)
+    assert np.array_equal(np.concatenate([o.get_z() for o in shards]), whole.get_z())
+    for o in shards:
+        assert np.array_equal(o.get_type_topic_counts(), whole.get_type_topic_counts())
+        assert np.array_equal(o.get_phi().view(np.int64), whole.get_phi().view(np.int64))
+
+
+def test_collapsed_count_form(oracle, cats):
+    """MSLDA:158-226 restatement: deterministic given the seed, counts stay consistent."""
+    K = 3
+    runs = []
+    for _ in range(2):
+        o = oracle.OracleSampler(K, cats.num_types, 5.0, 7.0, 0)
+        o.set_corpus(cats.doc_ptr, cats.tokens)
+        o.init_z_java_lcg(2019)
+        o.collapsed_sweep(2019, 5)
+        nwk = o.get_type_topic_counts()
+        ref = np.zeros_like(nwk)
+        np.add.at(ref, (cats.tokens, o.get_z()), 1)
+        assert np.array_equal(ref, nwk) and np.array_equal(nwk.sum(0), o.get_topic_totals())
+        runs.append(o.get_z())
+    assert np.array_equal(*runs)
+
+
+@pytest.mark.parametrize("K", [3, 20])
+def test_golden_cats(oracle, cats, K):
+    gold = np.load(os.path.join(GOLD, "cats_ggs_golden.npz"))
+    import hashlib
+    o = oracle.OracleSampler(K, cats.num_types, 5.0, 7.0, 2019)        # plda-cats-test.cfg:18-25
+    o.set_corpus(cats.doc_ptr, cats.tokens)
+    o.init_z_java_lcg(2019)
+    assert np.array_equal(o.get_z(), gold["K%d_z0" % K])
+    assert np.array_equal(o.get_z(), oracle.jrandom_ints(2019, K, cats.num_tokens))   # UPLDA:458-460
+    o.init_phi()
+    sha = lambda a: np.frombuffer(hashlib.sha256(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)  # noqa: E731
+    assert np.array_equal(sha(o.get_phi()), gold["K%d_phi0_sha256" % K])
+    o.sweep(3)
+    assert np.array_equal(o.get_z(), gold["K%d_z3" % K])
+    assert np.array_equal(o.get_topic_totals(), gold["K%d_nk3" % K])
+    assert np.array_equal(o.get_type_topic_counts(), gold["K%d_nwk3" % K])
+    assert np.array_equal(sha(o.get_phi()), gold["K%d_phi3_sha256" % K])
+    assert np.array_equal(sha(o.get_theta()), gold["K%d_theta3_sha256" % K])
+
+
+def test_phi_mean_gating(oracle):
+    c = random_corpus(40, 60, 30, seed=4)
+    o = oracle.OracleSampler(4, c.num_types, 0.3, 0.1, 5)
+    o.set_phi_mean_gating(True, 2, 2)                        # UPLDA:1350-1352
+    o.set_corpus(c.doc_ptr, c.tokens)
+    o.init_z_java_lcg(1)
+    o.init_phi()
+    assert o.get_phi_mean() == (None, 0)
+    acc = []
+    for it in range(1, 9):
+        o.sweep(1)
+        if it > 2 and it % 2 == 0:
+            acc.append(o.get_phi())
+    m, n = o.get_phi_mean()
+    assert n == 3
+    s = acc[0] + acc[1]
+    s = s + acc[2]
+    assert np.array_equal(m.view(np.int64), (s / 3).view(np.int64))
+
+
+def test_error_codes(oracle):
+    c = random_corpus(5, 10, 8, seed=1)
+    o = oracle.OracleSampler(3, c.num_types, 0.1, 0.1, 1)
+    bad = c.tokens.copy()
+    bad[0] = c.num_types
+    with pytest.raises(oracle.OracleError) as e:
+        o.set_corpus(c.doc_ptr, bad)
+    assert e.value.code == oracle.ERR_BAD_ARG
+    o.set_corpus(c.doc_ptr, c.tokens)
+    o.init_z_java_lcg(1)
+    o.set_phi(np.zeros((3, c.num_types)))                    # sum == 0 -> newTopic stays -1 -> GGS:116-118
+    with pytest.raises(oracle.OracleError) as e:
+        o.sweep(1)
+    assert e.value.code == oracle.ERR_INVALID_TOPIC and "Topic sampled is invalid" in str(e.value)

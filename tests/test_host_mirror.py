@@ -1,0 +1,148 @@
+"""The host-side mirrors of the reference interface (Python: sampler.py, C++: ggs_sampler.hpp)."""
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from ldagroupedgibbssampler_amd.corpus import random_corpus
+from ldagroupedgibbssampler_amd.sampler import (LDAGroupedGibbsSampler, SimpleLDAConfiguration, calc_theta_estimate, calc_zbar,
+                                                create_model)
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+KAT = json.load(open(os.path.join(ROOT, "tests", "golden", "kat_vectors.json")))["modified_simple_lda_test"]
+
+
+# ---- the reference's own known answers: src/test/java/cc/mallet/topics/ModifiedSimpleLDATest.java
+def _counts():
+    return np.bincount(KAT["oneDocTopics"], minlength=KAT["numTopics"]).astype(np.float64)
+
+
+def test_theta_estimate_symmetric_alpha():              # testThetaEstimate, :29-44
+    est = calc_theta_estimate(KAT["numTopics"], KAT["alpha"], KAT["oneDocTopics"])
+    alpha_sum = 0.0
+    for k in range(KAT["numTopics"]):
+        alpha_sum += _counts()[k] + KAT["alpha"]
+    assert (est != 0).all()
+    assert np.array_equal(est, (_counts() + KAT["alpha"]) / alpha_sum)       # assertTrue(a == b): exact
+    assert abs(est.sum() - 1.0) < 1e-10
+
+
+def test_theta_estimate_asymmetric_alpha():             # testThetaEstimateNonSymAlpha / testThetaEstimates, :46-56,:94-104
+    alphas = np.array(KAT["alphas"])
+    est = calc_theta_estimate(KAT["numTopics"], alphas, KAT["oneDocTopics"])
+    alpha_sum = 0.0
+    for k in range(KAT["numTopics"]):
+        alpha_sum += _counts()[k] + alphas[k]
+    assert (est != 0).all() and np.array_equal(est, (_counts() + alphas) / alpha_sum)
+    assert abs(est.sum() - 1.0) < 1e-10
+
+
+def test_theta_estimate_empty_document():               # testThetaEstimate*EmptyDoc, :58-92
+    alphas = np.array(KAT["alphas"])
+    est = calc_theta_estimate(KAT["numTopics"], alphas, [])
+    s = 0.0
+    for a in alphas:
+        s += a
+    assert np.array_equal(est, alphas / s) and (est != 0).all()
+    est = calc_theta_estimate(KAT["numTopics"], KAT["alpha"], [])
+    assert np.array_equal(est, np.full(5, KAT["alpha"] / (5 * KAT["alpha"]))) or np.allclose(est, 0.2, atol=1e-15)
+    assert abs(est.sum() - 1.0) < 1e-10
+
+
+def test_zbar():                                        # testZbar, :106-113
+    zb = calc_zbar(KAT["numTopics"], KAT["oneDocTopics"])
+    assert abs(zb.sum() - 1.0) < 1e-10
+    assert np.array_equal(zb, _counts() / 10)
+    assert np.array_equal(calc_zbar(5, []), np.zeros(5))                    # docLength == 0 -> zeros, MSLDA:657-658
+
+
+def test_configuration_defaults_and_registry():
+    c = SimpleLDAConfiguration()
+    assert (c.topics, c.alpha, c.beta, c.iterations, c.exec_time) == (10, 5.0, 0.01, 1500, 10)   # LDAConfiguration.java:11-17,35
+    assert c.scheme == "ggs" and c.seed == 0 and c.get_seed() != 0        # seed 0 -> clock, ParsedLDAConfiguration.java:137-141
+    with pytest.raises(TypeError):
+        SimpleLDAConfiguration(no_such_key=1)
+    m = create_model(SimpleLDAConfiguration(topics=3, seed=5))
+    assert isinstance(m, LDAGroupedGibbsSampler) and m.getNoTopics() == 3 and m.getStartSeed() == 5
+    with pytest.raises(ValueError):
+        create_model(SimpleLDAConfiguration(), "collapsed")
+    with pytest.raises(RuntimeError):
+        m.sample(1)                                      # before addInstances
+
+
+# ---- on the GPU: the mirrors drive the C-ABI
+@pytest.mark.gpu
+def test_python_mirror_matches_oracle(oracle, cats):
+    cfg = SimpleLDAConfiguration(topics=3, alpha=5.0, beta=7.0, seed=2019, iterations=4, exec_time=1800, paranoid=True,
+                                 save_phi_mean=True, phi_mean_burnin=25, phi_mean_thin=1)           # plda-cats-test.cfg:16-25
+    m = create_model(cfg)
+    m.setRandomSeed(2019)
+    m.addInstances(cats)
+    calls = []
+    m.preIteration = lambda: calls.append("pre")
+    m.postPhi = lambda: calls.append("phi")
+    m.sample(4)
+    assert calls == ["pre", "phi"] * 4 and m.getCurrentIteration() == 4
+    o = oracle.OracleSampler(3, cats.num_types, 5.0, 7.0, 2019)
+    o.set_phi_mean_gating(True, 1, 1)
+    o.set_corpus(cats.doc_ptr, cats.tokens)
+    o.init_z_java_lcg(2019)
+    o.init_phi()
+    o.sweep(4)
+    assert np.array_equal(np.concatenate(m.getZIndicators()), o.get_z())
+    assert np.array_equal(m.getTypeTopicMatrix(), o.get_type_topic_counts())
+    assert np.array_equal(m.getTopicTotals(), o.get_topic_totals())
+    assert np.array_equal(m.getDocumentTopicMatrix(), o.get_doc_topic_counts())
+    assert np.array_equal(m.getPhi().view(np.int64), o.get_phi().view(np.int64))
+    assert np.array_equal(m.getTheta().view(np.int64), o.get_theta().view(np.int64))
+    assert m.getNoSampledPhi() == 3 and np.array_equal(m.getPhiMeans().view(np.int64), o.get_phi_mean()[0].view(np.int64))
+    # z-bar / theta estimate against the per-document helpers
+    zs = m.getZIndicators()
+    assert np.array_equal(m.getZbar()[0], calc_zbar(3, zs[0]))
+    assert np.array_equal(m.getThetaEstimate()[5], calc_theta_estimate(3, 5.0, zs[5]))
+    assert m.zSamplingTimeCum > 0 and m.phiSamplingTimeCum > 0
+    # setZIndicators round trip + its length check (UPLDA:1828-1830)
+    m.setZIndicators(zs)
+    assert np.array_equal(m.getTypeTopicMatrix(), o.get_type_topic_counts())
+    with pytest.raises(ValueError):
+        m.setZIndicators(zs[:-1])
+    # exec_time budget: a zero budget stops after the first iteration (UPLDA:926-928)
+    m2 = create_model(SimpleLDAConfiguration(topics=3, alpha=5.0, beta=7.0, seed=1, exec_time=0))
+    m2.addInstances(cats)
+    m2.sample(50)
+    assert m2.getCurrentIteration() == 1
+    # abort flag checked per iteration (UPLDA:645)
+    m3 = create_model(SimpleLDAConfiguration(topics=3, alpha=5.0, beta=7.0, seed=1, exec_time=1800))
+    m3.addInstances(cats)
+    m3.postIteration = lambda: m3.abort() if m3.getCurrentIteration() >= 2 else None
+    m3.sample(50)
+    assert m3.getAbort() and m3.getCurrentIteration() == 2
+
+
+@pytest.mark.gpu
+def test_cpp_mirror_matches_python_path(native, tmp_path):
+    exe = os.path.join(ROOT, "examples", "ggs_host_demo")
+    if not os.path.exists(exe):
+        pytest.fail("examples/ggs_host_demo is not built: run __graft_entry__.build()")
+    c = random_corpus(60, 90, 70, seed=12, empty_every=8)
+    path = os.path.join(str(tmp_path), "corpus.txt")
+    with open(path, "w") as f:
+        f.write("%d %d\n" % (c.num_docs, c.num_types))
+        for d in range(c.num_docs):
+            t = c.tokens[c.doc_ptr[d]:c.doc_ptr[d + 1]]
+            f.write(" ".join([str(len(t))] + [str(int(x)) for x in t]) + "\n")
+    K, alpha, beta, seed, its = 6, 0.5, 0.1, 99, 3
+    out = subprocess.run([exe, path, str(K), str(alpha), str(beta), str(seed), str(its)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    lines = dict(l.split(" ", 1) for l in out.stdout.strip().splitlines())
+    g = native.GGSHandle(K, c.num_types, alpha, beta, seed)
+    g.set_corpus(c.doc_ptr, c.tokens)
+    g.init_z_java_lcg(seed)
+    g.init_phi()
+    g.sweep(its)
+    assert lines["iteration"] == "%d hooks %d %d" % (its, its, its)
+    assert np.array_equal(np.array(lines["z"].split(), np.int32), g.get_z())
+    assert np.array_equal(np.array(lines["nk"].split(), np.int32), g.get_topic_totals())
+    assert abs(float(lines["theta_estimate_doc0_sum"]) - 1.0) < 1e-12

@@ -32,6 +32,31 @@ def algorithmic_bytes_per_token(K):
     return 8 * K + 28
 
 
+def measured_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same
+    command (profiles/r*_pmc_counters.txt; FETCH_SIZE and WRITE_SIZE are collected in separate
+    rocprofv3 runs, in KiB).  gfx950: FETCH_SIZE counts 128-byte requests at 64 bytes for wide
+    coalesced reads, so it is doubled (MI355X_MICROARCH.md, HBM).  None if no profile is present."""
+    import ast
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.txt")))
+    if not files:
+        return None
+    fetch = write = None
+    for line in open(files[-1]):
+        if not line.startswith(kernel_prefix):
+            continue
+        try:
+            d = ast.literal_eval(line[line.index("{"):line.rindex("}") + 1])
+        except (ValueError, SyntaxError):
+            continue
+        fetch = d.get("FETCH_SIZE", fetch)
+        write = d.get("WRITE_SIZE", write)
+    if fetch is None or write is None:
+        return None
+    return int((2.0 * fetch + write) * 1024)
+
+
 def cpu_baseline(corpus, K, alpha, beta, seed, z0, sample_docs):
     """The oracle (a C restatement of the Java GGS sweep, Java layouts kept: phi[K][V],
     atomic [K][V] deltas, dynamic chunks of 100 documents) on all host cores, on the first
@@ -170,7 +195,7 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                "traffic": measured_traffic("void ggs::z_sliced_kernel" if K <= 192 else "void ggs::z_kernel"),
                 "bytes_per_token": btok,
                 "tokens_per_launch": n_local,
                 "avg_launch_ms": round(z_ms, 4),

@@ -1,0 +1,89 @@
+/*
+ * ggs_jni.c -- JNI glue between cc.mallet.topics.LDAGroupedGibbsSamplerHIP and the C-ABI of
+ * include/ggs_hip.h.  SOURCE ONLY (no jni.h in the build image).  Build on a box with a JDK:
+ *
+ *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude \
+ *       integration/jni/ggs_jni.c -Lldagroupedgibbssampler_amd/csrc -lggs_hip -o libggs_jni.so
+ *
+ * Every native method is a flat copy: Java arrays are pinned with Get<Type>ArrayElements /
+ * GetPrimitiveArrayCritical for the duration of ONE C-ABI call, as the header promises.  A
+ * non-zero return becomes the exception the Java code itself would have thrown
+ * (IllegalStateException for GGS:84-85,116-118; IllegalArgumentException for bad arguments).
+ */
+#include <jni.h>
+#include "ggs_hip.h"
+
+#define H(h) ((ggs_handle *)(intptr_t)(h))
+
+static void throw_for(JNIEnv *env, ggs_handle *h, int rc) {
+  const char *cls = (rc == GGS_ERR_BAD_ARG) ? "java/lang/IllegalArgumentException" : "java/lang/IllegalStateException";
+  (*env)->ThrowNew(env, (*env)->FindClass(env, cls), h ? ggs_last_error(h) : "ggs_create failed");
+}
+#define CHECK(h, call) do { int rc_ = (call); if (rc_) throw_for(env, (h), rc_); } while (0)
+
+JNIEXPORT jlong JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nCreate(JNIEnv *env, jclass c, jint K, jint V,
+    jdoubleArray alpha, jdouble beta, jlong seed, jint device, jint flags, jint burnIn, jint thin) {
+  ggs_config cfg = {0};
+  ggs_handle *h = 0;
+  jdouble *a = (*env)->GetDoubleArrayElements(env, alpha, 0);
+  cfg.struct_size = (int32_t)sizeof cfg; cfg.num_topics = K; cfg.num_types = V; cfg.device_id = device;
+  cfg.alpha = a; cfg.beta = beta; cfg.seed = (uint64_t)seed; cfg.flags = flags; cfg.phi_burn_in = burnIn; cfg.phi_mean_thin = thin;
+  int rc = ggs_create(&cfg, &h);
+  (*env)->ReleaseDoubleArrayElements(env, alpha, a, JNI_ABORT);
+  if (rc) throw_for(env, 0, rc);
+  return (jlong)(intptr_t)h;
+}
+JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nDestroy(JNIEnv *env, jclass c, jlong h) { ggs_destroy(H(h)); }
+
+JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSetCorpus(JNIEnv *env, jclass c, jlong h,
+    jlongArray docPtr, jintArray tokens, jlong docBase, jlong tokBase) {
+  jsize D = (*env)->GetArrayLength(env, docPtr) - 1;
+  jlong *p = (*env)->GetLongArrayElements(env, docPtr, 0);
+  jint *t = (*env)->GetIntArrayElements(env, tokens, 0);
+  int rc = ggs_set_corpus(H(h), D, (const int64_t *)p, (const int32_t *)t, docBase, tokBase);
+  (*env)->ReleaseIntArrayElements(env, tokens, t, JNI_ABORT);
+  (*env)->ReleaseLongArrayElements(env, docPtr, p, JNI_ABORT);
+  if (rc) throw_for(env, H(h), rc);
+}
+JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSetZ(JNIEnv *env, jclass c, jlong h, jintArray z, jboolean redraw) {
+  jint *p = (*env)->GetIntArrayElements(env, z, 0);
+  int rc = ggs_set_z(H(h), (const int32_t *)p, redraw ? 1 : 0);
+  (*env)->ReleaseIntArrayElements(env, z, p, JNI_ABORT);
+  if (rc) throw_for(env, H(h), rc);
+}
+JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSetIteration(JNIEnv *env, jclass c, jlong h, jint it) { CHECK(H(h), ggs_set_iteration(H(h), it)); }
+JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSweepBegin(JNIEnv *env, jclass c, jlong h) { CHECK(H(h), ggs_sweep_begin(H(h))); }
+JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSweepEnd(JNIEnv *env, jclass c, jlong h) { CHECK(H(h), ggs_sweep_end(H(h))); }
+JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSampleZGivenPhi(JNIEnv *env, jclass c, jlong h, jint n) { CHECK(H(h), ggs_sample_z_given_phi(H(h), n)); }
+
+#define GETTER_INT(NAME, CALL) \
+JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_##NAME(JNIEnv *env, jclass c, jlong h, jintArray out) { \
+  jint *p = (*env)->GetIntArrayElements(env, out, 0); int rc = CALL(H(h), (int32_t *)p); \
+  (*env)->ReleaseIntArrayElements(env, out, p, 0); if (rc) throw_for(env, H(h), rc); }
+GETTER_INT(nGetZ, ggs_get_z)
+GETTER_INT(nGetTypeTopicCounts, ggs_get_type_topic_counts)
+GETTER_INT(nGetTopicTotals, ggs_get_topic_totals)
+
+JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nGetPhi(JNIEnv *env, jclass c, jlong h, jdoubleArray out) {
+  jdouble *p = (*env)->GetDoubleArrayElements(env, out, 0); int rc = ggs_get_phi(H(h), p);
+  (*env)->ReleaseDoubleArrayElements(env, out, p, 0); if (rc) throw_for(env, H(h), rc);
+}
+JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSetPhi(JNIEnv *env, jclass c, jlong h, jdoubleArray in) {
+  jdouble *p = (*env)->GetDoubleArrayElements(env, in, 0); int rc = ggs_set_phi(H(h), p);
+  (*env)->ReleaseDoubleArrayElements(env, in, p, JNI_ABORT); if (rc) throw_for(env, H(h), rc);
+}
+JNIEXPORT jint JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nGetPhiMean(JNIEnv *env, jclass c, jlong h, jdoubleArray out) {
+  int32_t n = 0; jdouble *p = (*env)->GetDoubleArrayElements(env, out, 0); int rc = ggs_get_phi_mean(H(h), p, &n);
+  (*env)->ReleaseDoubleArrayElements(env, out, p, 0); if (rc) throw_for(env, H(h), rc); return n;
+}
+JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nGetTheta(JNIEnv *env, jclass c, jlong h, jlong b, jlong e, jdoubleArray out) {
+  jdouble *p = (*env)->GetDoubleArrayElements(env, out, 0); int rc = ggs_get_theta(H(h), b, e, p);
+  (*env)->ReleaseDoubleArrayElements(env, out, p, 0); if (rc) throw_for(env, H(h), rc);
+}
+JNIEXPORT jdoubleArray JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nGetTimings(JNIEnv *env, jclass c, jlong h) {
+  ggs_timings t; jdouble v[4]; jdoubleArray out = (*env)->NewDoubleArray(env, 4);
+  if (ggs_get_timings(H(h), &t)) return out;
+  v[0] = t.theta_ms; v[1] = t.z_ms; v[2] = t.merge_ms; v[3] = t.phi_ms;
+  (*env)->SetDoubleArrayRegion(env, out, 0, 4, v);
+  return out;
+}

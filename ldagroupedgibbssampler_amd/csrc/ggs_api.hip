@@ -49,6 +49,15 @@ struct ggs_handle {
   int64_t *d_doc_ptr = nullptr, *d_chunk_start = nullptr;
   int32_t *d_tok = nullptr, *d_z = nullptr, *d_chunk_doc = nullptr, *d_chunk_len = nullptr;
   int32_t *d_perm = nullptr, *d_seg_word = nullptr, *d_seg_begin = nullptr;
+  // theta of the current / last z step, and the buffer the next iteration's theta is drawn into
+  // on the side stream while this iteration's counts and Phi are computed (theta_{t+1} depends
+  // on z_t only, GGS:57-72)
+  double *d_theta_next = nullptr;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_theta0[2] = {nullptr, nullptr}, ev_theta1[2] = {nullptr, nullptr};   // ping-pong: one pair being timed, one being recorded
+  int ahead_slot = 0, consumed_slot = 0;
+  bool overlap_theta = true, consumed_ahead = false;
+  int64_t theta_ahead_iter = INT64_MIN;     // iteration the side-stream theta was drawn for, or none
   double *d_alpha = nullptr, *d_theta = nullptr, *d_phiT = nullptr, *d_mag = nullptr, *d_tot = nullptr, *d_phi_mean = nullptr;
   int32_t *d_n_wk = nullptr, *d_n_k = nullptr;
   uint32_t *d_status = nullptr;
@@ -159,14 +168,14 @@ int launch_phi(ggs_handle *h, bool initial, bool accumulate_mean) {
   return GGS_OK;
 }
 
-int launch_theta(ggs_handle *h) {
+int launch_theta(ggs_handle *h, hipStream_t stream, double *dst, int32_t iteration) {
   if (h->D == 0) return GGS_OK;
   ThetaParams tp{};
-  tp.doc_ptr = h->d_doc_ptr; tp.z = h->d_z; tp.alpha = h->d_alpha; tp.theta = h->d_theta; tp.status = h->d_status;
-  tp.num_docs = h->D; tp.doc_base = h->doc_base; tp.seed = h->seed; tp.iteration = (uint32_t)h->iteration;
+  tp.doc_ptr = h->d_doc_ptr; tp.z = h->d_z; tp.alpha = h->d_alpha; tp.theta = dst; tp.status = h->d_status;
+  tp.num_docs = h->D; tp.doc_base = h->doc_base; tp.seed = h->seed; tp.iteration = (uint32_t)iteration;
   tp.K = h->K; tp.docs_per_block = h->theta_docs_per_block;
   const int64_t grid = (h->D + h->theta_docs_per_block - 1) / h->theta_docs_per_block;
-  hipLaunchKernelGGL(theta_kernel<kThetaBlock>, dim3((unsigned)grid), dim3(kThetaBlock), h->theta_lds, h->stream, tp);
+  hipLaunchKernelGGL(theta_kernel<kThetaBlock>, dim3((unsigned)grid), dim3(kThetaBlock), h->theta_lds, stream, tp);
   HIP_TRY(h, hipGetLastError());
   return GGS_OK;
 }
@@ -256,13 +265,38 @@ int require_ready(ggs_handle *h, bool need_phi) {
   return bind_device(h);
 }
 
+// The side-stream theta must not outlive the z it was drawn from.
+int drop_theta_ahead(ggs_handle *h) {
+  if (h->side) HIP_TRY(h, hipStreamSynchronize(h->side));
+  h->theta_ahead_iter = INT64_MIN;
+  return GGS_OK;
+}
+
 int z_phase(ggs_handle *h) {
   int rc;
-  HIP_TRY(h, hipEventRecord(h->ev.e[0], h->stream));
-  if ((rc = launch_theta(h))) return rc;
+  h->consumed_ahead = h->theta_ahead_iter == (int64_t)h->iteration;
+  if (h->consumed_ahead) {
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_theta1[h->ahead_slot], 0));   // drawn during the previous iteration's Phi phase
+    h->consumed_slot = h->ahead_slot;
+    std::swap(h->d_theta, h->d_theta_next);
+  } else {
+    if (h->side) HIP_TRY(h, hipStreamSynchronize(h->side));
+    HIP_TRY(h, hipEventRecord(h->ev.e[0], h->stream));
+    if ((rc = launch_theta(h, h->stream, h->d_theta, h->iteration))) return rc;
+  }
   HIP_TRY(h, hipEventRecord(h->ev.e[1], h->stream));
   if ((rc = launch_z(h))) return rc;
   HIP_TRY(h, hipEventRecord(h->ev.e[2], h->stream));
+  h->theta_ahead_iter = INT64_MIN;
+  if (h->overlap_theta && h->side && h->D > 0) {
+    // theta of iteration t+1 from the z just drawn, concurrent with the counts and the Phi draw
+    HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev.e[2], 0));
+    h->ahead_slot ^= 1;
+    HIP_TRY(h, hipEventRecord(h->ev_theta0[h->ahead_slot], h->side));
+    if ((rc = launch_theta(h, h->side, h->d_theta_next, h->iteration + 1))) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev_theta1[h->ahead_slot], h->side));
+    h->theta_ahead_iter = (int64_t)h->iteration + 1;
+  }
   if ((rc = launch_count_rebuild(h))) return rc;   // this shard's counts; summed across shards by the caller
   HIP_TRY(h, hipEventRecord(h->ev.e[3], h->stream));
   return GGS_OK;
@@ -280,7 +314,13 @@ int finish_sweep(ggs_handle *h, bool with_phi) {
   if ((rc = check_status(h))) return rc;   // synchronises the stream
   if (acc) h->n_sampled_phi++;             // GGS:168-170
   float ms = 0;
-  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev.e[0], h->ev.e[1])); h->tm.theta_ms += ms;
+  if (h->consumed_ahead) {
+    // the stream waited on ev_theta1 before the z kernel, so both side-stream events are complete;
+    // their span is the duration of a kernel that ran beside the previous iteration's Phi phase
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_theta0[h->consumed_slot], h->ev_theta1[h->consumed_slot])); h->tm.theta_ms += ms;
+  } else {
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev.e[0], h->ev.e[1])); h->tm.theta_ms += ms;
+  }
   HIP_TRY(h, hipEventElapsedTime(&ms, h->ev.e[1], h->ev.e[2])); h->tm.z_ms += ms;
   HIP_TRY(h, hipEventElapsedTime(&ms, h->ev.e[2], h->ev.e[3])); h->tm.merge_ms += ms;
   HIP_TRY(h, hipEventElapsedTime(&ms, h->ev.e[4], h->ev.e[5])); h->tm.phi_ms += ms;
@@ -388,6 +428,15 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
   for (auto &e : h->ev.e)
     if (hipEventCreate(&e) != hipSuccess) return bail(GGS_ERR_HIP);
   h->ev.ok = true;
+  if (const char *e = std::getenv("GGS_DEBUG_NO_OVERLAP")) h->overlap_theta = std::atoi(e) == 0;
+  {
+    // lowest priority: the theta draw fills whatever the Phi phase (on the caller's stream) leaves idle
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo) != hipSuccess) return bail(GGS_ERR_HIP);
+  }
+  for (int i = 0; i < 2; ++i)
+    if (hipEventCreate(&h->ev_theta0[i]) != hipSuccess || hipEventCreate(&h->ev_theta1[i]) != hipSuccess) return bail(GGS_ERR_HIP);
   *out = h;
   return GGS_OK;
 }
@@ -396,13 +445,18 @@ void ggs_destroy(ggs_handle *h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
-  void *bufs[] = {h->d_doc_ptr, h->d_chunk_start, h->d_tok, h->d_z, h->d_chunk_doc, h->d_chunk_len, h->d_alpha, h->d_theta,
+  void *bufs[] = {h->d_doc_ptr, h->d_chunk_start, h->d_tok, h->d_z, h->d_chunk_doc, h->d_chunk_len, h->d_alpha, h->d_theta, h->d_theta_next,
                   h->d_phiT, h->d_mag, h->d_tot, h->d_phi_mean, h->d_n_wk, h->d_n_k, h->d_perm, h->d_seg_word, h->d_seg_begin,
                   h->d_status, h->d_scratch};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (h->ev.ok)
     for (auto &e : h->ev.e) (void)hipEventDestroy(e);
+  for (int i = 0; i < 2; ++i) {
+    if (h->ev_theta0[i]) (void)hipEventDestroy(h->ev_theta0[i]);
+    if (h->ev_theta1[i]) (void)hipEventDestroy(h->ev_theta1[i]);
+  }
+  if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
 }
 
@@ -411,6 +465,7 @@ int ggs_set_stream(ggs_handle *h, void *hip_stream) {
   int rc = bind_device(h);
   if (rc) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if ((rc = drop_theta_ahead(h))) return rc;
   h->stream = reinterpret_cast<hipStream_t>(hip_stream);
   return GGS_OK;
 }
@@ -427,6 +482,7 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
     if (tokens[i] < 0 || tokens[i] >= h->V) return set_err(h, GGS_ERR_BAD_ARG, "token id outside [0, num_types)");
   int rc = bind_device(h);
   if (rc) return rc;
+  if ((rc = drop_theta_ahead(h))) return rc;
 
   // z-kernel work items: each document is cut into ceil(len/T) near-equal chunks of <= T tokens.
   std::vector<int64_t> cstart;
@@ -461,7 +517,7 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
   }
   h->D = D; h->N = N; h->C = (int64_t)cstart.size(); h->S = (int64_t)seg_word.size(); h->doc_base = doc_base; h->tok_base = tok_base;
   if ((rc = dev_alloc(h, &h->d_doc_ptr, (size_t)D + 1)) || (rc = dev_alloc(h, &h->d_tok, (size_t)N)) || (rc = dev_alloc(h, &h->d_z, (size_t)N)) ||
-      (rc = dev_alloc(h, &h->d_theta, (size_t)D * h->K)) || (rc = dev_alloc(h, &h->d_chunk_start, (size_t)h->C)) ||
+      (rc = dev_alloc(h, &h->d_theta, (size_t)D * h->K)) || (rc = dev_alloc(h, &h->d_theta_next, (size_t)D * h->K)) || (rc = dev_alloc(h, &h->d_chunk_start, (size_t)h->C)) ||
       (rc = dev_alloc(h, &h->d_chunk_doc, (size_t)h->C)) || (rc = dev_alloc(h, &h->d_chunk_len, (size_t)h->C)) ||
       (rc = dev_alloc(h, &h->d_perm, (size_t)N)) || (rc = dev_alloc(h, &h->d_seg_word, (size_t)h->S)) ||
       (rc = dev_alloc(h, &h->d_seg_begin, (size_t)h->S + 1)))
@@ -473,6 +529,7 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
   if (N) HIP_TRY(h, hipMemcpy(h->d_tok, tokens, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemset(h->d_z, 0, sizeof(int32_t) * std::max<size_t>((size_t)N, 1)));
   HIP_TRY(h, hipMemset(h->d_theta, 0, sizeof(double) * std::max<size_t>((size_t)D * h->K, 1)));
+  HIP_TRY(h, hipMemset(h->d_theta_next, 0, sizeof(double) * std::max<size_t>((size_t)D * h->K, 1)));
   if (h->C) {
     HIP_TRY(h, hipMemcpy(h->d_chunk_start, cstart.data(), sizeof(int64_t) * cstart.size(), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_chunk_doc, cdoc.data(), sizeof(int32_t) * cdoc.size(), hipMemcpyHostToDevice));
@@ -486,6 +543,7 @@ int ggs_init_z_java_lcg(ggs_handle *h, int32_t seed) {
   int rc = require_ready(h, false);
   if (rc) return rc;
   if (h->tok_base != 0) return set_err(h, GGS_ERR_STATE, "java-LCG init is one sequential stream: only valid with tok_base == 0");
+  if ((rc = drop_theta_ahead(h))) return rc;
   // One sequential stream, so it runs on the host exactly once at start-up.
   std::vector<int32_t> z((size_t)h->N);
   java_lcg_next_ints(seed, h->K, h->N, z.data());
@@ -501,6 +559,7 @@ int ggs_set_z(ggs_handle *h, const int32_t *z, int32_t redraw_phi) {
   if (h->N > 0 && !z) return set_err(h, GGS_ERR_BAD_ARG, "z is null");
   for (int64_t i = 0; i < h->N; ++i)
     if (z[i] < 0 || z[i] >= h->K) return set_err(h, GGS_ERR_BAD_ARG, "topic indicator outside [0, num_topics)");
+  if ((rc = drop_theta_ahead(h))) return rc;
   if (h->N) HIP_TRY(h, hipMemcpyAsync(h->d_z, z, sizeof(int32_t) * (size_t)h->N, hipMemcpyHostToDevice, h->stream));
   if ((rc = launch_count_rebuild(h))) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -515,7 +574,7 @@ int ggs_init_phi(ggs_handle *h) {
   return check_status(h);
 }
 
-int ggs_set_iteration(ggs_handle *h, int32_t it) { if (!h) return GGS_ERR_BAD_ARG; h->iteration = it; return GGS_OK; }
+int ggs_set_iteration(ggs_handle *h, int32_t it) { if (!h) return GGS_ERR_BAD_ARG; h->iteration = it; return GGS_OK; }   // a theta drawn ahead for another iteration is simply not used
 int ggs_get_iteration(const ggs_handle *h, int32_t *it) { if (!h || !it) return GGS_ERR_BAD_ARG; *it = h->iteration; return GGS_OK; }
 
 int ggs_sweep_begin(ggs_handle *h) {

@@ -185,14 +185,14 @@ __global__ __launch_bounds__(256) void count_sorted_kernel(CountParams p) {
 //
 // column_chain: a sum over V in index order is one dependent fp64 add chain per topic --
 // it cannot be split, only fed.  One workgroup owns 8 adjacent topics (a 64-byte / 32-byte
-// slice of every row); all 256 threads stream [1024 rows x 8 topics] tiles through a
+// slice of every row); all 256 threads stream [256 rows x 8 topics] tiles through a
 // double-buffered LDS ring with plain coalesced loads while 8 lanes of wave 0 walk the
 // previous tile row by row.  K/8 workgroups keep K/8 CUs' worth of loads in flight.
 // ------------------------------------------------------------------------------
 template <typename T, bool MAGNITUDE>
 __global__ __launch_bounds__(256) void column_chain_kernel(const T *src, int32_t pitch, int32_t K, int32_t V, double beta,
                                                            double *out_sum) {
-  constexpr int TPB = 8, ROWS = 1024, PER_THREAD = ROWS * TPB / 256;
+  constexpr int TPB = 8, ROWS = 256, PER_THREAD = ROWS * TPB / 256;   // 32 KiB of LDS: small enough to slot in beside the theta draw running on the side stream
   __shared__ double buf[2][ROWS * TPB];
   const int tid = threadIdx.x;
   const int k0 = blockIdx.x * TPB;

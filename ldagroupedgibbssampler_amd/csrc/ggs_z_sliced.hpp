@@ -123,27 +123,37 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
           issued = true;
         }
         // LDS-DMA completion is tracked by vmcnt in issue order: all but the 16 youngest done
-        // means slice s has landed.
-        if (issued) asm volatile("s_waitcnt vmcnt(16)");
-        else asm volatile("s_waitcnt vmcnt(0)");
-        __syncthreads();
+        // means slice s has landed.  One wave per workgroup: no hardware barrier is needed, only
+        // a compiler fence (the "memory" clobber) so that no LDS read moves above the wait --
+        // a __syncthreads() here would also wait for the slice just issued.
+        if (issued) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane < len0) {
           const unsigned char *rb = my_rows + cur * kSliceBytes;
           const unsigned char *tb = thb + s * kSliceTopics * 8;
+          // unit u = topics (k, k+1); two register sets, the reads of unit u+1 are in flight
+          // while unit u is scored
+          D2 pa = lds_d2(rb + ((lane & 15) << 4)), ta = lds_d2(tb), pb = pa, tb2 = ta;
 #pragma unroll
-          for (int u = 0; u < 16; ++u) {
+          for (int u = 0; u < 16; u += 2) {
             const int k = s * kSliceTopics + 2 * u;
             if (k + 1 < KMAX) {                          // compile time (KMAX is even)
-              const D2 ph = lds_d2(rb + (((u + lane) & 15) << 4));
-              const D2 th = lds_d2(tb + u * 16);
-              sc[k] = th.a * ph.a;
+              if (k + 3 < KMAX) { pb = lds_d2(rb + (((u + 1 + lane) & 15) << 4)); tb2 = lds_d2(tb + (u + 1) * 16); }
+              sc[k] = ta.a * pa.a;
               sum += sc[k];
-              sc[k + 1] = th.b * ph.b;
+              sc[k + 1] = ta.b * pa.b;
               sum += sc[k + 1];
+              if (k + 3 < KMAX) {
+                if (k + 5 < KMAX && u + 2 < 16) { pa = lds_d2(rb + (((u + 2 + lane) & 15) << 4)); ta = lds_d2(tb + (u + 2) * 16); }
+                sc[k + 2] = tb2.a * pb.a;
+                sum += sc[k + 2];
+                sc[k + 3] = tb2.b * pb.b;
+                sum += sc[k + 3];
+              }
             }
           }
         }
-        __syncthreads();                                 // every read of this ring slot is done before it is refilled
+        asm volatile("" ::: "memory");                   // every read of this ring slot is issued before it is refilled
       }
     }
     // ring slot of the next chunk's slice 0

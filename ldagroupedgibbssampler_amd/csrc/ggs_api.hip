@@ -383,7 +383,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       // 64-token chunks, a 2-slot ring of 32-topic slices + the theta row; one wave per SIMD
       // (the score registers take most of the 512-entry file)
       h->z_tile_tokens = 64;
-      h->z_lds = 2 * kSliceBytes + ((h->K + 7) / 8) * 64;   // ring + theta row zero-padded to KMAX
+      h->z_lds = kRingSlots * kSliceBytes + ((h->K + 7) / 8) * 64;   // ring + theta row zero-padded to KMAX
       h->z_waves_per_cu = std::min(4, kMaxLdsBytes / alloc_of(h->z_lds));
       if (const char *e = std::getenv("GGS_DEBUG_WPC")) h->z_waves_per_cu = std::max(1, std::atoi(e));
     } else {
@@ -414,13 +414,13 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(theta_kernel<kThetaBlock>), hipFuncAttributeMaxDynamicSharedMemorySize, h->theta_lds) != hipSuccess)
     return bail(GGS_ERR_HIP);
   const size_t kv = (size_t)h->K * h->V;
-  if ((rc = dev_alloc(h, &h->d_alpha, h->K)) || (rc = dev_alloc(h, &h->d_phiT, (size_t)h->V * h->Kp)) ||
+  if ((rc = dev_alloc(h, &h->d_alpha, h->K)) || (rc = dev_alloc(h, &h->d_phiT, (size_t)h->V * h->Kp + kPhiTailPadBytes / 8)) ||
       (rc = dev_alloc(h, &h->d_mag, h->K)) || (rc = dev_alloc(h, &h->d_tot, h->K)) || (rc = dev_alloc(h, &h->d_n_wk, kv)) ||
       (rc = dev_alloc(h, &h->d_n_k, h->K)) || (rc = dev_alloc(h, &h->d_status, 4)))
     return bail(rc);
   if ((h->flags & GGS_FLAG_SAVE_PHI_MEAN) && (rc = dev_alloc(h, &h->d_phi_mean, kv))) return bail(rc);
   if (hipMemcpy(h->d_alpha, h->alpha.data(), sizeof(double) * h->K, hipMemcpyHostToDevice) != hipSuccess ||
-      hipMemset(h->d_phiT, 0, sizeof(double) * (size_t)h->V * h->Kp) != hipSuccess ||
+      hipMemset(h->d_phiT, 0, sizeof(double) * ((size_t)h->V * h->Kp + kPhiTailPadBytes / 8)) != hipSuccess ||
       hipMemset(h->d_n_wk, 0, sizeof(int32_t) * kv) != hipSuccess ||
       hipMemset(h->d_n_k, 0, sizeof(int32_t) * h->K) != hipSuccess || hipMemset(h->d_status, 0, 16) != hipSuccess ||
       (h->d_phi_mean && hipMemset(h->d_phi_mean, 0, sizeof(double) * kv) != hipSuccess))

@@ -1,47 +1,54 @@
-// ggs_z_sliced.hpp -- K3, the token loop (GGS:79-130), for K <= 32*kSlicedMaxNS topics: the K
-// scores of a token live in REGISTERS, exactly like the Java topicTermScores[] array.
+// ggs_z_sliced.hpp -- K3, the token loop (GGS:79-130), for K <= kSlicedMaxTopics: the K scores
+// of a token live in REGISTERS, exactly like the Java topicTermScores[] array.
 //
 // Persistent single-wave workgroups stride the chunk table; one chunk = up to 64 consecutive
 // tokens of ONE document, lane t owns token t.  The phiT rows of the chunk are streamed
-// through a 2-slot LDS ring in slices of 32 topics (256 B per row, 16 KiB per slice):
+// through a 4-slot LDS ring in slices of 16 topics (128 B per row, 8 KiB per slice), kept
+// kAhead slices ahead of the arithmetic, across chunk boundaries:
 //
-//   for each slice s:   issue the LDS-DMA of slice s+1 (or slice 0 of the next chunk)
+//   for each slice s:   issue the LDS-DMA of slice s+kAhead (of this or the next chunk)
 //                       wait for slice s; score[k] = theta[k]*phi[k][w_t], sum += score[k]
-//                       for its 32 topics, k ascending                       (GGS:96-101)
+//                       for its 16 topics, k ascending                       (GGS:96-101)
 //   U from Philox, sample = U*sum                                            (GGS:107-108)
 //   walk: cnt += (sample > 0); sample -= score[k], k ascending               (GGS:109-113)
 //   store z
 //
 // The two fp64 chains per token (sum, then walk) are the reference's sequential chains; the
 // products are computed once and kept, as in the reference.  HBM->LDS traffic is one pass over
-// each row (no second read for the walk), the DMA of the next slice is in flight while this
-// slice is scored, and the next chunk's first slice is in flight during the walk.  Word ids
-// and theta rows are requested two chunks ahead, chunk descriptors three.
+// each row.  Word ids and theta rows are requested two chunks ahead, chunk descriptors three.
 //
-// DMA shape: one global_load_lds_dwordx4 wave-instruction fills 1 KiB = 4 rows x 256 B, lane l
-// -> row 4m + l/16, LDS slot l%16.  Slot j of row r holds source unit (j - r) mod 16 (a per-row
-// rotation chosen through the per-lane SOURCE address), so lane t's 16-byte read of unit u,
-// at slot (u + t) mod 16 of row t, is bank-conflict free across the wave.
+// DMA shape: one global_load_lds_dwordx4 wave-instruction fills 1 KiB = 8 rows x 128 B, lane l
+// -> row 8m + l/8, LDS slot l%8.  Slot j of row r holds source unit (j - r/2) mod 8 (a per-row
+// rotation chosen through the per-lane SOURCE address), so lane t's 16-byte read of unit u, at
+// slot (u + t/2) mod 8 of row t, is bank-conflict free across the wave.  Per chunk every lane
+// computes its 8 source row addresses once; each DMA then only adds an immediate slice offset.
+// Lanes with nothing useful to fetch (rows past the chunk, units past the row) read whatever
+// finite bytes sit there (word 0's row; the next row's first entries; the zeroed tail pad of
+// phiT): those scores are multiplied by theta = 0 or belong to lanes that store nothing.
 #pragma once
 #include "ggs_z_kernel.hpp"
 
 namespace ggs {
 
-constexpr int kSliceTopics = 32;
-constexpr int kSliceBytes = 64 * 256;     // 64 rows x 32 topics x 8 B
+constexpr int kSliceTopics = 16;
+constexpr int kSliceUnits = 8;            // 16-byte units per row per slice
+constexpr int kSliceBytes = 64 * 128;     // 64 rows x 16 topics x 8 B
+constexpr int kRingSlots = 4;
 constexpr int kSlicedMaxTopics = 192;     // 384 score registers (VGPR + AGPR) + working set < 512
+constexpr int kPhiTailPadBytes = 256;     // zeroed bytes after the last phiT row (see above)
 
 // KMAX = K rounded up to a multiple of 8: the size of the score register file.  Topics
 // K..KMAX-1 are scored too, with theta = 0 (the LDS theta row is zero-padded) against finite
 // phi bytes, so they add +0.0 to the sum and subtract 0.0 in the walk: no per-topic guards.
 template <int KMAX>
 __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
-  constexpr int NS = (KMAX + kSliceTopics - 1) / kSliceTopics;
+  constexpr int NS = (KMAX + kSliceTopics - 1) / kSliceTopics;     // slices per chunk
+  constexpr int kAhead = NS < 3 ? NS : 3;                          // slices in flight beyond the one being scored
+  constexpr int NT = (KMAX + 63) / 64;                             // 64-topic pieces of a theta row
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
   const int K = p.K, Kp = p.Kp;
-  const int upr = Kp >> 1;                               // 16-byte units per phi row
-  unsigned char *thb = smem + 2 * kSliceBytes;           // theta row, Kp doubles
+  unsigned char *thb = smem + kRingSlots * kSliceBytes;            // theta row, KMAX doubles
   const unsigned char *phib = reinterpret_cast<const unsigned char *>(p.phiT);
   const size_t rowbytes = (size_t)Kp * 8;
   const const_i64_t *cstart = (const const_i64_t *)p.chunk_start;
@@ -49,27 +56,26 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
   const const_i32_t *cdoc = (const const_i32_t *)p.chunk_doc;
   const int64_t stride = gridDim.x;
   const int64_t C = p.num_chunks;
-  constexpr int NT = (KMAX + 63) / 64;                   // 64-topic slices of a theta row
 
-  const int lrow = lane >> 4, lslot = lane & 15;
-  const unsigned char *my_rows = smem + lane * 256;      // + ring slot base + ((u + lane) & 15) * 16
+  const int lrow = lane >> 3, lslot = lane & 7;
+  // byte offset of unit u of this lane's row inside a ring slot: lane*128 + ((u + lane/2) & 7)*16
+  const unsigned char *my_row = smem + lane * 128;
+  const int rot = lane >> 1;
 
-  // One slice of one chunk: 16 DMA wave-instructions, always all 16 and always with every lane
-  // active (lanes with nothing to fetch re-read the first bytes of phiT), so that the vmcnt
-  // arithmetic below is exact.
-  auto issue_slice = [&](const int s, const int ring, const int (&wl)[16], const int len) {
+  // Source addresses of this lane's 8 DMA rows (m = 0..7): row 8m + lrow of the chunk, unit
+  // (lslot - row/2) mod 8 of slice 0.  Slice s adds s*128 bytes as an immediate.
+  auto row_addresses = [&](const int w, const unsigned char *(&ra)[8]) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) {
-      const int row = 4 * m + lrow;
-      const int unit = s * 16 + ((lslot - row) & 15);
-      const bool valid = row < len && unit < upr;
-      const unsigned char *src = valid ? phib + (size_t)wl[m] * rowbytes + (size_t)unit * 16 : phib;
-      __builtin_amdgcn_global_load_lds((glb_cvoid_t *)src, (lds_void_t *)(smem + ring * kSliceBytes + m * 1024), 16, 0, 0);
+    for (int m = 0; m < 8; ++m) {
+      const int row = 8 * m + lrow;
+      const int wm = __shfl(w, row);                               // 0 for rows past the chunk
+      ra[m] = phib + (size_t)wm * rowbytes + (size_t)(((lslot - (row >> 1)) & 7) << 4);
     }
   };
-  auto gather_words = [&](const int w, int (&wl)[16]) {
+  auto issue_slice = [&](const int s, const int slot, const unsigned char *const (&ra)[8]) {
 #pragma unroll
-    for (int m = 0; m < 16; ++m) wl[m] = __shfl(w, 4 * m + lrow);
+    for (int m = 0; m < 8; ++m)
+      __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(ra[m] + s * 128), (lds_void_t *)(smem + slot * kSliceBytes + m * 1024), 16, 0, 0);
   };
   auto load_theta = [&](const int doc, double (&tv)[NT]) {
     const double *thg = p.theta + (size_t)doc * K;
@@ -86,17 +92,19 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
   if (c + stride < C) { start1 = cstart[c + stride]; len1 = clen[c + stride]; doc1 = cdoc[c + stride]; }
   if (c + 2 * stride < C) { start2 = cstart[c + 2 * stride]; len2 = clen[c + 2 * stride]; doc2 = cdoc[c + 2 * stride]; }
   int w0 = (lane < len0) ? p.tok[start0 + lane] : 0;
-  int w1 = (lane < len1) ? p.tok[start1 + lane] : 0;    // len1 == 0 when there is no next chunk
+  int w1 = (lane < len1) ? p.tok[start1 + lane] : 0;              // len1 == 0 when there is no next chunk
   int w2 = 0;
   double tv0[NT], tv1[NT], tv2[NT];
   load_theta(doc0, tv0);
-  load_theta(doc1, tv1);                                 // doc1 == 0 (a valid row) when there is no next chunk
+  load_theta(doc1, tv1);                                           // doc1 == 0 (a valid row) when there is no next chunk
 #pragma unroll
   for (int t = 0; t < NT; ++t) tv2[t] = 0.0;
-  int wl[16];
-  gather_words(w0, wl);
-  int ring = 0;                                          // ring slot that holds (or will hold) slice 0 of this chunk
-  issue_slice(0, ring, wl, len0);
+  const unsigned char *ra[8], *ran[8];                             // DMA row addresses: this chunk, next chunk
+  row_addresses(w0, ra);
+  row_addresses(w1, ran);
+  int g = 0;                                                       // ring slot of this chunk's slice 0
+#pragma unroll
+  for (int s = 0; s < kAhead; ++s) issue_slice(s, (g + s) & (kRingSlots - 1), ra);
 
   for (;;) {
     const bool has1 = c + stride < C, has2 = c + 2 * stride < C;
@@ -109,58 +117,48 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
     double sum = 0.0;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
-      {
-        const int cur = (ring + s) & 1;
-        // next slice into the other ring slot (its previous contents were scored last step)
-        bool issued = false;
-        if (s + 1 < NS) {
-          issue_slice(s + 1, cur ^ 1, wl, len0);
-          issued = true;
-        } else if (has1) {
-          int wln[16];
-          gather_words(w1, wln);
-          issue_slice(0, cur ^ 1, wln, len1);
-          issued = true;
-        }
-        // LDS-DMA completion is tracked by vmcnt in issue order: all but the 16 youngest done
-        // means slice s has landed.  One wave per workgroup: no hardware barrier is needed, only
-        // a compiler fence (the "memory" clobber) so that no LDS read moves above the wait --
-        // a __syncthreads() here would also wait for the slice just issued.
-        if (issued) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (lane < len0) {
-          const unsigned char *rb = my_rows + cur * kSliceBytes;
-          const unsigned char *tb = thb + s * kSliceTopics * 8;
-          // unit u = topics (k, k+1); two register sets, the reads of unit u+1 are in flight
-          // while unit u is scored
-          D2 pa = lds_d2(rb + ((lane & 15) << 4)), ta = lds_d2(tb), pb = pa, tb2 = ta;
+      const int cur = (g + s) & (kRingSlots - 1);
+      const int nxt = (g + s + kAhead) & (kRingSlots - 1);          // freed by the slice scored last step
+      // keep kAhead slices in flight: slice s + kAhead of this chunk, or of the next one
+      if (s + kAhead < NS) issue_slice(s + kAhead, nxt, ra);
+      else if (has1) issue_slice(s + kAhead - NS, nxt, ran);
+      // LDS-DMA completion is tracked by vmcnt in issue order.  With kAhead slices (8 DMAs each)
+      // issued after slice s, "at most 8*kAhead outstanding" means slice s has landed; at the tail
+      // of the last chunk fewer slices follow.  One wave per workgroup: no hardware barrier, only
+      // a compiler fence so that no LDS read moves above the wait.
+      if (has1 || s + kAhead < NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * kAhead) : "memory");
+      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NS - 1 - s)) : "memory");
+      if (lane < len0) {
+        const unsigned char *rb = my_row + cur * kSliceBytes;
+        const unsigned char *tb = thb + s * kSliceTopics * 8;
+        // unit u = topics (k, k+1); two register sets, the reads of unit u+1 are in flight
+        // while unit u is scored
+        D2 pa = lds_d2(rb + ((rot & 7) << 4)), ta = lds_d2(tb), pb = pa, tb2 = ta;
 #pragma unroll
-          for (int u = 0; u < 16; u += 2) {
-            const int k = s * kSliceTopics + 2 * u;
-            if (k + 1 < KMAX) {                          // compile time (KMAX is even)
-              if (k + 3 < KMAX) { pb = lds_d2(rb + (((u + 1 + lane) & 15) << 4)); tb2 = lds_d2(tb + (u + 1) * 16); }
-              sc[k] = ta.a * pa.a;
-              sum += sc[k];
-              sc[k + 1] = ta.b * pa.b;
-              sum += sc[k + 1];
-              if (k + 3 < KMAX) {
-                if (k + 5 < KMAX && u + 2 < 16) { pa = lds_d2(rb + (((u + 2 + lane) & 15) << 4)); ta = lds_d2(tb + (u + 2) * 16); }
-                sc[k + 2] = tb2.a * pb.a;
-                sum += sc[k + 2];
-                sc[k + 3] = tb2.b * pb.b;
-                sum += sc[k + 3];
-              }
+        for (int u = 0; u < kSliceUnits; u += 2) {
+          const int k = s * kSliceTopics + 2 * u;
+          if (k + 1 < KMAX) {                                      // compile time (KMAX is even)
+            if (k + 3 < KMAX) { pb = lds_d2(rb + (((u + 1 + rot) & 7) << 4)); tb2 = lds_d2(tb + (u + 1) * 16); }
+            sc[k] = ta.a * pa.a;
+            sum += sc[k];
+            sc[k + 1] = ta.b * pa.b;
+            sum += sc[k + 1];
+            if (k + 3 < KMAX) {
+              if (k + 5 < KMAX && u + 2 < kSliceUnits) { pa = lds_d2(rb + (((u + 2 + rot) & 7) << 4)); ta = lds_d2(tb + (u + 2) * 16); }
+              sc[k + 2] = tb2.a * pb.a;
+              sum += sc[k + 2];
+              sc[k + 3] = tb2.b * pb.b;
+              sum += sc[k + 3];
             }
           }
         }
-        asm volatile("" ::: "memory");                   // every read of this ring slot is issued before it is refilled
       }
+      asm volatile("" ::: "memory");                               // every read of this ring slot is issued before it is refilled
     }
-    // ring slot of the next chunk's slice 0
-    ring = (ring + NS) & 1;
+    g = (g + NS) & (kRingSlots - 1);                               // ring slot of the next chunk's slice 0
 
-    // requests for two chunks ahead: they are younger than every DMA above, so they are only
-    // waited for at the next chunk's first slice, after the walk below.
+    // requests for two chunks ahead: younger than every DMA above, so they are only waited for
+    // at the next chunk's slices, after the walk below.
     if (has2) {
       if (c + 3 * stride < C) { start3 = cstart[c + 3 * stride]; len3 = clen[c + 3 * stride]; doc3 = cdoc[c + 3 * stride]; }
       else { start3 = 0; len3 = 0; doc3 = 0; }
@@ -180,7 +178,7 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
       bool live = true;
 #pragma unroll
       for (int kb = 0; kb < KMAX; kb += 16) {
-        if (live) {                                      // wave-uniform
+        if (live) {                                                // wave-uniform
 #pragma unroll
           for (int j = 0; j < 16; ++j)
             if (kb + j < KMAX) { cnt += (sample > 0.0); sample -= sc[kb + j]; }
@@ -188,8 +186,8 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
         }
       }
       int new_topic = cnt - 1;
-      if (new_topic < 0 || sample > 0.0) {               // GGS:116-118 (and the index past K Java would throw on;
-                                                         // only then can cnt have run past K through the padding)
+      if (new_topic < 0 || sample > 0.0) {                         // GGS:116-118 (and the index past K Java would throw on;
+                                                                   // only then can cnt have run past K through the padding)
         atomicOr(p.status, ST_INVALID_TOPIC);
         new_topic = new_topic < 0 ? 0 : K - 1;
       }
@@ -202,7 +200,9 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
     start2 = start3; len2 = len3; doc2 = doc3;
 #pragma unroll
     for (int t = 0; t < NT; ++t) { tv0[t] = tv1[t]; tv1[t] = tv2[t]; }
-    gather_words(w0, wl);
+#pragma unroll
+    for (int m = 0; m < 8; ++m) ra[m] = ran[m];
+    row_addresses(w1, ran);                                        // w1 was requested a chunk ago
   }
 }
 

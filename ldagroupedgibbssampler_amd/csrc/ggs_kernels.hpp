@@ -184,78 +184,76 @@ __global__ __launch_bounds__(256) void count_sorted_kernel(CountParams p) {
 //   phi_normalise              lane per (v,k): divide, clamp, optional running phiMean +=
 //
 // column_chain: a sum over V in index order is one dependent fp64 add chain per topic --
-// it cannot be split, only fed.  One workgroup owns 8 adjacent topics (a 64-byte / 32-byte
-// slice of every row); all 256 threads stream [256 rows x 8 topics] tiles through a
-// double-buffered LDS ring with plain coalesced loads while 8 lanes of wave 0 walk the
-// previous tile row by row.  K/8 workgroups keep K/8 CUs' worth of loads in flight.
+// it cannot be split, only fed (8 cycles per add for a lone wave: >= 0.17 ms at V = 50k).
+// One workgroup owns 8 adjacent topics (a 64-byte / 32-byte slice of every row).  Waves 1-3
+// are loaders: they stream [384 rows x 8 topics] tiles into a double-buffered LDS ring with
+// plain coalesced loads and do the per-element part of the sum (beta + count) on the way;
+// 8 lanes of wave 0 do nothing but walk the previous tile row by row.  48 KiB of LDS: small
+// enough to slot in beside the theta draw running on the side stream.
 // ------------------------------------------------------------------------------
 template <typename T, bool MAGNITUDE>
 __global__ __launch_bounds__(256) void column_chain_kernel(const T *src, int32_t pitch, int32_t K, int32_t V, double beta,
                                                            double *out_sum) {
-  constexpr int TPB = 8, ROWS = 256, PER_THREAD = ROWS * TPB / 256;   // 32 KiB of LDS: small enough to slot in beside the theta draw running on the side stream
+  constexpr int TPB = 8, ROWS = 384, LOADERS = 192, PER_THREAD = ROWS * TPB / LOADERS;   // 16
   __shared__ double buf[2][ROWS * TPB];
   const int tid = threadIdx.x;
   const int k0 = blockIdx.x * TPB;
-  const int t = tid & 7, r0 = tid >> 3;             // element (row r0 + 32 j, topic t)
+  const bool loader = tid >= 64;
+  const int lt = tid - 64;                           // loader thread id
+  const int t = lt & 7, r0 = lt >> 3;               // element (row r0 + 24 j, topic t)
   // Loads are unconditional (addresses clamped into the matrix) so that all PER_THREAD of
   // them are in flight together; rows >= V and topics >= K are loaded but never consumed.
-  const T *col = src + min(k0 + t, K - 1);
+  const T *col = src + min(k0 + (t & 7), K - 1);
 
   T regs[PER_THREAD];
   auto load_tile = [&](int v0) {
 #pragma unroll
     for (int j = 0; j < PER_THREAD; ++j) {
-      const int v = min(v0 + r0 + 32 * j, V - 1);
+      const int v = min(v0 + r0 + 24 * j, V - 1);
       regs[j] = col[(size_t)v * pitch];
     }
   };
-  // the per-element part of the sum is done here, in parallel, by all 256 threads:
-  // GGS:188 dirichletParams[type] = beta + count (int -> double, one rounding)
+  // GGS:188 dirichletParams[type] = beta + count (int -> double, one rounding), in parallel
   auto store_tile = [&](int b) {
 #pragma unroll
     for (int j = 0; j < PER_THREAD; ++j)
-      buf[b][(r0 + 32 * j) * TPB + t] = MAGNITUDE ? (beta + (double)regs[j]) : (double)regs[j];
+      buf[b][(r0 + 24 * j) * TPB + t] = MAGNITUDE ? (beta + (double)regs[j]) : (double)regs[j];
   };
 
   double acc = 0;
-  load_tile(0);
-  store_tile(0);
+  if (loader) { load_tile(0); store_tile(0); }
   __syncthreads();
   int b = 0;
   for (int v0 = 0; v0 < V; v0 += ROWS, b ^= 1) {
     const bool more = v0 + ROWS < V;
-    if (more) load_tile(v0 + ROWS);                 // in flight while the chain below runs
-    if (tid < TPB) {
+    if (loader) {
+      if (more) { load_tile(v0 + ROWS); store_tile(b ^ 1); }   // lands while the chain below runs
+    } else if (tid < TPB) {
       const int rows = min(ROWS, V - v0);
       const double *bp = &buf[b][tid];
-      int r = 0;
-      if (rows >= 16) {
-        // 16 rows per step, two register sets: the LDS reads of the next 16 rows are in flight
-        // while this step's dependent add chain runs.  (The tile has ROWS rows allocated, so
-        // reading ahead of `rows` stays inside the buffer and is never added.)
+      if (rows == ROWS) {
+        // two register sets of 16 rows, no copies: the LDS reads of the next 16 rows are in
+        // flight while this set's dependent add chain runs
         double x[16], y[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) x[j] = bp[j * TPB];
-        for (; r + 32 <= rows; r += 32) {
+#pragma unroll
+        for (int r = 0; r < ROWS; r += 32) {
 #pragma unroll
           for (int j = 0; j < 16; ++j) y[j] = bp[(r + 16 + j) * TPB];
 #pragma unroll
           for (int j = 0; j < 16; ++j) acc += x[j];
-          const int rn = (r + 48 <= ROWS) ? r + 32 : r;
+          if (r + 32 < ROWS) {
 #pragma unroll
-          for (int j = 0; j < 16; ++j) x[j] = bp[(rn + j) * TPB];
+            for (int j = 0; j < 16; ++j) x[j] = bp[(r + 32 + j) * TPB];
+          }
 #pragma unroll
           for (int j = 0; j < 16; ++j) acc += y[j];
         }
-        if (r + 16 <= rows) {
-#pragma unroll
-          for (int j = 0; j < 16; ++j) acc += x[j];
-          r += 16;
-        }
+      } else {
+        for (int r = 0; r < rows; ++r) acc += bp[r * TPB];   // the last, partial tile
       }
-      for (; r < rows; ++r) acc += bp[r * TPB];
     }
-    if (more) store_tile(b ^ 1);
     __syncthreads();
   }
   if (tid < TPB && k0 + tid < K) out_sum[k0 + tid] = acc;

@@ -105,6 +105,8 @@ def main():
     ap.add_argument("--seed", type=int, default=2019)
     ap.add_argument("--cpu-sample-docs", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="run the doc-sharded path (process group + RCCL all-reduce) even with one rank; for testing")
     args = ap.parse_args()
 
     import numpy as np
@@ -125,8 +127,11 @@ def main():
         sys.exit("no GPU visible: the HIP path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist
+        if "MASTER_ADDR" not in os.environ:          # single-rank self test without a launcher
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29531"
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     K = args.topics
@@ -134,7 +139,7 @@ def main():
     z0 = java_lcg_initial_z(corpus.num_tokens, K, args.seed)
 
     h = native.GGSHandle(K, corpus.num_types, args.alpha, args.beta, args.seed, device_id=local_rank)
-    if world > 1:
+    if sharded:
         sh = ShardedGGS(h, TorchHipExchange, corpus, rank, world)
         sh.set_z_global(z0)
         step = lambda: sh.sweep(1)  # noqa: E731
@@ -186,7 +191,7 @@ def main():
             "config": {
                 "workload": "LDAGroupedGibbsSampler sweep, synthetic LDA corpus D=%d V=%d N=%d tokens K=%d alpha=%g beta=%g seed=%d"
                             % (corpus.num_docs, corpus.num_types, corpus.num_tokens, K, args.alpha, args.beta, args.seed),
-                "parallelism": "doc-sharded x%d, int32 delta all-reduce per sweep" % world if world > 1 else "1 GPU",
+                "parallelism": "doc-sharded x%d, int32 count all-reduce (RCCL) per sweep" % world if sharded else "1 GPU",
             },
             "roofline": {
                 "bound": "hbm",

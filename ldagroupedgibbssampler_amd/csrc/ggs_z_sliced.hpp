@@ -131,25 +131,23 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
       if (lane < len0) {
         const unsigned char *rb = my_row + cur * kSliceBytes;
         const unsigned char *tb = thb + s * kSliceTopics * 8;
-        // unit u = topics (k, k+1); two register sets, the reads of unit u+1 are in flight
-        // while unit u is scored
-        D2 pa = lds_d2(rb + ((rot & 7) << 4)), ta = lds_d2(tb), pb = pa, tb2 = ta;
+        // unit u = topics (k, k+1).  All 16 LDS reads of the slice are issued up front (they return
+        // in order), so the chain below starts after one LDS latency and never waits again.
+        D2 ph[kSliceUnits], th[kSliceUnits];
 #pragma unroll
-        for (int u = 0; u < kSliceUnits; u += 2) {
+        for (int u = 0; u < kSliceUnits; ++u)
+          if (s * kSliceTopics + 2 * u + 1 < KMAX) {               // compile time (KMAX is even)
+            ph[u] = lds_d2(rb + (((u + rot) & 7) << 4));
+            th[u] = lds_d2(tb + u * 16);
+          }
+#pragma unroll
+        for (int u = 0; u < kSliceUnits; ++u) {
           const int k = s * kSliceTopics + 2 * u;
-          if (k + 1 < KMAX) {                                      // compile time (KMAX is even)
-            if (k + 3 < KMAX) { pb = lds_d2(rb + (((u + 1 + rot) & 7) << 4)); tb2 = lds_d2(tb + (u + 1) * 16); }
-            sc[k] = ta.a * pa.a;
+          if (k + 1 < KMAX) {
+            sc[k] = th[u].a * ph[u].a;
             sum += sc[k];
-            sc[k + 1] = ta.b * pa.b;
+            sc[k + 1] = th[u].b * ph[u].b;
             sum += sc[k + 1];
-            if (k + 3 < KMAX) {
-              if (k + 5 < KMAX && u + 2 < kSliceUnits) { pa = lds_d2(rb + (((u + 2 + rot) & 7) << 4)); ta = lds_d2(tb + (u + 2) * 16); }
-              sc[k + 2] = tb2.a * pb.a;
-              sum += sc[k + 2];
-              sc[k + 3] = tb2.b * pb.b;
-              sum += sc[k + 3];
-            }
           }
         }
       }

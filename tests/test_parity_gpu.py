@@ -135,6 +135,17 @@ def test_ragged_corpus_with_empty_documents(native, oracle, K, alpha, beta):
     compare_state(g, o, "ragged K=%d" % K)
 
 
+@pytest.mark.parametrize("K", [193, 200, 257, 1024])
+def test_wide_topic_rows_use_the_lds_tile_kernel(native, oracle, K):
+    """K > 192: scores no longer fit the register file; z_kernel<NT> keeps the whole phiT row tile
+    in LDS and reads it twice (BASELINE config 3 is K = 1024)."""
+    c = random_corpus(120, 300, 90, seed=K, empty_every=9)
+    g, o = make_pair(native, oracle, c, K, 0.1, 0.01, 7 + K, flags=native.FLAG_PARANOID, zseed=K)
+    g.sweep(2)
+    o.sweep(2)
+    compare_state(g, o, "wide K=%d" % K)
+
+
 def test_asymmetric_alpha_and_tiny_alpha(native, oracle):
     K = 5
     alphas = np.array([0.01, 5.0, 0.04, 0.1, 0.000001])    # ModifiedSimpleLDATest.java:12

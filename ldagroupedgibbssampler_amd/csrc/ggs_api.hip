@@ -48,7 +48,7 @@ struct ggs_handle {
   // device buffers
   int64_t *d_doc_ptr = nullptr, *d_chunk_start = nullptr;
   int32_t *d_tok = nullptr, *d_z = nullptr, *d_chunk_doc = nullptr, *d_chunk_len = nullptr;
-  int32_t *d_perm = nullptr, *d_seg_word = nullptr, *d_seg_begin = nullptr;
+  int32_t *d_perm = nullptr, *d_inv_perm = nullptr, *d_zw = nullptr, *d_seg_word = nullptr, *d_seg_begin = nullptr;
   // theta of the current / last z step, and the buffer the next iteration's theta is drawn into
   // on the side stream while this iteration's counts and Phi are computed (theta_{t+1} depends
   // on z_t only, GGS:57-72)
@@ -123,12 +123,20 @@ int check_status(ggs_handle *h) {
 }
 
 // n_wk = histogram of (word, z) over this handle's tokens (UPLDA:471-474 summed over the corpus).
+// after a host upload of z (document order): refresh the word-sorted copy the count kernel reads
+int launch_permute_z(ggs_handle *h) {
+  if (h->N > 0)
+    hipLaunchKernelGGL(permute_z_kernel, dim3(grid_for(h->N, 256)), dim3(256), 0, h->stream, h->d_perm, h->d_z, h->d_zw, h->N);
+  HIP_TRY(h, hipGetLastError());
+  return GGS_OK;
+}
+
 int launch_count_rebuild(ggs_handle *h) {
   const size_t kv = (size_t)h->K * h->V;
   HIP_TRY(h, hipMemsetAsync(h->d_n_wk, 0, kv * sizeof(int32_t), h->stream));
   if (h->S > 0) {
     CountParams cp{};
-    cp.perm = h->d_perm; cp.z = h->d_z; cp.seg_word = h->d_seg_word; cp.seg_begin = h->d_seg_begin; cp.n_wk = h->d_n_wk; cp.K = h->K;
+    cp.zw = h->d_zw; cp.seg_word = h->d_seg_word; cp.seg_begin = h->d_seg_begin; cp.n_wk = h->d_n_wk; cp.K = h->K;
     hipLaunchKernelGGL(count_sorted_kernel, dim3((unsigned)h->S), dim3(256), (size_t)h->K * sizeof(int32_t), h->stream, cp);
   }
   HIP_TRY(h, hipGetLastError());
@@ -213,7 +221,7 @@ const void *sliced_kernel_for(int K) {
 int launch_z(ggs_handle *h) {
   if (h->C == 0) return GGS_OK;
   ZParams zp{};
-  zp.tok = h->d_tok; zp.z = h->d_z; zp.chunk_start = h->d_chunk_start; zp.chunk_doc = h->d_chunk_doc; zp.chunk_len = h->d_chunk_len;
+  zp.tok = h->d_tok; zp.inv_perm = h->d_inv_perm; zp.z = h->d_z; zp.zw = h->d_zw; zp.chunk_start = h->d_chunk_start; zp.chunk_doc = h->d_chunk_doc; zp.chunk_len = h->d_chunk_len;
   zp.theta = h->d_theta; zp.phiT = h->d_phiT; zp.status = h->d_status;
   zp.tok_base = h->tok_base; zp.seed = h->seed; zp.iteration = (uint32_t)h->iteration;
   zp.K = h->K; zp.Kp = h->Kp; zp.pitch16 = h->pitch16; zp.tile_tokens = h->z_tile_tokens;
@@ -433,6 +441,8 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     // lowest priority: the theta draw fills whatever the Phi phase (on the caller's stream) leaves idle
     int lo = 0, hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    // (a CU-masked side stream was tried: hipExtStreamCreateWithCUMask gives a blocking stream that
+    // serialises with the legacy default stream, so the overlap is lost -- priority alone it is)
     if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo) != hipSuccess) return bail(GGS_ERR_HIP);
   }
   for (int i = 0; i < 2; ++i)
@@ -446,7 +456,7 @@ void ggs_destroy(ggs_handle *h) {
   (void)hipSetDevice(h->device);
   (void)hipDeviceSynchronize();
   void *bufs[] = {h->d_doc_ptr, h->d_chunk_start, h->d_tok, h->d_z, h->d_chunk_doc, h->d_chunk_len, h->d_alpha, h->d_theta, h->d_theta_next,
-                  h->d_phiT, h->d_mag, h->d_tot, h->d_phi_mean, h->d_n_wk, h->d_n_k, h->d_perm, h->d_seg_word, h->d_seg_begin,
+                  h->d_phiT, h->d_mag, h->d_tot, h->d_phi_mean, h->d_n_wk, h->d_n_k, h->d_perm, h->d_inv_perm, h->d_zw, h->d_seg_word, h->d_seg_begin,
                   h->d_status, h->d_scratch};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
@@ -519,10 +529,16 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
   if ((rc = dev_alloc(h, &h->d_doc_ptr, (size_t)D + 1)) || (rc = dev_alloc(h, &h->d_tok, (size_t)N)) || (rc = dev_alloc(h, &h->d_z, (size_t)N)) ||
       (rc = dev_alloc(h, &h->d_theta, (size_t)D * h->K)) || (rc = dev_alloc(h, &h->d_theta_next, (size_t)D * h->K)) || (rc = dev_alloc(h, &h->d_chunk_start, (size_t)h->C)) ||
       (rc = dev_alloc(h, &h->d_chunk_doc, (size_t)h->C)) || (rc = dev_alloc(h, &h->d_chunk_len, (size_t)h->C)) ||
-      (rc = dev_alloc(h, &h->d_perm, (size_t)N)) || (rc = dev_alloc(h, &h->d_seg_word, (size_t)h->S)) ||
+      (rc = dev_alloc(h, &h->d_perm, (size_t)N)) || (rc = dev_alloc(h, &h->d_inv_perm, (size_t)N)) || (rc = dev_alloc(h, &h->d_zw, (size_t)N)) || (rc = dev_alloc(h, &h->d_seg_word, (size_t)h->S)) ||
       (rc = dev_alloc(h, &h->d_seg_begin, (size_t)h->S + 1)))
     return rc;
-  if (N) HIP_TRY(h, hipMemcpy(h->d_perm, perm.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice));
+  if (N) {
+    HIP_TRY(h, hipMemcpy(h->d_perm, perm.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice));
+    std::vector<int32_t> inv((size_t)N);
+    for (int64_t i = 0; i < N; ++i) inv[(size_t)perm[(size_t)i]] = (int32_t)i;
+    HIP_TRY(h, hipMemcpy(h->d_inv_perm, inv.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice));
+  }
+  HIP_TRY(h, hipMemset(h->d_zw, 0, sizeof(int32_t) * std::max<size_t>((size_t)N, 1)));
   if (h->S) HIP_TRY(h, hipMemcpy(h->d_seg_word, seg_word.data(), sizeof(int32_t) * seg_word.size(), hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(h->d_seg_begin, seg_begin.data(), sizeof(int32_t) * seg_begin.size(), hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(h->d_doc_ptr, doc_ptr, sizeof(int64_t) * ((size_t)D + 1), hipMemcpyHostToDevice));
@@ -548,6 +564,7 @@ int ggs_init_z_java_lcg(ggs_handle *h, int32_t seed) {
   std::vector<int32_t> z((size_t)h->N);
   java_lcg_next_ints(seed, h->K, h->N, z.data());
   if (h->N) HIP_TRY(h, hipMemcpyAsync(h->d_z, z.data(), sizeof(int32_t) * (size_t)h->N, hipMemcpyHostToDevice, h->stream));
+  if ((rc = launch_permute_z(h))) return rc;
   if ((rc = launch_count_rebuild(h))) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return GGS_OK;
@@ -561,6 +578,7 @@ int ggs_set_z(ggs_handle *h, const int32_t *z, int32_t redraw_phi) {
     if (z[i] < 0 || z[i] >= h->K) return set_err(h, GGS_ERR_BAD_ARG, "topic indicator outside [0, num_topics)");
   if ((rc = drop_theta_ahead(h))) return rc;
   if (h->N) HIP_TRY(h, hipMemcpyAsync(h->d_z, z, sizeof(int32_t) * (size_t)h->N, hipMemcpyHostToDevice, h->stream));
+  if ((rc = launch_permute_z(h))) return rc;
   if ((rc = launch_count_rebuild(h))) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   if (redraw_phi) return ggs_init_phi(h);

@@ -5,6 +5,9 @@
 //   z[N]              int32   topic assignments
 //   chunk_*[C]                z-kernel work items: <=64 consecutive tokens of ONE document
 //   perm[N]           int32   token indices sorted by word id (built once on the host)
+//   inv_perm[N]       int32   its inverse: position of token i in the word-sorted order
+//   zw[N]             int32   z in word-sorted order (zw[inv_perm[i]] == z[i]), written by the
+//                             z kernel beside z so that the count rebuild streams instead of gathering
 //   seg_*[S]                  count-kernel work items: <=4096 consecutive entries of perm
 //                             that all carry the same word
 //   theta[D][K]       fp64    thetaMatrix rows (GGS:72)
@@ -136,15 +139,14 @@ __global__ __launch_bounds__(BLOCK) void theta_kernel(ThetaParams p) {
 
 // ------------------------------------------------------------------------------
 // K4+K5: type-topic counts.  One workgroup = one segment = up to 4096 consecutive entries
-// of the word-sorted token permutation, all with the same word w: topic histogram in LDS,
+// of the word-sorted topic assignments zw, all with the same word w: topic histogram in LDS,
 // then K integer adds onto row w (n_wk is zeroed before the launch; several segments of a
 // frequent word add to the same row).  Short segments (rare words) add straight to HBM.
 // ------------------------------------------------------------------------------
 struct CountParams {
-  const int32_t *perm;       // token indices sorted by word
-  const int32_t *z;
+  const int32_t *zw;         // topic assignments in word-sorted order
   const int32_t *seg_word;   // [S]
-  const int32_t *seg_begin;  // [S+1] offsets into perm
+  const int32_t *seg_begin;  // [S+1] offsets into zw
   int32_t *n_wk;
   int32_t K;
 };
@@ -156,18 +158,17 @@ __global__ __launch_bounds__(256) void count_sorted_kernel(CountParams p) {
   const int beg = p.seg_begin[seg], end = p.seg_begin[seg + 1];
   int32_t *row = p.n_wk + (size_t)p.seg_word[seg] * K;
   if (end - beg <= 256) {                    // wave-uniform per block
-    if (beg + tid < end) atomicAdd(&row[p.z[p.perm[beg + tid]]], 1);
+    if (beg + tid < end) atomicAdd(&row[p.zw[beg + tid]], 1);
     return;
   }
   for (int k = tid; k < K; k += 256) hist[k] = 0;
   __syncthreads();
   int i = beg + tid;
   for (; i + 768 < end; i += 1024) {
-    const int t0 = p.perm[i], t1 = p.perm[i + 256], t2 = p.perm[i + 512], t3 = p.perm[i + 768];
-    const int k0 = p.z[t0], k1 = p.z[t1], k2 = p.z[t2], k3 = p.z[t3];
+    const int k0 = p.zw[i], k1 = p.zw[i + 256], k2 = p.zw[i + 512], k3 = p.zw[i + 768];
     atomicAdd(&hist[k0], 1); atomicAdd(&hist[k1], 1); atomicAdd(&hist[k2], 1); atomicAdd(&hist[k3], 1);
   }
-  for (; i < end; i += 256) atomicAdd(&hist[p.z[p.perm[i]]], 1);
+  for (; i < end; i += 256) atomicAdd(&hist[p.zw[i]], 1);
   __syncthreads();
   for (int k = tid; k < K; k += 256) {
     const int32_t cnt = hist[k];
@@ -257,6 +258,12 @@ __global__ __launch_bounds__(256) void column_chain_kernel(const T *src, int32_t
     __syncthreads();
   }
   if (tid < TPB && k0 + tid < K) out_sum[k0 + tid] = acc;
+}
+
+// zw[i] = z[perm[i]]: word-sorted copy of z after a host upload (set_z, seeded initial z)
+__global__ __launch_bounds__(256) void permute_z_kernel(const int32_t *perm, const int32_t *z, int32_t *zw, int64_t n) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) zw[i] = z[perm[i]];
 }
 
 // tokensPerTopic n_k = sum_v n_wk[v][k]: integers, any order.

@@ -24,7 +24,9 @@ namespace ggs {
 
 struct ZParams {
   const int32_t *tok;
-  int32_t *z;
+  const int32_t *inv_perm;     // position of token i in the word-sorted order
+  int32_t *z;                  // document (CSR) order
+  int32_t *zw;                 // word-sorted order, zw[inv_perm[i]] = z[i]
   const int64_t *chunk_start;  // local token index of the chunk's first token
   const int32_t *chunk_doc;    // local document index
   const int32_t *chunk_len;
@@ -214,6 +216,7 @@ __global__ __launch_bounds__(64) void z_kernel(ZParams p) {
         new_topic = new_topic < 0 ? 0 : K - 1;
       }
       p.z[start + lane] = new_topic;
+      p.zw[p.inv_perm[start + lane]] = new_topic;
     }
     if (!has_next) break;
     __syncthreads();                               // every LDS read of this tile is done before the next tile lands

@@ -94,6 +94,10 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
   int w0 = (lane < len0) ? p.tok[start0 + lane] : 0;
   int w1 = (lane < len1) ? p.tok[start1 + lane] : 0;              // len1 == 0 when there is no next chunk
   int w2 = 0;
+  // word-sorted slot of each lane's token (for the second z store), requested with the word ids
+  int ip0 = (lane < len0) ? p.inv_perm[start0 + lane] : 0;
+  int ip1 = (lane < len1) ? p.inv_perm[start1 + lane] : 0;
+  int ip2 = 0;
   double tv0[NT], tv1[NT], tv2[NT];
   load_theta(doc0, tv0);
   load_theta(doc1, tv1);                                           // doc1 == 0 (a valid row) when there is no next chunk
@@ -161,6 +165,7 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
       if (c + 3 * stride < C) { start3 = cstart[c + 3 * stride]; len3 = clen[c + 3 * stride]; doc3 = cdoc[c + 3 * stride]; }
       else { start3 = 0; len3 = 0; doc3 = 0; }
       w2 = (lane < len2) ? p.tok[start2 + lane] : 0;
+      ip2 = (lane < len2) ? p.inv_perm[start2 + lane] : 0;
       load_theta(doc2, tv2);
     }
 
@@ -190,11 +195,12 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
         new_topic = new_topic < 0 ? 0 : K - 1;
       }
       p.z[start0 + lane] = new_topic;
+      p.zw[ip0] = new_topic;
     }
     if (!has1) break;
     c += stride;
-    start0 = start1; len0 = len1; doc0 = doc1; w0 = w1;
-    start1 = start2; len1 = len2; doc1 = doc2; w1 = w2;
+    start0 = start1; len0 = len1; doc0 = doc1; w0 = w1; ip0 = ip1;
+    start1 = start2; len1 = len2; doc1 = doc2; w1 = w2; ip1 = ip2;
     start2 = start3; len2 = len3; doc2 = doc3;
 #pragma unroll
     for (int t = 0; t < NT; ++t) { tv0[t] = tv1[t]; tv1[t] = tv2[t]; }

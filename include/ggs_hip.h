@@ -160,8 +160,10 @@ int ggs_get_theta(ggs_handle *h, int64_t doc_begin, int64_t doc_end, double *the
 int ggs_get_doc_topic_counts(ggs_handle *h, int64_t doc_begin, int64_t doc_end, int32_t *n_dk); /* getDocumentTopicMatrix, MSLDA:536-547 */
 int ggs_get_timings(ggs_handle *h, ggs_timings *out);                   /* zSamplingTimeCum / phiSamplingTimeCum, UPLDA:642-693 */
 int ggs_reset_timings(ggs_handle *h);
-/* replaces: ensureConsistentTopicTypeCounts (UPLDA:299-338) + the "all deltas
- * zero at postSample" assert (ParanoidUncollapsedParallelLDA.java:42-55). */
+/* replaces: ensureConsistentTopicTypeCounts (UPLDA:299-338): counts >= 0, they sum to the
+ * corpus size, column sums == tokensPerTopic.  (The reference's other paranoid assert, "all
+ * deltas zero at postSample", ParanoidUncollapsedParallelLDA.java:42-55, has no device
+ * counterpart: there is no delta matrix, the counts are rebuilt from z every sweep.) */
 int ggs_check_invariants(ggs_handle *h);
 /* Launch geometry of the z kernel, for bench.py's roofline accounting. */
 int ggs_get_launch_info(ggs_handle *h, int64_t *num_chunks, int32_t *lds_bytes_z, int32_t *docs_per_block_theta);

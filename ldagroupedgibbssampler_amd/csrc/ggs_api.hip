@@ -122,7 +122,6 @@ int check_status(ggs_handle *h) {
   return set_err(h, GGS_ERR_RNG_EXHAUSTED, "a gamma rejection loop exceeded GGS_MAX_BLOCKS Philox blocks");
 }
 
-// n_wk = histogram of (word, z) over this handle's tokens (UPLDA:471-474 summed over the corpus).
 // after a host upload of z (document order): refresh the word-sorted copy the count kernel reads
 int launch_permute_z(ggs_handle *h) {
   if (h->N > 0)
@@ -131,6 +130,7 @@ int launch_permute_z(ggs_handle *h) {
   return GGS_OK;
 }
 
+// n_wk = histogram of (word, z) over this handle's tokens (UPLDA:471-474 summed over the corpus).
 int launch_count_rebuild(ggs_handle *h) {
   const size_t kv = (size_t)h->K * h->V;
   HIP_TRY(h, hipMemsetAsync(h->d_n_wk, 0, kv * sizeof(int32_t), h->stream));
@@ -388,7 +388,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     h->z_sliced = h->K <= kSlicedMaxTopics;
     if (const char *e = std::getenv("GGS_DEBUG_ZKERNEL")) h->z_sliced = h->z_sliced && std::atoi(e) != 0;
     if (h->z_sliced) {
-      // 64-token chunks, a 2-slot ring of 32-topic slices + the theta row; one wave per SIMD
+      // 64-token chunks, a 4-slot ring of 16-topic slices + the theta row; one wave per SIMD
       // (the score registers take most of the 512-entry file)
       h->z_tile_tokens = 64;
       h->z_lds = kRingSlots * kSliceBytes + ((h->K + 7) / 8) * 64;   // ring + theta row zero-padded to KMAX

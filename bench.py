@@ -195,7 +195,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "z_kernel",
+                "kernel": "z_sliced_kernel<%d>" % (8 * ((K + 7) // 8)) if K <= 192 else "z_kernel",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

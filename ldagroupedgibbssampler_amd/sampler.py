@@ -71,6 +71,33 @@ def calc_theta_estimate(num_topics, alpha, one_doc_topics):
     return est
 
 
+def model_log_likelihood(n_dk, n_wk, n_k, alpha, beta):
+    """UncollapsedParallelLDA.modelLogLikelihood (UPLDA:1644-1758): Dirichlet-multinomial log
+    likelihood of the topic assignments, from the count matrices alone.  Host-side diagnostic
+    (it stays on the host in the reference too).  MALLET's Dirichlet.logGammaStirling is not
+    in the reference tree; scipy's gammaln stands in for it (restate from the public
+    formula, ~1e-6 relative), so against a JVM value this is pinned only to that accuracy."""
+    from scipy.special import gammaln
+    n_dk = np.asarray(n_dk, np.float64)
+    n_wk = np.asarray(n_wk, np.float64)
+    n_k = np.asarray(n_k, np.float64)
+    K = n_dk.shape[1]
+    V = n_wk.shape[0]
+    a = np.broadcast_to(np.asarray(alpha, np.float64), (K,))
+    alpha_sum = float(a.sum())
+    ll = 0.0
+    nz = n_dk > 0                                                    # UPLDA:1680-1685
+    ll += float((gammaln(n_dk + a)[nz]).sum() - (np.broadcast_to(gammaln(a), n_dk.shape)[nz]).sum())
+    ll -= float(gammaln(alpha_sum + n_dk.sum(1)).sum())              # UPLDA:1689
+    ll += n_dk.shape[0] * float(gammaln(alpha_sum))                  # UPLDA:1694
+    nzw = n_wk > 0                                                   # UPLDA:1701-1722
+    ll += float(gammaln(beta + n_wk[nzw]).sum())
+    ll -= float(gammaln(beta * V + n_k).sum())                       # UPLDA:1724-1728
+    ll += float(gammaln(beta * V)) * K                               # UPLDA:1742-1743
+    ll -= float(gammaln(beta)) * int(nzw.sum())                      # UPLDA:1746-1747
+    return ll
+
+
 class LDAGroupedGibbsSampler:
     """scheme=ggs on MI355X.  One instance drives one GPU (doc-sharded runs wrap the same
     native handle with ldagroupedgibbssampler_amd.sharded.ShardedGGS)."""
@@ -223,6 +250,11 @@ class LDAGroupedGibbsSampler:
         """thetaMatrix of the last z step (GGS:72; what UPLDA:716-720 copies for scheme ggs)."""
         self._need_data()
         return self._h.get_theta()
+
+    def modelLogLikelihood(self):
+        """UPLDA:1644-1758, computed on the host from copied-back counts (a diagnostic)."""
+        return model_log_likelihood(self.getDocumentTopicMatrix(), self.getTypeTopicMatrix(), self.getTopicTotals(),
+                                    self.alpha, self.beta)
 
     def getBeta(self):
         return self.beta

@@ -341,3 +341,36 @@ def test_full_size_properties(native):
     assert (phi > 0).all()
     *_, h2 = run()
     assert h1 == h2
+
+
+def test_sharded_orchestration_over_rccl_single_rank(native, oracle):
+    """The product's sharded path end to end -- ShardedGGS + TorchHipExchange (torch.distributed,
+    backend nccl == RCCL) acting in place on the library's own count buffer -- with the one rank a
+    one-GPU box allows.  (Two-rank logic: tests/test_distributed_gloo.py; three shards on one GPU:
+    test_sharded_via_torch above.)"""
+    torch = pytest.importorskip("torch")
+    import os
+    import torch.distributed as dist
+    from ldagroupedgibbssampler_amd.sharded import ShardedGGS, TorchHipExchange, java_lcg_initial_z
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29577")
+    torch.cuda.set_device(0)
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        c = random_corpus(150, 220, 90, seed=31, empty_every=12)
+        K, alpha, beta, seed = 16, 0.1, 0.01, 5150
+        h = native.GGSHandle(K, c.num_types, alpha, beta, seed, flags=native.FLAG_PARANOID)
+        sh = ShardedGGS(h, TorchHipExchange, c, 0, 1)
+        z0 = java_lcg_initial_z(c.num_tokens, K, 9)
+        sh.set_z_global(z0)
+        sh.sweep(3)
+        o = oracle.OracleSampler(K, c.num_types, alpha, beta, seed)
+        o.set_corpus(c.doc_ptr, c.tokens)
+        o.set_z(z0, redraw_phi=True)
+        o.sweep(3)
+        compare_state(h, o, "rccl single rank")
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -14,6 +14,7 @@
 
 #include "ggs_kernels.hpp"
 #include "ggs_z_sliced.hpp"
+#include "ggs_z_stream.hpp"
 
 using namespace ggs;
 
@@ -43,6 +44,7 @@ struct ggs_handle {
   bool have_corpus = false, have_phi = false, in_sweep = false;
   int32_t theta_docs_per_block = 0, theta_lds = 0, z_lds = 0, z_tile_tokens = 0, z_waves_per_cu = 0, num_cus = 0;
   bool z_sliced = false;   // scores-in-registers kernel (K <= kSlicedMaxTopics)
+  bool z_stream = false;   // two-pass streaming kernel (K > kSlicedMaxTopics)
 
   hipStream_t stream = nullptr;
   // device buffers
@@ -233,7 +235,8 @@ int launch_z(ggs_handle *h) {
   if (h->z_sliced) {
     void *args[] = {&zp};
     HIP_TRY(h, hipLaunchKernel(sliced_kernel_for(h->K), grid, block, args, (size_t)h->z_lds, h->stream));
-  } else if (nt <= 1) hipLaunchKernelGGL(z_kernel<1>, grid, block, h->z_lds, h->stream, zp);
+  } else if (h->z_stream) hipLaunchKernelGGL(z_stream_kernel, grid, block, h->z_lds, h->stream, zp);
+  else if (nt <= 1) hipLaunchKernelGGL(z_kernel<1>, grid, block, h->z_lds, h->stream, zp);
   else if (nt <= 2) hipLaunchKernelGGL(z_kernel<2>, grid, block, h->z_lds, h->stream, zp);
   else if (nt <= 4) hipLaunchKernelGGL(z_kernel<4>, grid, block, h->z_lds, h->stream, zp);
   else if (nt <= 8) hipLaunchKernelGGL(z_kernel<8>, grid, block, h->z_lds, h->stream, zp);
@@ -386,8 +389,21 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     auto alloc_of = [&](int bytes) { return (bytes + kGranule - 1) / kGranule * kGranule; };
     const int pitch = h->pitch16 * 16, thbytes = ((h->Kp * 8 + 15) / 16) * 16;
     h->z_sliced = h->K <= kSlicedMaxTopics;
-    if (const char *e = std::getenv("GGS_DEBUG_ZKERNEL")) h->z_sliced = h->z_sliced && std::atoi(e) != 0;
-    if (h->z_sliced) {
+    h->z_stream = !h->z_sliced;
+    if (const char *e = std::getenv("GGS_DEBUG_ZKERNEL")) {          // 0: whole-row tile kernel, 2: streaming kernel where it applies
+      const int mode = std::atoi(e);
+      h->z_sliced = h->z_sliced && mode == 1;
+      h->z_stream = mode == 2 ? h->K > 2 * kSliceTopics : (h->z_stream && mode != 0);
+    }
+    if (h->z_stream) {
+      // 64-token chunks, the same 4-slot ring + the theta row zero-padded to whole slices; no
+      // score registers, so 8 waves per CU fit the register file and LDS bounds the residency
+      h->z_tile_tokens = 64;
+      h->z_lds = kRingSlots * kSliceBytes + ((h->K + kSliceTopics - 1) / kSliceTopics) * kSliceTopics * 8;
+      if (h->z_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);   // K > ~16000: the theta row itself would need slicing
+      h->z_waves_per_cu = std::max(1, std::min(8, kMaxLdsBytes / alloc_of(h->z_lds)));
+      if (const char *e = std::getenv("GGS_DEBUG_WPC")) h->z_waves_per_cu = std::max(1, std::atoi(e));
+    } else if (h->z_sliced) {
       // 64-token chunks, a 4-slot ring of 16-topic slices + the theta row; one wave per SIMD
       // (the score registers take most of the 512-entry file)
       h->z_tile_tokens = 64;
@@ -417,8 +433,10 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
   const void *zk[] = {reinterpret_cast<const void *>(z_kernel<1>), reinterpret_cast<const void *>(z_kernel<2>),
                       reinterpret_cast<const void *>(z_kernel<4>), reinterpret_cast<const void *>(z_kernel<8>),
                       reinterpret_cast<const void *>(z_kernel<16>), reinterpret_cast<const void *>(z_kernel<20>)};
+  if (h->z_stream && hipFuncSetAttribute(reinterpret_cast<const void *>(z_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, h->z_lds) != hipSuccess)
+    return bail(GGS_ERR_HIP);
   for (const void *f : zk)
-    if (!h->z_sliced && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, h->z_lds) != hipSuccess) return bail(GGS_ERR_HIP);
+    if (!h->z_sliced && !h->z_stream &&hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, h->z_lds) != hipSuccess) return bail(GGS_ERR_HIP);
   if (hipFuncSetAttribute(reinterpret_cast<const void *>(theta_kernel<kThetaBlock>), hipFuncAttributeMaxDynamicSharedMemorySize, h->theta_lds) != hipSuccess)
     return bail(GGS_ERR_HIP);
   const size_t kv = (size_t)h->K * h->V;

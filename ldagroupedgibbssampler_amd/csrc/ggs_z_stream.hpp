@@ -1,0 +1,178 @@
+// ggs_z_stream.hpp -- K3, the token loop (GGS:79-130), for any number of topics: the wide-row
+// variant (K > kSlicedMaxTopics, e.g. BASELINE config 3 with K = 1024), where a token's K scores
+// fit neither the register file nor LDS.
+//
+// Same machinery as ggs_z_sliced.hpp -- persistent single-wave workgroups striding the chunk
+// table, lane t owns token t of a <= 64-token chunk of ONE document, phiT rows streamed by
+// LDS-DMA through a 4-slot ring of 16-topic slices (8 KiB) kept 3 slices ahead, the same
+// per-row rotation for conflict-free reads -- but the row is streamed TWICE per chunk:
+//
+//   pass 1 (slices 0..NS-1):  sum += theta[k]*phi[k][w_t], k ascending          (GGS:96-101)
+//   U from Philox, sample = U*sum                                               (GGS:107-108)
+//   pass 2 (slices 0..NS-1):  cnt += (sample > 0); sample -= theta[k]*phi[k][w_t] (GGS:109-113)
+//
+// The product theta[k]*phi[k][w] is the same single IEEE multiplication in both passes, so
+// pass 2 subtracts exactly the scores pass 1 summed (what Java keeps in topicTermScores[]).
+// The 2*NS slices of a chunk and the first slices of the next chunk form one regular DMA
+// stream (no early exit: the latest lane of a 64-token chunk almost always walks to the end),
+// so the vmcnt arithmetic stays exact.  Second-pass reads are mostly L2 / Infinity-Cache hits.
+#pragma once
+#include "ggs_z_sliced.hpp"
+
+namespace ggs {
+
+__global__ __launch_bounds__(64) void z_stream_kernel(ZParams p) {
+  constexpr int kAhead = 3;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const int K = p.K, Kp = p.Kp;
+  const int NS = (K + kSliceTopics - 1) / kSliceTopics;            // slices per pass (host guarantees NS >= 3)
+  const int KT = NS * kSliceTopics;                                // theta row in LDS, zero padded
+  double *thb = reinterpret_cast<double *>(smem + kRingSlots * kSliceBytes);
+  const unsigned char *phib = reinterpret_cast<const unsigned char *>(p.phiT);
+  const size_t rowbytes = (size_t)Kp * 8;
+  const const_i64_t *cstart = (const const_i64_t *)p.chunk_start;
+  const const_i32_t *clen = (const const_i32_t *)p.chunk_len;
+  const const_i32_t *cdoc = (const const_i32_t *)p.chunk_doc;
+  const int64_t C = p.num_chunks;
+
+  const int lrow = lane >> 3, lslot = lane & 7;
+  const unsigned char *my_row = smem + lane * 128;
+  const int rot = lane >> 1;
+
+  auto row_addresses = [&](const int w, const unsigned char *(&ra)[8]) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int row = 8 * m + lrow;
+      const int wm = __shfl(w, row);                               // 0 for rows past the chunk
+      ra[m] = phib + (size_t)wm * rowbytes + (size_t)(((lslot - (row >> 1)) & 7) << 4);
+    }
+  };
+  auto issue_slice = [&](const int s, const int slot, const unsigned char *const (&ra)[8]) {
+    const size_t off = (size_t)s * 128;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+      __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(ra[m] + off), (lds_void_t *)(smem + slot * kSliceBytes + m * 1024), 16, 0, 0);
+  };
+
+  // a contiguous range of chunks per wave (every chunk costs the same whatever its length), so
+  // the chunks of one document follow each other and its theta row is staged once
+  const int64_t cend = C * (int64_t)(blockIdx.x + 1) / (int64_t)gridDim.x;
+  int64_t c = C * (int64_t)blockIdx.x / (int64_t)gridDim.x;
+  if (c >= cend) return;
+  int doc_in_lds = -1;
+  int64_t start0 = cstart[c], start1 = 0;
+  int len0 = clen[c], len1 = 0, doc0 = cdoc[c], doc1 = 0;
+  if (c + 1 < cend) { start1 = cstart[c + 1]; len1 = clen[c + 1]; doc1 = cdoc[c + 1]; }
+  int w0 = (lane < len0) ? p.tok[start0 + lane] : 0;
+  int ip0 = (lane < len0) ? p.inv_perm[start0 + lane] : 0;
+  const unsigned char *ra[8], *ran[8];
+  row_addresses(w0, ra);
+  int g = 0;                                                       // ring slot of this chunk's first slice
+#pragma unroll
+  for (int s = 0; s < kAhead; ++s) issue_slice(s, (g + s) & (kRingSlots - 1), ra);
+
+  for (;;) {
+    const bool has1 = c + 1 < cend;
+    // This chunk's theta row -> LDS, and the next chunk's word ids / addresses.  The loads are
+    // waited for right here (they drain the DMA queue once per chunk: a small bubble against
+    // 2*NS slices of work).
+    if (doc0 != doc_in_lds) {                                      // wave-uniform: consecutive chunks share the document
+      const double *thg = p.theta + (size_t)doc0 * K;
+      for (int base = 0; base < KT; base += 1024) {                // 16 loads in flight per lane, one round trip per 1024 topics
+        double t[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int k = base + i * 64 + lane;
+          t[i] = thg[k < K ? k : K - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int k = base + i * 64 + lane;
+          if (k < KT) thb[k] = (k < K) ? t[i] : 0.0;
+        }
+      }
+      doc_in_lds = doc0;
+    }
+    int w1 = 0, ip1 = 0;
+    int64_t start2 = 0;
+    int len2 = 0, doc2 = 0;
+    if (has1) {
+      w1 = (lane < len1) ? p.tok[start1 + lane] : 0;
+      ip1 = (lane < len1) ? p.inv_perm[start1 + lane] : 0;
+      if (c + 2 < cend) { start2 = cstart[c + 2]; len2 = clen[c + 2]; doc2 = cdoc[c + 2]; }
+      row_addresses(w1, ran);
+    }
+    asm volatile("" ::: "memory");
+
+    double sum = 0.0, sample = 0.0, U = 0.0;
+    int cnt = 0;
+    for (int j = 0; j < 2 * NS; ++j) {
+      const int s = j < NS ? j : j - NS;
+      const int cur = (g + j) & (kRingSlots - 1);
+      const int nxt = (g + j + kAhead) & (kRingSlots - 1);
+      const int ja = j + kAhead;
+      if (ja < 2 * NS) issue_slice(ja < NS ? ja : ja - NS, nxt, ra);
+      else if (has1) issue_slice(ja - 2 * NS, nxt, ran);
+      // all but the youngest 8*kAhead DMAs done => slice j has landed; at the tail of the last
+      // chunk fewer slices follow it
+      if (has1 || ja < 2 * NS) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else {
+        const int rem = 2 * NS - 1 - j;                            // 0, 1 or 2 slices still behind this one
+        if (rem == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if (rem == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      if (lane < len0) {
+        const unsigned char *rb = my_row + cur * kSliceBytes;
+        const unsigned char *tb = reinterpret_cast<const unsigned char *>(thb) + s * kSliceTopics * 8;
+        D2 ph[kSliceUnits], th[kSliceUnits];
+#pragma unroll
+        for (int u = 0; u < kSliceUnits; ++u) {
+          ph[u] = lds_d2(rb + (((u + rot) & 7) << 4));
+          th[u] = lds_d2(tb + u * 16);
+        }
+        if (j < NS) {
+#pragma unroll
+          for (int u = 0; u < kSliceUnits; ++u) {
+            sum += th[u].a * ph[u].a;
+            sum += th[u].b * ph[u].b;
+          }
+          if (j == NS - 1) {
+            const uint64_t gtok = (uint64_t)(p.tok_base + start0 + lane);
+            const U4 o = philox4x32_10((uint32_t)gtok, (uint32_t)(gtok >> 32), (uint32_t)GGS_PURPOSE_Z << 24, p.iteration,
+                                       (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
+            U = u53(o.x, o.y);
+            sample = U * sum;
+          }
+        } else {
+#pragma unroll
+          for (int u = 0; u < kSliceUnits; ++u) {
+            cnt += (sample > 0.0); sample -= th[u].a * ph[u].a;
+            cnt += (sample > 0.0); sample -= th[u].b * ph[u].b;
+          }
+        }
+      }
+      asm volatile("" ::: "memory");                               // every read of this ring slot is issued before it is refilled
+    }
+    g = (g + 2 * NS) & (kRingSlots - 1);
+
+    if (lane < len0) {
+      int new_topic = cnt - 1;
+      if (new_topic < 0 || sample > 0.0) {                         // GGS:116-118 (and the index past K Java would throw on)
+        atomicOr(p.status, ST_INVALID_TOPIC);
+        new_topic = new_topic < 0 ? 0 : K - 1;
+      }
+      p.z[start0 + lane] = new_topic;
+      p.zw[ip0] = new_topic;
+    }
+    if (!has1) break;
+    c += 1;
+    start0 = start1; len0 = len1; doc0 = doc1; w0 = w1; ip0 = ip1;
+    start1 = start2; len1 = len2; doc1 = doc2;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) ra[m] = ran[m];
+  }
+}
+
+}  // namespace ggs

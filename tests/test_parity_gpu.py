@@ -135,15 +135,30 @@ def test_ragged_corpus_with_empty_documents(native, oracle, K, alpha, beta):
     compare_state(g, o, "ragged K=%d" % K)
 
 
-@pytest.mark.parametrize("K", [193, 200, 257, 1024])
-def test_wide_topic_rows_use_the_lds_tile_kernel(native, oracle, K):
-    """K > 192: scores no longer fit the register file; z_kernel<NT> keeps the whole phiT row tile
-    in LDS and reads it twice (BASELINE config 3 is K = 1024)."""
-    c = random_corpus(120, 300, 90, seed=K, empty_every=9)
+@pytest.mark.parametrize("K", [193, 200, 257, 1024, 1100, 2049])
+def test_wide_topic_rows_use_the_streaming_kernel(native, oracle, K):
+    """K > 192: scores no longer fit the register file; z_stream_kernel streams the phiT rows
+    through the slice ring twice (BASELINE config 3 is K = 1024; > 1024 topics take a second
+    round of theta staging)."""
+    c = random_corpus(120, 300, 150, seed=K, empty_every=9)
     g, o = make_pair(native, oracle, c, K, 0.1, 0.01, 7 + K, flags=native.FLAG_PARANOID, zseed=K)
+    assert g.launch_info()["lds_bytes_z"] == 4 * 8192 + (K + 15) // 16 * 128
     g.sweep(2)
     o.sweep(2)
     compare_state(g, o, "wide K=%d" % K)
+
+
+@pytest.mark.parametrize("mode,K", [(2, 33), (2, 48), (2, 100), (2, 192), (0, 5), (0, 100), (0, 257)])
+def test_alternate_z_kernels_agree(native, oracle, K, mode, monkeypatch):
+    """The three z kernels are interchangeable: GGS_DEBUG_ZKERNEL=2 forces the streaming kernel
+    below 193 topics, =0 the whole-row LDS tile kernel (first-generation, kept as a cross-check)."""
+    monkeypatch.setenv("GGS_DEBUG_ZKERNEL", str(mode))
+    c = random_corpus(150, 400, 140, seed=K + mode, empty_every=11)
+    g, o = make_pair(native, oracle, c, K, 0.1, 0.01, 70 + K, flags=native.FLAG_PARANOID, zseed=K)
+    monkeypatch.delenv("GGS_DEBUG_ZKERNEL")
+    g.sweep(3)
+    o.sweep(3)
+    compare_state(g, o, "z kernel mode %d K=%d" % (mode, K))
 
 
 def test_asymmetric_alpha_and_tiny_alpha(native, oracle):

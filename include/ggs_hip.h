@@ -172,6 +172,10 @@ int ggs_debug_philox(int32_t device_id, int64_t n, const uint32_t *ctr /*n*4*/, 
 int ggs_debug_math(int32_t device_id, int32_t op /*0 log,1 pow,2 sqrt,3 div*/, int64_t n, const double *x, const double *y, double *out);
 int ggs_debug_draw(int32_t device_id, int32_t kind /*0 uniform,1 gaussian,2 gamma*/, uint64_t seed, uint32_t iteration,
                    uint32_t purpose, uint64_t elem0, int64_t n, const double *shape, double *out, int32_t *status);
+/* out[k] = x[0][k] + x[1][k] + ... in index order (exactly one of x / counts given; with counts the addends are
+ * beta + counts[v][k]): the Phi normalisers' exact parallel column sum on its own, for adversarial inputs */
+int ggs_debug_column_sum(int32_t device_id, int32_t V, int32_t K, const double *x /*V*K or NULL*/, const int32_t *counts /*V*K or NULL*/,
+                         double beta, double *out /*K*/);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libggs_hip.so")
+LIB_PATH = os.environ.get("GGS_HIP_LIB") or os.path.join(CSRC, "libggs_hip.so")   # override: kernel experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ggs_hip.h")
 
 ABI_VERSION = 1
@@ -88,12 +88,13 @@ SIGNATURES = {
     "ggs_debug_math": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _dp, _dp, _dp]),
     "ggs_debug_draw": (C.c_int, [C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int64,
                                  _dp, _dp, _ip]),
+    "ggs_debug_column_sum": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _ip, C.c_double, _dp]),
 }
 
 
 def build(force=False):
     """Compile libggs_hip.so in-tree (hipcc --offload-arch=gfx950)."""
-    srcs = [os.path.join(CSRC, f) for f in ("ggs_api.hip", "ggs_kernels.hpp", "ggs_z_kernel.hpp", "ggs_z_sliced.hpp", "ggs_device_math.hpp")] + [HEADER_PATH]
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".hpp"))] + [HEADER_PATH]
     if (not force and os.path.exists(LIB_PATH)
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs)):
         return LIB_PATH

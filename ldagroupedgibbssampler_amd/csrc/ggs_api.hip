@@ -15,6 +15,7 @@
 #include "ggs_kernels.hpp"
 #include "ggs_z_sliced.hpp"
 #include "ggs_z_stream.hpp"
+#include "ggs_exact_sum.hpp"
 
 using namespace ggs;
 
@@ -62,6 +63,9 @@ struct ggs_handle {
   int64_t theta_ahead_iter = INT64_MIN;     // iteration the side-stream theta was drawn for, or none
   double *d_alpha = nullptr, *d_theta = nullptr, *d_phiT = nullptr, *d_mag = nullptr, *d_tot = nullptr, *d_phi_mean = nullptr;
   int32_t *d_n_wk = nullptr, *d_n_k = nullptr;
+  double *d_sum_pref = nullptr, *d_sum_fn = nullptr;   // work space of the exact parallel column sums (ggs_exact_sum.hpp)
+  int32_t sum_nseg = 0;
+  bool exact_sum = true;                               // GGS_DEBUG_CHAIN=1: the element-by-element column_chain_kernel instead
   uint32_t *d_status = nullptr;
   void *d_scratch = nullptr;
   size_t scratch_bytes = 0;
@@ -145,9 +149,26 @@ int launch_count_rebuild(ggs_handle *h) {
   return GGS_OK;
 }
 
+// out[k] = sum over v, in index order, of src[v][k] (MAGNITUDE: of beta + src[v][k]) -- the exact
+// parallel formulation of ggs_exact_sum.hpp, or the element-by-element chain it replaces
+template <typename T, bool MAGNITUDE>
+void launch_column_sum(ggs_handle *h, const T *src, int32_t pitch, double *out) {
+  if (!h->exact_sum) {
+    hipLaunchKernelGGL((column_chain_kernel<T, MAGNITUDE>), dim3((h->K + 7) / 8), dim3(256), 0, h->stream, src, pitch, h->K, h->V, h->beta, out);
+    return;
+  }
+  SumParams sp{};
+  sp.src = src; sp.pref = h->d_sum_pref; sp.fn = h->d_sum_fn; sp.out = out; sp.beta = h->beta;
+  sp.pitch = pitch; sp.K = h->K; sp.V = h->V; sp.nseg = h->sum_nseg;
+  const dim3 rows((unsigned)h->sum_nseg, (unsigned)((h->K + kSumBlock - 1) / kSumBlock));
+  hipLaunchKernelGGL((sum_seg_kernel<T, MAGNITUDE>), rows, dim3(kSumBlock), 0, h->stream, sp);
+  hipLaunchKernelGGL(sum_prefix_kernel, dim3((unsigned)h->K), dim3(64), 0, h->stream, sp);
+  hipLaunchKernelGGL((sum_segfn_kernel<T, MAGNITUDE>), rows, dim3(kSumBlock), 0, h->stream, sp);
+  hipLaunchKernelGGL((sum_walk_kernel<T, MAGNITUDE>), dim3((unsigned)h->K), dim3(64), 0, h->stream, sp);
+}
+
 int launch_magnitude(ggs_handle *h) {
-  hipLaunchKernelGGL((column_chain_kernel<int32_t, true>), dim3((h->K + 7) / 8), dim3(256), 0, h->stream, h->d_n_wk, h->K, h->K, h->V, h->beta,
-                     h->d_mag);
+  launch_column_sum<int32_t, true>(h, h->d_n_wk, h->K, h->d_mag);
   HIP_TRY(h, hipMemsetAsync(h->d_n_k, 0, sizeof(int32_t) * (size_t)h->K, h->stream));
   hipLaunchKernelGGL(topic_totals_kernel, dim3(grid_for((int64_t)h->K * h->V, 256, 16)), dim3(256), (size_t)h->K * sizeof(int32_t), h->stream, h->d_n_wk,
                      h->K, h->V, h->d_n_k);
@@ -170,7 +191,7 @@ int launch_phi(ggs_handle *h, bool initial, bool accumulate_mean) {
   gp.initial = initial ? 1 : 0;
   const int64_t kv = (int64_t)K * V;
   hipLaunchKernelGGL(phi_gamma_kernel, dim3(grid_for(kv, 256, 2)), dim3(256), 0, h->stream, gp);
-  hipLaunchKernelGGL((column_chain_kernel<double, false>), dim3((K + 7) / 8), dim3(256), 0, h->stream, h->d_phiT, h->Kp, K, V, 0.0, h->d_tot);
+  launch_column_sum<double, false>(h, h->d_phiT, h->Kp, h->d_tot);
   hipLaunchKernelGGL(phi_normalise_kernel, dim3(grid_for(kv, 256, 2)), dim3(256), 0, h->stream, h->d_phiT, h->d_tot, K, h->Kp, V,
                      accumulate_mean ? h->d_phi_mean : nullptr);
   HIP_TRY(h, hipGetLastError());
@@ -445,6 +466,11 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       (rc = dev_alloc(h, &h->d_n_k, h->K)) || (rc = dev_alloc(h, &h->d_status, 4)))
     return bail(rc);
   if ((h->flags & GGS_FLAG_SAVE_PHI_MEAN) && (rc = dev_alloc(h, &h->d_phi_mean, kv))) return bail(rc);
+  if (const char *e = std::getenv("GGS_DEBUG_CHAIN")) h->exact_sum = std::atoi(e) == 0;
+  h->sum_nseg = (h->V + kSumSegRows - 1) / kSumSegRows;
+  if (h->exact_sum && ((rc = dev_alloc(h, &h->d_sum_pref, ((size_t)h->sum_nseg + 1) * h->K)) ||
+                       (rc = dev_alloc(h, &h->d_sum_fn, (size_t)h->sum_nseg * h->K * 4))))
+    return bail(rc);
   if (hipMemcpy(h->d_alpha, h->alpha.data(), sizeof(double) * h->K, hipMemcpyHostToDevice) != hipSuccess ||
       hipMemset(h->d_phiT, 0, sizeof(double) * ((size_t)h->V * h->Kp + kPhiTailPadBytes / 8)) != hipSuccess ||
       hipMemset(h->d_n_wk, 0, sizeof(int32_t) * kv) != hipSuccess ||
@@ -475,7 +501,7 @@ void ggs_destroy(ggs_handle *h) {
   (void)hipDeviceSynchronize();
   void *bufs[] = {h->d_doc_ptr, h->d_chunk_start, h->d_tok, h->d_z, h->d_chunk_doc, h->d_chunk_len, h->d_alpha, h->d_theta, h->d_theta_next,
                   h->d_phiT, h->d_mag, h->d_tot, h->d_phi_mean, h->d_n_wk, h->d_n_k, h->d_perm, h->d_inv_perm, h->d_zw, h->d_seg_word, h->d_seg_begin,
-                  h->d_status, h->d_scratch};
+                  h->d_status, h->d_scratch, h->d_sum_pref, h->d_sum_fn};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (h->ev.ok)
@@ -849,6 +875,29 @@ int ggs_debug_draw(int32_t device_id, int32_t kind, uint64_t seed, uint32_t iter
   if (hipMemcpy(out, dou, n * 8, hipMemcpyDeviceToHost) != hipSuccess || hipMemcpy(&st, dst, 4, hipMemcpyDeviceToHost) != hipSuccess) return GGS_ERR_HIP;
   if (status) *status = (int32_t)st;
   return GGS_OK;
+}
+
+int ggs_debug_column_sum(int32_t device_id, int32_t V, int32_t K, const double *x, const int32_t *counts, double beta, double *out) {
+  if (V <= 0 || K <= 0 || (!x == !counts) || !out || hipSetDevice(device_id) != hipSuccess) return GGS_ERR_BAD_ARG;
+  TmpDev t;
+  const size_t kv = (size_t)V * K;
+  ggs_handle tmp;                                     // only the fields launch_column_sum reads
+  tmp.K = K; tmp.V = V; tmp.beta = beta; tmp.stream = nullptr; tmp.exact_sum = true;
+  tmp.sum_nseg = (V + kSumSegRows - 1) / kSumSegRows;
+  tmp.d_sum_pref = static_cast<double *>(t.get(((size_t)tmp.sum_nseg + 1) * K * 8));
+  tmp.d_sum_fn = static_cast<double *>(t.get((size_t)tmp.sum_nseg * K * 32));
+  void *dsrc = t.get(kv * (x ? 8 : 4));
+  auto *dou = static_cast<double *>(t.get((size_t)K * 8));
+  int rc = GGS_OK;
+  if (!tmp.d_sum_pref || !tmp.d_sum_fn || !dsrc || !dou) rc = GGS_ERR_HIP;
+  else if (hipMemcpy(dsrc, x ? (const void *)x : (const void *)counts, kv * (x ? 8 : 4), hipMemcpyHostToDevice) != hipSuccess) rc = GGS_ERR_HIP;
+  else {
+    if (x) launch_column_sum<double, false>(&tmp, static_cast<const double *>(dsrc), K, dou);
+    else launch_column_sum<int32_t, true>(&tmp, static_cast<const int32_t *>(dsrc), K, dou);
+    if (hipGetLastError() != hipSuccess || hipMemcpy(out, dou, (size_t)K * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = GGS_ERR_HIP;
+  }
+  tmp.d_sum_pref = nullptr; tmp.d_sum_fn = nullptr;   // owned by t
+  return rc;
 }
 
 }  // extern "C"

@@ -1,0 +1,211 @@
+// ggs_exact_sum.hpp -- the two V-long normalisers of the Phi draw, bit-exact and parallel.
+//
+// Java adds V doubles per topic in index order: the Dirichlet(double[]) magnitude
+// sum_v (beta + n_kv) (MALLET Dirichlet constructor, used at GGS:190) and the sum of the
+// gamma draws (ParallelDirichlet.java:53-57).  Each is ONE dependent rounding chain per topic --
+// 0.28 ms at V = 50k when walked element by element, whatever the hardware.  But all addends
+// are >= 0, so the running sum s only grows, and while s stays inside one binade
+// [2^e, 2^(e+1)) its ulp u = 2^(e-52) is constant and
+//
+//     fl(s + x) = s + R_u(x),   R_u(x) = x rounded to the nearest multiple of u,
+//
+// independent of s except when x mod u == u/2 exactly (a tie: then the result is the EVEN
+// multiple).  Inside a binade the chain is therefore integer arithmetic on quantised addends,
+// which any number of lanes can add up in any order.  Per topic:
+//
+//   sum_seg      plain (order-free) sums of 64-row segments                 -> a guess only
+//   sum_prefix   exclusive prefix of those                                  -> a guess only
+//   sum_segfn    per segment, assuming the binade e of the guessed start:  D1 = u * sum of R_u(x)
+//                up to the first tie (floor part of the tie included), H = u/2 if there was a
+//                tie, D2 = u * sum after it (later ties resolved by parity: the sum is even
+//                right after a tie).  Then  s_out = ((s_in + D1) + H) + D2  with every add exact
+//                except the "+ H", which the hardware rounds to even exactly as the chain would.
+//   sum_walk     one wave per topic walks the segments.  A step is ACCEPTED only if s_in and
+//                s_out both lie in binade e -- s is monotone, so then every intermediate sum did
+//                too and the assumption held; the guess never decides a result.  Anything else
+//                (binade crossings, the start at s = 0, wrong guesses, NaN) is re-done the Java
+//                way, element by element, from the raw data.  64 consecutive clean tie-free
+//                segments of one binade collapse into a single exact add (wave reduction).
+//
+// About ten segments of 782 take the element-by-element path at V = 50k (s doubles ~25 times,
+// mostly inside the first segment).
+#pragma once
+#include "ggs_device_math.hpp"
+
+namespace ggs {
+
+constexpr int kSumSegRows = 64;        // rows per segment == lanes per wave (sum_walk loads a segment with one load per lane)
+constexpr int kSumBlock = 128;         // topics per workgroup in the row-streaming kernels
+constexpr double kSumDirty = -5000.0;  // fn[3] marker (binades are -900..1000): no segment function, walk the raw elements
+constexpr double kSumPastEnd = -6000.0;
+
+struct SumParams {
+  const void *src;        // int32 [V][pitch] counts (MAGNITUDE) or fp64 [V][pitch] gamma draws
+  double *pref;           // [nseg + 1][K] guessed running sum at each segment start
+  double *fn;             // [nseg][K][4]: D1, H, D2, e (as a double; kSumDirty = none)
+  double *out;            // [K]
+  double beta;
+  int32_t pitch, K, V, nseg;
+};
+
+__device__ __forceinline__ int binade_of(double x) { return ((hi32(x) >> 20) & 0x7ff) - 1023; }   // 1024 for NaN/inf, -1023 for 0
+
+template <typename T, bool MAGNITUDE>
+__device__ __forceinline__ double sum_elem(const T *src, size_t idx, double beta) {
+  return MAGNITUDE ? (beta + (double)src[idx]) : (double)src[idx];   // GGS:188: beta + count, one rounding
+}
+
+template <typename T, bool MAGNITUDE>
+__global__ __launch_bounds__(kSumBlock) void sum_seg_kernel(SumParams p) {
+  const int k = blockIdx.y * kSumBlock + threadIdx.x;
+  if (k >= p.K) return;
+  const int i = blockIdx.x;
+  const T *src = static_cast<const T *>(p.src);
+  const int v0 = i * kSumSegRows;
+  double a = 0.0;
+  // 16 loads in flight; rows past V are clamped and contribute + 0.0
+#pragma unroll 1
+  for (int r0 = 0; r0 < kSumSegRows; r0 += 16) {
+    double xs[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xs[j] = sum_elem<T, MAGNITUDE>(src, (size_t)min(v0 + r0 + j, p.V - 1) * p.pitch + k, p.beta);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) a += (v0 + r0 + j < p.V) ? xs[j] : 0.0;
+  }
+  p.pref[(size_t)i * p.K + k] = a;
+}
+
+// one wave per topic: exclusive prefix over the segment sums, in place; pref[nseg][k] = total
+__global__ __launch_bounds__(64) void sum_prefix_kernel(SumParams p) {
+  const int k = blockIdx.x, lane = threadIdx.x;
+  const int per = (p.nseg + 63) / 64;
+  const int i0 = min(lane * per, p.nseg), i1 = min(i0 + per, p.nseg);
+  double mine = 0.0;
+  for (int i = i0; i < i1; ++i) mine += p.pref[(size_t)i * p.K + k];
+  double incl = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const double o = __shfl_up(incl, d);
+    if (lane >= d) incl += o;
+  }
+  double run = incl - mine;
+  for (int i = i0; i < i1; ++i) {
+    const double t = p.pref[(size_t)i * p.K + k];
+    p.pref[(size_t)i * p.K + k] = run;
+    run += t;
+  }
+  if (lane == 63) p.pref[(size_t)p.nseg * p.K + k] = incl;
+}
+
+template <typename T, bool MAGNITUDE>
+__global__ __launch_bounds__(kSumBlock) void sum_segfn_kernel(SumParams p) {
+  const int k = blockIdx.y * kSumBlock + threadIdx.x;
+  if (k >= p.K) return;
+  const int i = blockIdx.x;
+  const T *src = static_cast<const T *>(p.src);
+  double *fn = p.fn + ((size_t)i * p.K + k) * 4;
+  const double s0 = p.pref[(size_t)i * p.K + k], s1 = p.pref[(size_t)(i + 1) * p.K + k];
+  const int e = binade_of(s0);
+  // the guess must leave a margin on both sides of the binade, or the step would mostly be rejected
+  const bool plausible = s0 > 0.0 && e >= -900 && e <= 1000 && binade_of(s0 * (1.0 - 1e-9)) == e && binade_of(s1 * (1.0 + 1e-9)) == e;
+  if (!plausible) { fn[3] = kSumDirty; return; }
+  const double u = mk((1023 + e - 52) << 20, 0), scale = mk((1023 + 52 - e) << 20, 0);   // 2^(e-52), 2^(52-e)
+  const int v0 = i * kSumSegRows;
+  double pre = 0.0, post = 0.0;      // integer-valued doubles (< 2^53 whenever the step ends up accepted)
+  bool tie = false;
+  int32_t bad = 0;                   // sign bit of any addend: the monotonicity argument needs x >= 0
+#pragma unroll 1
+  for (int r0 = 0; r0 < kSumSegRows; r0 += 16) {
+    double xs[16];                   // 16 loads in flight; rows past V are clamped and count as + 0.0
+#pragma unroll
+    for (int j = 0; j < 16; ++j) xs[j] = sum_elem<T, MAGNITUDE>(src, (size_t)min(v0 + r0 + j, p.V - 1) * p.pitch + k, p.beta);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const double x = (v0 + r0 + j < p.V) ? xs[j] : 0.0;
+      bad |= hi32(x);
+      const double y = x * scale;    // exact (power of two): x / u
+      const double f = floor(y);
+      const double r = y - f;        // exact
+      if (r == 0.5) {
+        if (!tie) {                  // the first tie: hardware rounds "+ u/2" to even in the walk
+          tie = true;
+          pre += f;
+        } else {                     // s is even right after a tie, so parity(s/u) == parity(post) from here on
+          const double z = post + f, h = z * 0.5;
+          post = z + (h != floor(h) ? 1.0 : 0.0);
+        }
+      } else {
+        const double q = r > 0.5 ? f + 1.0 : f;
+        if (tie) post += q; else pre += q;
+      }
+    }
+  }
+  if (bad < 0) { fn[3] = kSumDirty; return; }
+  fn[0] = pre * u;
+  fn[1] = tie ? 0.5 * u : 0.0;
+  fn[2] = post * u;
+  fn[3] = (double)e;
+}
+
+template <typename T, bool MAGNITUDE>
+__global__ __launch_bounds__(64) void sum_walk_kernel(SumParams p) {
+  __shared__ double tup[64][4];
+  __shared__ double raw[64][kSumSegRows];
+  const int k = blockIdx.x, lane = threadIdx.x;
+  const T *src = static_cast<const T *>(p.src);
+  const int groups = (p.nseg + 63) / 64;
+  double s = 0.0;                                           // identical in every lane
+  for (int g = 0; g < groups; ++g) {
+    const int i = g * 64 + lane;
+    const bool valid = i < p.nseg;
+    double d1 = 0.0, hh = 0.0, d2 = 0.0, ee = kSumDirty;
+    if (valid) {
+      const double *fn = p.fn + ((size_t)i * p.K + k) * 4;
+      d1 = fn[0]; hh = fn[1]; d2 = fn[2]; ee = fn[3];
+    }
+    const bool dirty = valid && ee == kSumDirty;
+    const double e0 = __shfl(ee, 0);
+    // 64 clean, tie-free segments of one binade: their D1 are multiples of the same u, any order adds them exactly
+    if (__all(!valid || (!dirty && hh == 0.0 && ee == e0)) && e0 != kSumDirty) {
+      double tot = valid ? d1 : 0.0;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
+      const double t = s + tot;
+      const int e = (int)e0;
+      if (binade_of(s) == e && binade_of(t) == e) { s = t; continue; }
+    }
+    // segment by segment
+    __syncthreads();                                        // previous group's LDS reads are done
+    tup[lane][0] = d1; tup[lane][1] = hh; tup[lane][2] = d2; tup[lane][3] = valid ? ee : kSumPastEnd;
+    unsigned long long pre = __ballot(dirty);               // segments known to need their raw rows: fetch them together
+    for (unsigned long long m = pre; m; m &= m - 1) {
+      const int j = __ffsll((long long)m) - 1;
+      const int v = (g * 64 + j) * kSumSegRows + lane;
+      raw[j][lane] = v < p.V ? sum_elem<T, MAGNITUDE>(src, (size_t)v * p.pitch + k, p.beta) : 0.0;   // + 0.0 leaves s unchanged
+    }
+    __syncthreads();
+    for (int j = 0; j < 64; ++j) {
+      const double te = tup[j][3];
+      if (te == kSumPastEnd) break;                                // past the last segment
+      bool ok = false;
+      if (te != kSumDirty) {
+        const int e = (int)te;
+        const double t = ((s + tup[j][0]) + tup[j][1]) + tup[j][2];
+        ok = binade_of(s) == e && binade_of(t) == e;
+        if (ok) s = t;
+      }
+      if (!ok) {                                            // wave-uniform
+        if (!((pre >> j) & 1ull)) {                         // a rejected guess: its rows were not fetched above
+          const int v = (g * 64 + j) * kSumSegRows + lane;
+          raw[j][lane] = v < p.V ? sum_elem<T, MAGNITUDE>(src, (size_t)v * p.pitch + k, p.beta) : 0.0;
+          __syncthreads();
+        }
+#pragma unroll 16
+        for (int r = 0; r < kSumSegRows; ++r) s += raw[j][r];
+      }
+    }
+  }
+  if (lane == 0) p.out[k] = s;
+}
+
+}  // namespace ggs

@@ -28,6 +28,11 @@
 #pragma once
 #include "ggs_z_kernel.hpp"
 
+// timing-only experiments, compile time (results are wrong on purpose): 1 no DMA, 2 no walk, 4 no score pass
+#ifndef GGS_ABL
+#define GGS_ABL 0
+#endif
+
 namespace ggs {
 
 constexpr int kSliceTopics = 16;
@@ -73,6 +78,7 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
     }
   };
   auto issue_slice = [&](const int s, const int slot, const unsigned char *const (&ra)[8]) {
+    if (GGS_ABL & 1) return;
 #pragma unroll
     for (int m = 0; m < 8; ++m)
       __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(ra[m] + s * 128), (lds_void_t *)(smem + slot * kSliceBytes + m * 1024), 16, 0, 0);
@@ -119,6 +125,11 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
 
     double sc[KMAX];
     double sum = 0.0;
+    if (GGS_ABL & 4) {
+      sum = 1.0;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k) sc[k] = 0.01;
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int cur = (g + s) & (kRingSlots - 1);
@@ -130,9 +141,10 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
       // issued after slice s, "at most 8*kAhead outstanding" means slice s has landed; at the tail
       // of the last chunk fewer slices follow.  One wave per workgroup: no hardware barrier, only
       // a compiler fence so that no LDS read moves above the wait.
-      if (has1 || s + kAhead < NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * kAhead) : "memory");
+      if (GGS_ABL & 1) {}
+      else if (has1 || s + kAhead < NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * kAhead) : "memory");
       else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NS - 1 - s)) : "memory");
-      if (lane < len0) {
+      if ((GGS_ABL & 4) ? false : lane < len0) {
         const unsigned char *rb = my_row + cur * kSliceBytes;
         const unsigned char *tb = thb + s * kSliceTopics * 8;
         // unit u = topics (k, k+1).  All 16 LDS reads of the slice are issued up front (they return
@@ -181,7 +193,7 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
       bool live = true;
 #pragma unroll
       for (int kb = 0; kb < KMAX; kb += 16) {
-        if (live) {                                                // wave-uniform
+        if (live && !(GGS_ABL & 2)) {                              // wave-uniform
 #pragma unroll
           for (int j = 0; j < 16; ++j)
             if (kb + j < KMAX) { cnt += (sample > 0.0); sample -= sc[kb + j]; }

@@ -229,3 +229,23 @@ def debug_draw(kind, seed, iteration, purpose, elem0, n=None, shape=None, device
     if rc:
         raise GGSError(rc, "ggs_debug_draw")
     return out, st.value
+
+
+def debug_column_sum(x=None, counts=None, beta=0.0, device_id=0):
+    """Column sums in index order (Java's sequential rounding) of x [V][K], or of beta + counts [V][K]."""
+    L = _lib.load()
+    if (x is None) == (counts is None):
+        raise ValueError("exactly one of x / counts")
+    if x is not None:
+        x = np.ascontiguousarray(x, np.float64)
+        V, K = x.shape
+        xp, cp = _dp(x), None
+    else:
+        counts = np.ascontiguousarray(counts, np.int32)
+        V, K = counts.shape
+        xp, cp = None, _ip(counts)
+    out = np.empty(K, np.float64)
+    rc = L.ggs_debug_column_sum(device_id, V, K, xp, cp, float(beta), _dp(out))
+    if rc:
+        raise GGSError(rc, "ggs_debug_column_sum")
+    return out

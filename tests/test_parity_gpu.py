@@ -389,3 +389,53 @@ def test_sharded_orchestration_over_rccl_single_rank(native, oracle):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------- the exact parallel column sums
+def _sequential_column_sum(x):
+    s = np.zeros(x.shape[1], np.float64)
+    for row in x:                       # one IEEE add per element, rows in index order == the Java loop
+        s = s + row
+    return s
+
+
+@pytest.mark.gpu
+def test_exact_parallel_column_sum_adversarial(native):
+    """ggs_exact_sum.hpp against the plain sequential sum: sparse gamma columns, exact rounding ties,
+    binade crossings anywhere, huge dynamic range, zeros, non-finite values, ragged V."""
+    rng = np.random.default_rng(11)
+    cases = []
+    cases.append(("sparse gammas", rng.gamma(0.01 + (rng.random((50000, 7)) < 0.1) * rng.integers(1, 30, (50000, 7)))))
+    cases.append(("tiny gammas only", rng.gamma(0.01, size=(20000, 5))))
+    x = rng.integers(0, 8, (5000, 64)) * 2.0 ** -40 + (rng.random((5000, 64)) < 0.2) * rng.integers(0, 3, (5000, 64)) * 2.0 ** -39
+    x[0] = 2.0 ** 13 + rng.integers(0, 1000, 64) * 2.0 ** -39           # s in [2^13, 2^14): odd multiples of 2^-40 are exact ties
+    x[rng.integers(1, 5000, 20), rng.integers(0, 64, 20)] = 2.0 ** 13   # and a few forced crossings
+    cases.append(("ties", x))
+    cases.append(("forty binades", np.exp(rng.normal(0, 30, (9000, 9)))))
+    x = rng.gamma(0.5, size=(3000, 6))
+    x[:, 0] = 0.0
+    x[1234, 1] = np.nan
+    x[77, 2] = np.inf
+    x[:, 3] = 4.9e-324
+    cases.append(("zeros, NaN, inf, denormals", x))
+    for V in (1, 63, 64, 65, 129, 4097):
+        cases.append(("V=%d" % V, rng.gamma(0.3, size=(V, 3))))
+    cases.append(("K=200", rng.gamma(0.05, size=(3000, 200))))
+    for tag, x in cases:
+        assert_bit_equal(native.debug_column_sum(x=x), _sequential_column_sum(x), "column sum: " + tag)
+    for beta in (0.01, 0.5, 7.0):
+        n = ((rng.random((50000, 5)) < 0.05) * rng.integers(1, 400, (50000, 5))).astype(np.int32)
+        want = _sequential_column_sum(beta + n.astype(np.float64))
+        assert_bit_equal(native.debug_column_sum(counts=n, beta=beta), want, "magnitude beta=%g" % beta)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("beta", [0.01, 0.5])
+def test_long_vocabulary(native, oracle, beta):
+    """V = 30000 (469 segments, 8 groups per topic in the normalisers) with few tokens: sparse n_wk, mostly tiny gammas."""
+    c = random_corpus(400, 30000, 120, seed=5)
+    g, o = make_pair(native, oracle, c, 6, 0.1, beta, 1234, flags=native.FLAG_PARANOID, zseed=9)
+    compare_state(g, o, "long vocabulary init", theta=False)
+    g.sweep(3)
+    o.sweep(3)
+    compare_state(g, o, "long vocabulary")

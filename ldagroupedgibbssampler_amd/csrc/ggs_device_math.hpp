@@ -302,12 +302,14 @@ __device__ __forceinline__ double prgamma(DrawStream &r, double alpha) {
   }
 }
 // ParallelRandoms.java:60-70 with beta = 1, lambda = 0
+// One prgamma instance for both branches: a wave usually mixes shapes below and above 1 (sparse
+// counts), and two inlined copies would run one after the other.
 __device__ __forceinline__ double rgamma(DrawStream &r, double alpha) {
-  if (alpha < 1) {
-    const double u = r.next_double();
-    return prgamma(r, 1 + alpha) * strict_pow(u, 1.0 / alpha);
-  }
-  return prgamma(r, alpha);
+  const bool boost = alpha < 1;
+  double u = 1.0;
+  if (boost) u = r.next_double();                    // drawn BEFORE the Marsaglia-Tsang loop, as at ParallelRandoms.java:62
+  const double g = prgamma(r, boost ? 1 + alpha : alpha);
+  return boost ? g * strict_pow(u, 1.0 / alpha) : g;
 }
 
 }  // namespace ggs

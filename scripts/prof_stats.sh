@@ -9,5 +9,9 @@ rm -rf $out && mkdir -p $out
 cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $out -- python3 bench.py --no-cpu-baseline "$@" > $out/bench.log 2>&1
 find $out -name "*kernel_stats.csv" | head -1 | xargs -I{} cp {} $out/kernel_stats.csv
-column -s, -t < $out/kernel_stats.csv | cut -c1-200 | head -30
+python3 - $out/kernel_stats.csv <<PY
+import csv, sys
+for r in list(csv.DictReader(open(sys.argv[1])))[:24]:
+    print("%-66s calls %5s avg %9.1f us total %8.2f ms %6s%%" % (r["Name"][:66], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
+PY
 tail -1 $out/bench.log | cut -c1-400

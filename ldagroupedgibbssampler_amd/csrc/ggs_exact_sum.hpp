@@ -147,62 +147,123 @@ __global__ __launch_bounds__(kSumBlock) void sum_segfn_kernel(SumParams p) {
   fn[3] = (double)e;
 }
 
+// One wave per topic.  Segments are taken 1024 at a time (16 groups of 64, lane j of a group owns
+// segment j): all their segment functions and the raw rows of every segment already known to need
+// the element-by-element path are fetched up front, so memory latency is paid once, not per step.
+// Within a group the walk advances by RUNS: an inclusive wave scan of D1 over the consecutive clean,
+// tie-free segments of one binade gives every candidate s_out at once (sums of multiples of u below
+// 2^(e+1) are exact in any order; a partial sum that reached 2^(e+1) may have rounded, but only
+// upward of 2^(e+1), so its binade test still fails); the longest prefix whose s_out stays in the
+// binade is accepted in one step.  Whatever stops a run -- a tie, a dirty segment, a crossing -- is
+// then taken on its own.
+constexpr int kWalkSuper = 1024, kWalkRawSlots = 48;
+
 template <typename T, bool MAGNITUDE>
 __global__ __launch_bounds__(64) void sum_walk_kernel(SumParams p) {
-  __shared__ double tup[64][4];
-  __shared__ double raw[64][kSumSegRows];
+  __shared__ double tup[kWalkSuper][4];                     // 32 KiB
+  __shared__ double raw[kWalkRawSlots][kSumSegRows];        // 24 KiB
+  __shared__ int16_t dirty_list[kWalkSuper];
   const int k = blockIdx.x, lane = threadIdx.x;
   const T *src = static_cast<const T *>(p.src);
-  const int groups = (p.nseg + 63) / 64;
+  const unsigned long long lt_mask = (1ull << lane) - 1ull;
   double s = 0.0;                                           // identical in every lane
-  for (int g = 0; g < groups; ++g) {
-    const int i = g * 64 + lane;
-    const bool valid = i < p.nseg;
-    double d1 = 0.0, hh = 0.0, d2 = 0.0, ee = kSumDirty;
-    if (valid) {
-      const double *fn = p.fn + ((size_t)i * p.K + k) * 4;
-      d1 = fn[0]; hh = fn[1]; d2 = fn[2]; ee = fn[3];
-    }
-    const bool dirty = valid && ee == kSumDirty;
-    const double e0 = __shfl(ee, 0);
-    // 64 clean, tie-free segments of one binade: their D1 are multiples of the same u, any order adds them exactly
-    if (__all(!valid || (!dirty && hh == 0.0 && ee == e0)) && e0 != kSumDirty) {
-      double tot = valid ? d1 : 0.0;
+  auto load_row = [&](int seg) {                            // this lane's element of segment seg (+ 0.0 past V)
+    const int v = seg * kSumSegRows + lane;
+    const double x = sum_elem<T, MAGNITUDE>(src, (size_t)min(v, p.V - 1) * p.pitch + k, p.beta);
+    return v < p.V ? x : 0.0;
+  };
+  for (int sg = 0; sg < p.nseg; sg += kWalkSuper) {
+    const int nhere = min(kWalkSuper, p.nseg - sg), groups = (nhere + 63) / 64;
+    __syncthreads();
+    {                                                       // all segment functions of the super-group -> LDS
+      double t[16][4];
 #pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d);
-      const double t = s + tot;
-      const int e = (int)e0;
-      if (binade_of(s) == e && binade_of(t) == e) { s = t; continue; }
-    }
-    // segment by segment
-    __syncthreads();                                        // previous group's LDS reads are done
-    tup[lane][0] = d1; tup[lane][1] = hh; tup[lane][2] = d2; tup[lane][3] = valid ? ee : kSumPastEnd;
-    unsigned long long pre = __ballot(dirty);               // segments known to need their raw rows: fetch them together
-    for (unsigned long long m = pre; m; m &= m - 1) {
-      const int j = __ffsll((long long)m) - 1;
-      const int v = (g * 64 + j) * kSumSegRows + lane;
-      raw[j][lane] = v < p.V ? sum_elem<T, MAGNITUDE>(src, (size_t)v * p.pitch + k, p.beta) : 0.0;   // + 0.0 leaves s unchanged
+      for (int g = 0; g < 16; ++g) {
+        const int i = min(sg + g * 64 + lane, p.nseg - 1);
+        const double *fn = p.fn + ((size_t)i * p.K + k) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) t[g][c] = fn[c];
+      }
+#pragma unroll
+      for (int g = 0; g < 16; ++g) {
+        const bool valid = g * 64 + lane < nhere;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tup[g * 64 + lane][c] = t[g][c];
+        tup[g * 64 + lane][3] = valid ? t[g][3] : kSumPastEnd;
+      }
     }
     __syncthreads();
-    for (int j = 0; j < 64; ++j) {
-      const double te = tup[j][3];
-      if (te == kSumPastEnd) break;                                // past the last segment
-      bool ok = false;
-      if (te != kSumDirty) {
-        const int e = (int)te;
-        const double t = ((s + tup[j][0]) + tup[j][1]) + tup[j][2];
-        ok = binade_of(s) == e && binade_of(t) == e;
-        if (ok) s = t;
-      }
-      if (!ok) {                                            // wave-uniform
-        if (!((pre >> j) & 1ull)) {                         // a rejected guess: its rows were not fetched above
-          const int v = (g * 64 + j) * kSumSegRows + lane;
-          raw[j][lane] = v < p.V ? sum_elem<T, MAGNITUDE>(src, (size_t)v * p.pitch + k, p.beta) : 0.0;
-          __syncthreads();
+    int ndirty = 0;                                         // list of the predicted-dirty segments, in order
+    for (int g = 0; g < groups; ++g) {
+      const bool dirty = tup[g * 64 + lane][3] == kSumDirty;
+      const unsigned long long m = __ballot(dirty);
+      if (dirty) dirty_list[ndirty + __popcll(m & lt_mask)] = (int16_t)(g * 64 + lane);
+      ndirty += __popcll(m);
+    }
+    __syncthreads();
+    const int nslots = min(ndirty, kWalkRawSlots);
+    for (int b = 0; b < nslots; b += 8) {                   // their raw rows, 8 loads in flight
+      double x[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) x[j] = load_row(sg + dirty_list[min(b + j, nslots - 1)]);
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (b + j < nslots) raw[b + j][lane] = x[j];
+    }
+    __syncthreads();
+
+    int slot_base = 0;                                      // dirty segments before the current group
+    for (int g = 0; g < groups; ++g) {
+      const double d1 = tup[g * 64 + lane][0], hh = tup[g * 64 + lane][1], d2 = tup[g * 64 + lane][2], ee = tup[g * 64 + lane][3];
+      const bool valid = ee != kSumPastEnd, dirty = ee == kSumDirty;
+      const unsigned long long dirty_mask = __ballot(dirty);
+      unsigned long long remaining = __ballot(valid);
+      while (remaining) {
+        const int j0 = __ffsll((long long)remaining) - 1;
+        const double e0 = __shfl(ee, j0);
+        if (e0 != kSumDirty && binade_of(s) == (int)e0) {
+          // the run of clean tie-free segments of binade e0 starting at j0
+          const unsigned long long good = __ballot(valid && ee == e0 && hh == 0.0) >> j0;
+          const int run = good == ~0ull ? 64 - j0 : __ffsll((long long)~good) - 1;
+          if (run > 0) {
+            double inc = (lane >= j0 && lane < j0 + run) ? d1 : 0.0;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+              const double o = __shfl_up(inc, d);
+              if (lane >= d) inc += o;
+            }
+            const double t = s + inc;
+            const unsigned long long okm = __ballot(lane >= j0 && lane < j0 + run && binade_of(t) == (int)e0) >> j0;
+            const int acc = okm == ~0ull ? 64 - j0 : __ffsll((long long)~okm) - 1;   // leading accepted segments (s_out is monotone)
+            if (acc > 0) {
+              s = __shfl(t, j0 + acc - 1);
+              remaining &= ~(((acc >= 64) ? ~0ull : ((1ull << acc) - 1ull)) << j0);
+              continue;
+            }
+          }
         }
+        // segment j0 on its own
+        bool ok = false;
+        if (e0 != kSumDirty) {
+          const int e = (int)e0;
+          const double t = ((s + __shfl(d1, j0)) + __shfl(hh, j0)) + __shfl(d2, j0);
+          ok = binade_of(s) == e && binade_of(t) == e;
+          if (ok) s = t;
+        }
+        if (!ok) {
+          const int slot = slot_base + __popcll(dirty_mask & ((1ull << j0) - 1ull));
+          if ((dirty_mask >> j0) & 1ull && slot < kWalkRawSlots) {
 #pragma unroll 16
-        for (int r = 0; r < kSumSegRows; ++r) s += raw[j][r];
+            for (int r = 0; r < kSumSegRows; ++r) s += raw[slot][r];
+          } else {                                          // a rejected guess, or more dirty segments than slots: fetch now
+            const double x = load_row(sg + g * 64 + j0);
+#pragma unroll 16
+            for (int r = 0; r < kSumSegRows; ++r) s += __shfl(x, r);
+          }
+        }
+        remaining &= ~(1ull << j0);
       }
+      slot_base += __popcll(dirty_mask);
     }
   }
   if (lane == 0) p.out[k] = s;

@@ -428,7 +428,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       // 64-token chunks, a 4-slot ring of 16-topic slices + the theta row; one wave per SIMD
       // (the score registers take most of the 512-entry file)
       h->z_tile_tokens = 64;
-      h->z_lds = kRingSlots * kSliceBytes + ((h->K + 7) / 8) * 64;   // ring + theta row zero-padded to KMAX
+      h->z_lds = kRingBase + kRingSlots * kSliceBytes;               // theta row (zero-padded to KMAX) below the ring
       h->z_waves_per_cu = std::min(4, kMaxLdsBytes / alloc_of(h->z_lds));
       if (const char *e = std::getenv("GGS_DEBUG_WPC")) h->z_waves_per_cu = std::max(1, std::atoi(e));
     } else {

@@ -26,6 +26,8 @@
 // finite bytes sit there (word 0's row; the next row's first entries; the zeroed tail pad of
 // phiT): those scores are multiplied by theta = 0 or belong to lanes that store nothing.
 #pragma once
+#include <type_traits>
+
 #include "ggs_z_kernel.hpp"
 
 // timing-only experiments, compile time (results are wrong on purpose): 1 no DMA, 2 no walk, 4 no score pass
@@ -42,9 +44,25 @@ constexpr int kRingSlots = 4;
 constexpr int kSlicedMaxTopics = 192;     // 384 score registers (VGPR + AGPR) + working set < 512
 constexpr int kPhiTailPadBytes = 256;     // zeroed bytes after the last phiT row (see above)
 
+constexpr int kRingBase = 2048;           // ring offset inside the wave's LDS: the theta row (<= 1536 B) sits below it
+
+template <int S, int N, class F>
+__device__ __forceinline__ void static_for(F &&f) {
+  if constexpr (S < N) {
+    f(std::integral_constant<int, S>{});
+    static_for<S + 1, N>(f);
+  }
+}
+
 // KMAX = K rounded up to a multiple of 8: the size of the score register file.  Topics
 // K..KMAX-1 are scored too, with theta = 0 (the LDS theta row is zero-padded) against finite
 // phi bytes, so they add +0.0 to the sum and subtract 0.0 in the walk: no per-topic guards.
+//
+// Issue economy (one wave per SIMD: every VALU instruction costs ~8 cycles whatever it does):
+// the slice index is a compile-time constant, so a DMA's slice offset is the instruction's
+// immediate -- which the hardware adds to the LDS destination as well as to the global source,
+// hence the "- s*128" on the destination and the ring starting at kRingBase, not 0; the ring
+// slot is wave-uniform and goes to M0 through scalar registers.
 template <int KMAX>
 __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
   constexpr int NS = (KMAX + kSliceTopics - 1) / kSliceTopics;     // slices per chunk
@@ -53,7 +71,8 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
   const int K = p.K, Kp = p.Kp;
-  unsigned char *thb = smem + kRingSlots * kSliceBytes;            // theta row, KMAX doubles
+  unsigned char *thb = smem;                                       // theta row, KMAX doubles
+  unsigned char *ring = smem + kRingBase;
   const unsigned char *phib = reinterpret_cast<const unsigned char *>(p.phiT);
   const size_t rowbytes = (size_t)Kp * 8;
   const const_i64_t *cstart = (const const_i64_t *)p.chunk_start;
@@ -64,7 +83,7 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
 
   const int lrow = lane >> 3, lslot = lane & 7;
   // byte offset of unit u of this lane's row inside a ring slot: lane*128 + ((u + lane/2) & 7)*16
-  const unsigned char *my_row = smem + lane * 128;
+  const unsigned char *my_row = ring + lane * 128;
   const int rot = lane >> 1;
 
   // Source addresses of this lane's 8 DMA rows (m = 0..7): row 8m + lrow of the chunk, unit
@@ -77,11 +96,12 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
       ra[m] = phib + (size_t)wm * rowbytes + (size_t)(((lslot - (row >> 1)) & 7) << 4);
     }
   };
-  auto issue_slice = [&](const int s, const int slot, const unsigned char *const (&ra)[8]) {
+  auto issue_slice = [&](auto sc, const int slot, const unsigned char *const (&ra)[8]) {
+    constexpr int s = decltype(sc)::value;
     if (GGS_ABL & 1) return;
 #pragma unroll
     for (int m = 0; m < 8; ++m)
-      __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(ra[m] + s * 128), (lds_void_t *)(smem + slot * kSliceBytes + m * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_cvoid_t *)ra[m], (lds_void_t *)(ring + slot * kSliceBytes + m * 1024 - s * 128), 16, s * 128, 0);
   };
   auto load_theta = [&](const int doc, double (&tv)[NT]) {
     const double *thg = p.theta + (size_t)doc * K;
@@ -113,11 +133,11 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
   row_addresses(w0, ra);
   row_addresses(w1, ran);
   int g = 0;                                                       // ring slot of this chunk's slice 0
-#pragma unroll
-  for (int s = 0; s < kAhead; ++s) issue_slice(s, (g + s) & (kRingSlots - 1), ra);
+  static_for<0, kAhead>([&](auto sc) { issue_slice(sc, decltype(sc)::value & (kRingSlots - 1), ra); });
 
   for (;;) {
     const bool has1 = c + stride < C, has2 = c + 2 * stride < C;
+    g = __builtin_amdgcn_readfirstlane(g);                         // wave-uniform by construction: keep it scalar
     // this chunk's theta row: registers -> LDS (requested two chunks ago)
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -130,13 +150,13 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
 #pragma unroll
       for (int k = 0; k < KMAX; ++k) sc[k] = 0.01;
     }
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
+    static_for<0, NS>([&](auto sidx) {
+      constexpr int s = decltype(sidx)::value;
       const int cur = (g + s) & (kRingSlots - 1);
       const int nxt = (g + s + kAhead) & (kRingSlots - 1);          // freed by the slice scored last step
       // keep kAhead slices in flight: slice s + kAhead of this chunk, or of the next one
-      if (s + kAhead < NS) issue_slice(s + kAhead, nxt, ra);
-      else if (has1) issue_slice(s + kAhead - NS, nxt, ran);
+      if constexpr (s + kAhead < NS) issue_slice(std::integral_constant<int, s + kAhead>{}, nxt, ra);
+      else if (has1) issue_slice(std::integral_constant<int, s + kAhead - NS>{}, nxt, ran);
       // LDS-DMA completion is tracked by vmcnt in issue order.  With kAhead slices (8 DMAs each)
       // issued after slice s, "at most 8*kAhead outstanding" means slice s has landed; at the tail
       // of the last chunk fewer slices follow.  One wave per workgroup: no hardware barrier, only
@@ -158,7 +178,8 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
           }
 #pragma unroll
         for (int u = 0; u < kSliceUnits; ++u) {
-          const int k = s * kSliceTopics + 2 * u;
+          constexpr int k0 = s * kSliceTopics;
+          const int k = k0 + 2 * u;
           if (k + 1 < KMAX) {
             sc[k] = th[u].a * ph[u].a;
             sum += sc[k];
@@ -168,7 +189,7 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
         }
       }
       asm volatile("" ::: "memory");                               // every read of this ring slot is issued before it is refilled
-    }
+    });
     g = (g + NS) & (kRingSlots - 1);                               // ring slot of the next chunk's slice 0
 
     // requests for two chunks ahead: younger than every DMA above, so they are only waited for
@@ -186,22 +207,32 @@ __global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
       const U4 o = philox4x32_10((uint32_t)gtok, (uint32_t)(gtok >> 32), (uint32_t)GGS_PURPOSE_Z << 24, p.iteration,
                                  (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
       const double U = u53(o.x, o.y);
-      double sample = U * sum;
-      // The walk of GGS:108-113 in counting form: scores are >= 0, so once sample <= 0 it stays
-      // <= 0 and newTopic + 1 == #{k : sample before subtracting score[k] was > 0}.
+      // The walk of GGS:108-113, negated and in counting form.  t = -(sample): t_0 = 0 - U*sum and
+      // t_{j+1} = t_j + score[j] round exactly as sample_{j+1} = sample_j - score[j] does (round to
+      // nearest is symmetric), x + (-x) gives +0, and scores are >= +0, so t is never -0 and
+      //     sample_j > 0   <=>   the sign bit of t_j is set.
+      // Scores are >= 0, so once the sign clears it stays clear, and
+      // newTopic + 1 == #{j : sample_j > 0} == number of sign bits collected before each subtraction.
+      // One funnel shift per topic collects them; no compare, no carry add.
+      double t = 0.0 - U * sum;
       int cnt = 0;
       bool live = true;
 #pragma unroll
       for (int kb = 0; kb < KMAX; kb += 16) {
         if (live && !(GGS_ABL & 2)) {                              // wave-uniform
+          uint32_t bits = 0;
 #pragma unroll
           for (int j = 0; j < 16; ++j)
-            if (kb + j < KMAX) { cnt += (sample > 0.0); sample -= sc[kb + j]; }
-          live = __any(sample > 0.0);
+            if (kb + j < KMAX) {
+              bits = __builtin_amdgcn_alignbit(bits, (uint32_t)hi32(t), 31);   // (bits << 1) | sign(t)
+              t += sc[kb + j];
+            }
+          cnt += __popc(bits);
+          live = __any(hi32(t) < 0);
         }
       }
       int new_topic = cnt - 1;
-      if (new_topic < 0 || sample > 0.0) {                         // GGS:116-118 (and the index past K Java would throw on;
+      if (new_topic < 0 || hi32(t) < 0) {                          // GGS:116-118 (and the index past K Java would throw on;
                                                                    // only then can cnt have run past K through the padding)
         atomicOr(p.status, ST_INVALID_TOPIC);
         new_topic = new_topic < 0 ? 0 : K - 1;

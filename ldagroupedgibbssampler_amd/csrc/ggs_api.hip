@@ -51,6 +51,10 @@ struct ggs_handle {
   // device buffers
   int64_t *d_doc_ptr = nullptr, *d_chunk_start = nullptr;
   int32_t *d_tok = nullptr, *d_z = nullptr, *d_chunk_doc = nullptr, *d_chunk_len = nullptr;
+  // sliced z kernel (ggs_z_sliced.hpp): its chunk lists (cold chunks first), the hot-word table's word ids, LDS layout
+  int32_t *d_ct_tok = nullptr, *d_ct_idx = nullptr, *d_ct_ip = nullptr, *d_c_docs = nullptr, *d_hot_words = nullptr;
+  int64_t Cs = 0, Cc = 0;                              // sliced chunks in all, cold ones
+  int32_t hot_cap = 0, num_hot = 0, hot_pitch = 0, wave_lds = 0, ring_base = 0;
   int32_t *d_perm = nullptr, *d_inv_perm = nullptr, *d_zw = nullptr, *d_seg_word = nullptr, *d_seg_begin = nullptr;
   // theta of the current / last z step, and the buffer the next iteration's theta is drawn into
   // on the side stream while this iteration's counts and Phi are computed (theta_{t+1} depends
@@ -250,12 +254,19 @@ int launch_z(ggs_handle *h) {
   zp.K = h->K; zp.Kp = h->Kp; zp.pitch16 = h->pitch16; zp.tile_tokens = h->z_tile_tokens;
   zp.num_chunks = h->C;
   zp.ablate = h->ablate;
+  zp.ct_tok = h->d_ct_tok; zp.ct_idx = h->d_ct_idx; zp.ct_ip = h->d_ct_ip; zp.c_docs = h->d_c_docs; zp.num_cold = h->Cc;
+  zp.hot_words = h->d_hot_words; zp.num_hot = h->num_hot; zp.hot_pitch = h->hot_pitch;
+  zp.wave_lds = h->wave_lds; zp.hot_off = kSlicedWaves * h->wave_lds; zp.ring_base = h->ring_base;
   // persistent waves: as many single-wave workgroups as stay resident, each strides the chunk table
   const dim3 grid((unsigned)std::min<int64_t>(h->C, (int64_t)h->num_cus * h->z_waves_per_cu)), block(64);
   const int nt = (h->K + 63) / 64;
   if (h->z_sliced) {
+    // one 4-wave workgroup per CU (a wave per SIMD), persistent; the hot-word table fills the LDS the rings leave
+    zp.num_chunks = h->Cs;
     void *args[] = {&zp};
-    HIP_TRY(h, hipLaunchKernel(sliced_kernel_for(h->K), grid, block, args, (size_t)h->z_lds, h->stream));
+    const int64_t most = std::max(h->Cc, h->Cs - h->Cc);
+    const dim3 sgrid((unsigned)std::min<int64_t>((most + kSlicedWaves - 1) / kSlicedWaves, (int64_t)h->num_cus)), sblock(kSlicedWaves * 64);
+    HIP_TRY(h, hipLaunchKernel(sliced_kernel_for(h->K), sgrid, sblock, args, (size_t)(kSlicedWaves * h->wave_lds + h->num_hot * h->hot_pitch), h->stream));
   } else if (h->z_stream) hipLaunchKernelGGL(z_stream_kernel, grid, block, h->z_lds, h->stream, zp);
   else if (nt <= 1) hipLaunchKernelGGL(z_kernel<1>, grid, block, h->z_lds, h->stream, zp);
   else if (nt <= 2) hipLaunchKernelGGL(z_kernel<2>, grid, block, h->z_lds, h->stream, zp);
@@ -428,9 +439,17 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       // 64-token chunks, a 4-slot ring of 16-topic slices + the theta row; one wave per SIMD
       // (the score registers take most of the 512-entry file)
       h->z_tile_tokens = 64;
-      h->z_lds = kRingBase + kRingSlots * kSliceBytes;               // theta row (zero-padded to KMAX) below the ring
-      h->z_waves_per_cu = std::min(4, kMaxLdsBytes / alloc_of(h->z_lds));
-      if (const char *e = std::getenv("GGS_DEBUG_WPC")) h->z_waves_per_cu = std::max(1, std::atoi(e));
+      const int kmax = ((h->K + 7) / 8) * 8, ns = (kmax + kSliceTopics - 1) / kSliceTopics;
+      // per wave: the chunk's kChunkDocs theta rows (zero-padded to KMAX), then the ring; a DMA's immediate slice offset
+      // (< ns*128) is subtracted from its LDS destination, so the ring must not start below that
+      h->ring_base = (std::max(kChunkDocs * kmax * 8, ns * 128) + 255) / 256 * 256;
+      h->wave_lds = h->ring_base + kRingSlots * kSliceBytes;
+      h->hot_pitch = ((h->K + 7) / 8) * 64 + 16;                     // KMAX doubles + one unit: an odd number of 16-byte units
+      h->hot_cap = std::min(255, (kMaxLdsBytes - kSlicedWaves * h->wave_lds) / h->hot_pitch);
+      if (h->V >= (1 << kSlotShift)) return bail(GGS_ERR_UNSUPPORTED);   // the document slot shares the chunk token word with the word id
+      if (const char *e = std::getenv("GGS_DEBUG_HOT")) h->hot_cap = std::max(0, std::min(h->hot_cap, std::atoi(e)));
+      h->z_lds = kSlicedWaves * h->wave_lds + h->hot_cap * h->hot_pitch;
+      h->z_waves_per_cu = kSlicedWaves;
     } else {
     int T = (kMaxLdsBytes / 6 / kGranule * kGranule - thbytes) / pitch;
     if (const char *e = std::getenv("GGS_DEBUG_TILE")) T = std::atoi(e);
@@ -449,7 +468,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     if (lds_of(B) > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);
     h->theta_docs_per_block = B; h->theta_lds = lds_of(B);
   }
-  if (h->z_sliced && hipFuncSetAttribute(sliced_kernel_for(h->K), hipFuncAttributeMaxDynamicSharedMemorySize, h->z_lds) != hipSuccess)
+  if (h->z_sliced && hipFuncSetAttribute(sliced_kernel_for(h->K), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess)
     return bail(GGS_ERR_HIP);
   const void *zk[] = {reinterpret_cast<const void *>(z_kernel<1>), reinterpret_cast<const void *>(z_kernel<2>),
                       reinterpret_cast<const void *>(z_kernel<4>), reinterpret_cast<const void *>(z_kernel<8>),
@@ -501,7 +520,7 @@ void ggs_destroy(ggs_handle *h) {
   (void)hipDeviceSynchronize();
   void *bufs[] = {h->d_doc_ptr, h->d_chunk_start, h->d_tok, h->d_z, h->d_chunk_doc, h->d_chunk_len, h->d_alpha, h->d_theta, h->d_theta_next,
                   h->d_phiT, h->d_mag, h->d_tot, h->d_phi_mean, h->d_n_wk, h->d_n_k, h->d_perm, h->d_inv_perm, h->d_zw, h->d_seg_word, h->d_seg_begin,
-                  h->d_status, h->d_scratch, h->d_sum_pref, h->d_sum_fn};
+                  h->d_status, h->d_scratch, h->d_sum_pref, h->d_sum_fn, h->d_ct_tok, h->d_ct_idx, h->d_ct_ip, h->d_c_docs, h->d_hot_words};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (h->ev.ok)
@@ -556,7 +575,7 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
   // count-kernel work items: tokens sorted by word (counting sort, stable), each word's run
   // cut into segments of at most kSegTokens entries.
   constexpr int64_t kSegTokens = 4096;
-  std::vector<int32_t> perm((size_t)N), seg_word, seg_begin;
+  std::vector<int32_t> perm((size_t)N), seg_word, seg_begin, hot_words;
   {
     std::vector<int64_t> wptr((size_t)h->V + 1, 0);
     for (int64_t i = 0; i < N; ++i) wptr[(size_t)tokens[i] + 1]++;
@@ -566,6 +585,15 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
     seg_begin.push_back((int32_t)N);
     std::vector<int64_t> cur(wptr.begin(), wptr.end() - 1);
     for (int64_t i = 0; i < N; ++i) perm[(size_t)cur[(size_t)tokens[i]]++] = (int32_t)i;
+    // the hot-word table of the sliced z kernel: the hot_cap most frequent words of THIS handle's tokens
+    if (h->z_sliced && h->hot_cap > 0) {
+      std::vector<int32_t> order((size_t)h->V);
+      for (int32_t w = 0; w < h->V; ++w) order[(size_t)w] = w;
+      const size_t nh = (size_t)std::min<int32_t>(h->hot_cap, h->V);
+      auto freq = [&](int32_t w) { return wptr[(size_t)w + 1] - wptr[(size_t)w]; };
+      std::partial_sort(order.begin(), order.begin() + nh, order.end(), [&](int32_t a, int32_t b) { return freq(a) != freq(b) ? freq(a) > freq(b) : a < b; });
+      for (size_t r = 0; r < nh && freq(order[r]) > 0; ++r) hot_words.push_back(order[r]);
+    }
     // a segment ends where the next begins, or at the end of its word's run
     // (seg_begin[s+1] is the next segment's start, which is exactly that)
   }
@@ -576,9 +604,9 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
       (rc = dev_alloc(h, &h->d_perm, (size_t)N)) || (rc = dev_alloc(h, &h->d_inv_perm, (size_t)N)) || (rc = dev_alloc(h, &h->d_zw, (size_t)N)) || (rc = dev_alloc(h, &h->d_seg_word, (size_t)h->S)) ||
       (rc = dev_alloc(h, &h->d_seg_begin, (size_t)h->S + 1)))
     return rc;
+  std::vector<int32_t> inv((size_t)N);
   if (N) {
     HIP_TRY(h, hipMemcpy(h->d_perm, perm.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice));
-    std::vector<int32_t> inv((size_t)N);
     for (int64_t i = 0; i < N; ++i) inv[(size_t)perm[(size_t)i]] = (int32_t)i;
     HIP_TRY(h, hipMemcpy(h->d_inv_perm, inv.data(), sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice));
   }
@@ -587,6 +615,56 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
   HIP_TRY(h, hipMemcpy(h->d_seg_begin, seg_begin.data(), sizeof(int32_t) * seg_begin.size(), hipMemcpyHostToDevice));
   HIP_TRY(h, hipMemcpy(h->d_doc_ptr, doc_ptr, sizeof(int64_t) * ((size_t)D + 1), hipMemcpyHostToDevice));
   if (N) HIP_TRY(h, hipMemcpy(h->d_tok, tokens, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice));
+  h->num_hot = (int32_t)hot_words.size();
+  h->Cs = h->Cc = 0;
+  if (h->z_sliced) {
+    // Chunk lists of the sliced kernel: walk the documents in order and deal every token to the open
+    // cold chunk or the open hot chunk; a chunk closes at 64 tokens or when a third document would enter it.
+    struct Builder {
+      std::vector<int32_t> tok, idx, docs;
+      int fill = 64, ndocs = 0, last = -1;
+      void add(int32_t value, int32_t token, int32_t doc) {
+        if (fill == 64 || (doc != last && ndocs == kChunkDocs)) {
+          tok.resize(tok.size() + 64, 0); idx.resize(idx.size() + 64, -1);
+          docs.push_back(doc); docs.push_back(doc);
+          fill = 0; ndocs = 1; last = doc;
+        } else if (doc != last) {
+          docs[docs.size() - 1] = doc; ndocs = 2; last = doc;
+        }
+        const size_t at = tok.size() - 64 + (size_t)fill;
+        const int32_t slot = doc == docs[docs.size() - 2] ? 0 : 1;
+        tok[at] = value | (slot << kSlotShift); idx[at] = token;
+        ++fill;
+      }
+    } cold, hot;
+    std::vector<int32_t> row_of((size_t)h->V, -1);
+    for (size_t r = 0; r < hot_words.size(); ++r) row_of[(size_t)hot_words[r]] = (int32_t)r;
+    for (int64_t d = 0; d < D; ++d)
+      for (int64_t i = doc_ptr[d]; i < doc_ptr[d + 1]; ++i) {
+        const int32_t r = row_of[(size_t)tokens[i]];
+        if (r >= 0) hot.add(r, (int32_t)i, (int32_t)d);
+        else cold.add(tokens[i], (int32_t)i, (int32_t)d);
+      }
+    h->Cc = (int64_t)(cold.docs.size() / 2);
+    h->Cs = h->Cc + (int64_t)(hot.docs.size() / 2);
+    cold.tok.insert(cold.tok.end(), hot.tok.begin(), hot.tok.end());
+    cold.idx.insert(cold.idx.end(), hot.idx.begin(), hot.idx.end());
+    cold.docs.insert(cold.docs.end(), hot.docs.begin(), hot.docs.end());
+    std::vector<int32_t> ip(cold.idx.size(), 0);
+    for (size_t j = 0; j < ip.size(); ++j)
+      if (cold.idx[j] >= 0) ip[j] = inv[(size_t)cold.idx[j]];
+    const size_t n64 = cold.tok.size();
+    if ((rc = dev_alloc(h, &h->d_ct_tok, n64)) || (rc = dev_alloc(h, &h->d_ct_idx, n64)) || (rc = dev_alloc(h, &h->d_ct_ip, n64)) ||
+        (rc = dev_alloc(h, &h->d_c_docs, cold.docs.size())) || (rc = dev_alloc(h, &h->d_hot_words, hot_words.size())))
+      return rc;
+    if (n64) {
+      HIP_TRY(h, hipMemcpy(h->d_ct_tok, cold.tok.data(), sizeof(int32_t) * n64, hipMemcpyHostToDevice));
+      HIP_TRY(h, hipMemcpy(h->d_ct_idx, cold.idx.data(), sizeof(int32_t) * n64, hipMemcpyHostToDevice));
+      HIP_TRY(h, hipMemcpy(h->d_ct_ip, ip.data(), sizeof(int32_t) * n64, hipMemcpyHostToDevice));
+      HIP_TRY(h, hipMemcpy(h->d_c_docs, cold.docs.data(), sizeof(int32_t) * cold.docs.size(), hipMemcpyHostToDevice));
+    }
+    if (h->num_hot) HIP_TRY(h, hipMemcpy(h->d_hot_words, hot_words.data(), sizeof(int32_t) * hot_words.size(), hipMemcpyHostToDevice));
+  }
   HIP_TRY(h, hipMemset(h->d_z, 0, sizeof(int32_t) * std::max<size_t>((size_t)N, 1)));
   HIP_TRY(h, hipMemset(h->d_theta, 0, sizeof(double) * std::max<size_t>((size_t)D * h->K, 1)));
   HIP_TRY(h, hipMemset(h->d_theta_next, 0, sizeof(double) * std::max<size_t>((size_t)D * h->K, 1)));

@@ -39,6 +39,17 @@ struct ZParams {
   uint32_t iteration;
   int32_t K, Kp, pitch16, tile_tokens;
   int32_t ablate;   // timing-only experiments (env GGS_DEBUG_ABLATE): 2 no walk, 4 no staging, 8 no sum pass
+  // z_sliced_kernel only (ggs_z_sliced.hpp): its own chunk lists -- cold chunks [0, num_cold), hot chunks
+  // [num_cold, num_chunks) -- stored chunk-major, 64 entries per chunk
+  const int32_t *ct_tok;       // cold: word id, hot: row of the LDS table; | (0 or 1: which of the chunk's documents) << 30
+  const int32_t *ct_idx;       // local token index, -1 = idle lane
+  const int32_t *ct_ip;        // inv_perm[ct_idx]
+  const int32_t *c_docs;       // [num_chunks][2] local documents of a chunk (the second repeats the first if there is one)
+  int64_t num_cold;
+  const int32_t *hot_words;    // [num_hot] word ids of the table rows, most frequent first
+  int32_t num_hot, hot_pitch;  // rows and row pitch (bytes) of the LDS table
+  int32_t hot_off, wave_lds;   // LDS byte offset of the table; bytes of LDS per wave (theta rows + ring)
+  int32_t ring_base;           // offset of the ring inside a wave's LDS
 };
 
 struct alignas(16) D2 { double a, b; };

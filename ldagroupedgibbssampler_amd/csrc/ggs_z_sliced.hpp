@@ -1,27 +1,45 @@
 // ggs_z_sliced.hpp -- K3, the token loop (GGS:79-130), for K <= kSlicedMaxTopics: the K scores
 // of a token live in REGISTERS, exactly like the Java topicTermScores[] array.
 //
-// Persistent single-wave workgroups stride the chunk table; one chunk = up to 64 consecutive
-// tokens of ONE document, lane t owns token t.  The phiT rows of the chunk are streamed
-// through a 4-slot LDS ring in slices of 16 topics (128 B per row, 8 KiB per slice), kept
-// kAhead slices ahead of the arithmetic, across chunk boundaries:
+// Given theta and Phi every token's draw is independent of every other (GGS:79-130 touches only
+// its own z), and its random number is addressed by the token's index -- so tokens may be
+// processed in any grouping.  The host cuts the corpus into CHUNKS of up to 64 tokens drawn from
+// at most two consecutive documents (lane t owns token t and knows which of the chunk's two theta
+// rows is its own), and keeps two chunk lists:
 //
-//   for each slice s:   issue the LDS-DMA of slice s+kAhead (of this or the next chunk)
-//                       wait for slice s; score[k] = theta[k]*phi[k][w_t], sum += score[k]
-//                       for its 16 topics, k ascending                       (GGS:96-101)
+//   hot chunks   tokens of the few dozen most frequent words (Zipf: ~45 % of all tokens).  Their
+//                phiT rows are copied into LDS once per launch -- one table per workgroup
+//                (4 waves, one per SIMD, one workgroup per CU) -- and a hot chunk reads phi there:
+//                no global traffic at all.
+//   cold chunks  everything else.  Their phiT rows are streamed through a per-wave 4-slot LDS
+//                ring in slices of 16 topics (128 B per row, 8 KiB per slice) by LDS-DMA, kept
+//                kAhead slices ahead of the arithmetic, across chunk boundaries.
+//
+// Why the split: measured on MI355X, this kernel is bound by instruction ISSUE, and the issue of
+// the LDS-DMA instructions (64 lanes x 16 B each through the CU's one address unit, shared by
+// the 4 waves) does not overlap the wave's own arithmetic -- a chunk costs its VALU time PLUS
+// its DMA issue time, whether or not the data is waited for.  Hot chunks pay no DMA issue.
+// Odd waves take their hot chunks first, even waves their cold chunks, so that fewer waves
+// queue at the address unit at any time.
+//
+// Per chunk:
+//   for each slice s:   [cold: issue the LDS-DMA of slice s+kAhead (of this or the next chunk), wait for slice s]
+//                       score[k] = theta[k]*phi[k][w_t], sum += score[k] for its 16 topics, k ascending (GGS:96-101)
 //   U from Philox, sample = U*sum                                            (GGS:107-108)
-//   walk: cnt += (sample > 0); sample -= score[k], k ascending               (GGS:109-113)
-//   store z
+//   walk: count the k with sample > 0, sample -= score[k], k ascending       (GGS:109-113)
+//   store z (document order and word-sorted order)
 //
 // The two fp64 chains per token (sum, then walk) are the reference's sequential chains; the
-// products are computed once and kept, as in the reference.  HBM->LDS traffic is one pass over
-// each row.  Word ids and theta rows are requested two chunks ahead, chunk descriptors three.
+// products are computed once and kept, as in the reference.
 //
 // DMA shape: one global_load_lds_dwordx4 wave-instruction fills 1 KiB = 8 rows x 128 B, lane l
 // -> row 8m + l/8, LDS slot l%8.  Slot j of row r holds source unit (j - r/2) mod 8 (a per-row
 // rotation chosen through the per-lane SOURCE address), so lane t's 16-byte read of unit u, at
 // slot (u + t/2) mod 8 of row t, is bank-conflict free across the wave.  Per chunk every lane
-// computes its 8 source row addresses once; each DMA then only adds an immediate slice offset.
+// computes its 8 source row addresses once; the slice offset is the DMA instruction's immediate
+// -- which the hardware adds to the LDS destination as well as to the global source, hence the
+// "- s*128" on the destination and a ring that does not start at LDS address 0.  The ring slot
+// is wave-uniform and reaches M0 through scalar registers.
 // Lanes with nothing useful to fetch (rows past the chunk, units past the row) read whatever
 // finite bytes sit there (word 0's row; the next row's first entries; the zeroed tail pad of
 // phiT): those scores are multiplied by theta = 0 or belong to lanes that store nothing.
@@ -30,7 +48,7 @@
 
 #include "ggs_z_kernel.hpp"
 
-// timing-only experiments, compile time (results are wrong on purpose): 1 no DMA, 2 no walk, 4 no score pass
+// timing-only experiments, compile time (results are wrong on purpose): 1 no DMA, 8 DMA issued but never waited for
 #ifndef GGS_ABL
 #define GGS_ABL 0
 #endif
@@ -43,8 +61,9 @@ constexpr int kSliceBytes = 64 * 128;     // 64 rows x 16 topics x 8 B
 constexpr int kRingSlots = 4;
 constexpr int kSlicedMaxTopics = 192;     // 384 score registers (VGPR + AGPR) + working set < 512
 constexpr int kPhiTailPadBytes = 256;     // zeroed bytes after the last phiT row (see above)
-
-constexpr int kRingBase = 2048;           // ring offset inside the wave's LDS: the theta row (<= 1536 B) sits below it
+constexpr int kSlicedWaves = 4;           // waves per workgroup (one per SIMD), sharing the hot-word table
+constexpr int kChunkDocs = 2;             // documents a chunk may draw tokens from
+constexpr int kSlotShift = 30;            // chunk token word: value | (which of the chunk's documents) << 30
 
 template <int S, int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
@@ -55,201 +74,281 @@ __device__ __forceinline__ void static_for(F &&f) {
 }
 
 // KMAX = K rounded up to a multiple of 8: the size of the score register file.  Topics
-// K..KMAX-1 are scored too, with theta = 0 (the LDS theta row is zero-padded) against finite
+// K..KMAX-1 are scored too, with theta = 0 (the LDS theta rows are zero-padded) against finite
 // phi bytes, so they add +0.0 to the sum and subtract 0.0 in the walk: no per-topic guards.
-//
-// Issue economy (one wave per SIMD: every VALU instruction costs ~8 cycles whatever it does):
-// the slice index is a compile-time constant, so a DMA's slice offset is the instruction's
-// immediate -- which the hardware adds to the LDS destination as well as to the global source,
-// hence the "- s*128" on the destination and the ring starting at kRingBase, not 0; the ring
-// slot is wave-uniform and goes to M0 through scalar registers.
 template <int KMAX>
-__global__ __launch_bounds__(64) void z_sliced_kernel(ZParams p) {
+__global__ __launch_bounds__(kSlicedWaves * 64) void z_sliced_kernel(ZParams p) {
   constexpr int NS = (KMAX + kSliceTopics - 1) / kSliceTopics;     // slices per chunk
   constexpr int kAhead = NS < 3 ? NS : 3;                          // slices in flight beyond the one being scored
   constexpr int NT = (KMAX + 63) / 64;                             // 64-topic pieces of a theta row
+  constexpr int kThetaRow = KMAX * 8;                              // bytes of one theta row in LDS
   extern __shared__ __align__(16) unsigned char smem[];
-  const int lane = threadIdx.x;
-  const int K = p.K, Kp = p.Kp;
-  unsigned char *thb = smem;                                       // theta row, KMAX doubles
-  unsigned char *ring = smem + kRingBase;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int K = p.K;
+  unsigned char *thb = smem + wave * p.wave_lds;                   // the chunk's kChunkDocs theta rows
+  unsigned char *ring = thb + p.ring_base;
   const unsigned char *phib = reinterpret_cast<const unsigned char *>(p.phiT);
-  const size_t rowbytes = (size_t)Kp * 8;
-  const const_i64_t *cstart = (const const_i64_t *)p.chunk_start;
-  const const_i32_t *clen = (const const_i32_t *)p.chunk_len;
-  const const_i32_t *cdoc = (const const_i32_t *)p.chunk_doc;
-  const int64_t stride = gridDim.x;
-  const int64_t C = p.num_chunks;
+  const size_t rowbytes = (size_t)p.Kp * 8;
+  const const_i32_t *cdocs = (const const_i32_t *)p.c_docs;
+  const int64_t stride = (int64_t)gridDim.x * kSlicedWaves;
+  const int64_t wid = (int64_t)blockIdx.x * kSlicedWaves + wave;
+
+  // the hot rows: KMAX doubles each (like the ring, the tail past K is finite filler scored with theta = 0)
+  {
+    constexpr int upr = KMAX / 2;                                  // 16-byte units per row
+    for (int i = threadIdx.x; i < p.num_hot * upr; i += kSlicedWaves * 64) {
+      const int r = i / upr, u = i - r * upr;
+      *reinterpret_cast<D2 *>(smem + p.hot_off + r * p.hot_pitch + u * 16) =
+          *reinterpret_cast<const D2 *>(phib + (size_t)p.hot_words[r] * rowbytes + (size_t)u * 16);
+    }
+  }
+  __syncthreads();                                                 // the only barrier; no DMA is in flight yet
 
   const int lrow = lane >> 3, lslot = lane & 7;
   // byte offset of unit u of this lane's row inside a ring slot: lane*128 + ((u + lane/2) & 7)*16
   const unsigned char *my_row = ring + lane * 128;
   const int rot = lane >> 1;
 
-  // Source addresses of this lane's 8 DMA rows (m = 0..7): row 8m + lrow of the chunk, unit
-  // (lslot - row/2) mod 8 of slice 0.  Slice s adds s*128 bytes as an immediate.
-  auto row_addresses = [&](const int w, const unsigned char *(&ra)[8]) {
+  // theta rows of a chunk's two documents: lane l holds entries l, l + 64, ... of each (0.0 beyond K)
+  auto load_theta = [&](const int d0, const int d1, double (&tv)[kChunkDocs][NT]) {
+    const double *t0 = p.theta + (size_t)d0 * K, *t1 = p.theta + (size_t)d1 * K;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) {
-      const int row = 8 * m + lrow;
-      const int wm = __shfl(w, row);                               // 0 for rows past the chunk
-      ra[m] = phib + (size_t)wm * rowbytes + (size_t)(((lslot - (row >> 1)) & 7) << 4);
+    for (int t = 0; t < NT; ++t) {
+      tv[0][t] = (t * 64 + lane < K) ? t0[t * 64 + lane] : 0.0;
+      tv[1][t] = (t * 64 + lane < K) ? t1[t * 64 + lane] : 0.0;
     }
   };
-  auto issue_slice = [&](auto sc, const int slot, const unsigned char *const (&ra)[8]) {
-    constexpr int s = decltype(sc)::value;
-    if (GGS_ABL & 1) return;
+  auto stage_theta = [&](const double (&tv)[kChunkDocs][NT]) {
 #pragma unroll
-    for (int m = 0; m < 8; ++m)
-      __builtin_amdgcn_global_load_lds((glb_cvoid_t *)ra[m], (lds_void_t *)(ring + slot * kSliceBytes + m * 1024 - s * 128), 16, s * 128, 0);
+    for (int r = 0; r < kChunkDocs; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (t * 64 + lane < KMAX) reinterpret_cast<double *>(thb + r * kThetaRow)[t * 64 + lane] = tv[r][t];
   };
-  auto load_theta = [&](const int doc, double (&tv)[NT]) {
-    const double *thg = p.theta + (size_t)doc * K;
+  // U, the walk and the stores (GGS:107-130) of one chunk
+  auto finish = [&](const double (&sc)[KMAX], const double sum, const int idx, const int ip) {
+    if (idx < 0) return;
+    const uint64_t gtok = (uint64_t)(p.tok_base + idx);
+    const U4 o = philox4x32_10((uint32_t)gtok, (uint32_t)(gtok >> 32), (uint32_t)GGS_PURPOSE_Z << 24, p.iteration,
+                               (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
+    const double U = u53(o.x, o.y);
+    // The walk of GGS:108-113, negated and in counting form.  t = -(sample): t_0 = 0 - U*sum and
+    // t_{j+1} = t_j + score[j] round exactly as sample_{j+1} = sample_j - score[j] does (round to
+    // nearest is symmetric), x + (-x) gives +0, and scores are >= +0, so t is never -0 and
+    //     sample_j > 0   <=>   the sign bit of t_j is set.
+    // Scores are >= 0, so once the sign clears it stays clear, and
+    // newTopic + 1 == #{j : sample_j > 0} == number of sign bits collected before each subtraction.
+    // One funnel shift per topic collects them; no compare, no carry add.
+    double t = 0.0 - U * sum;
+    int cnt = 0;
+    bool live = true;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) tv[t] = (t * 64 + lane < K) ? thg[t * 64 + lane] : 0.0;
-  };
-
-  // ---- prologue.  Suffix 0 = this chunk, 1 = next, 2 = the one after; descriptors reach to 3.
-  int64_t c = blockIdx.x;
-  if (c >= C) return;
-  int64_t start0 = cstart[c], start1 = 0, start2 = 0, start3 = 0;
-  int len0 = clen[c], len1 = 0, len2 = 0, len3 = 0;
-  int doc0 = cdoc[c], doc1 = 0, doc2 = 0, doc3 = 0;
-  if (c + stride < C) { start1 = cstart[c + stride]; len1 = clen[c + stride]; doc1 = cdoc[c + stride]; }
-  if (c + 2 * stride < C) { start2 = cstart[c + 2 * stride]; len2 = clen[c + 2 * stride]; doc2 = cdoc[c + 2 * stride]; }
-  int w0 = (lane < len0) ? p.tok[start0 + lane] : 0;
-  int w1 = (lane < len1) ? p.tok[start1 + lane] : 0;              // len1 == 0 when there is no next chunk
-  int w2 = 0;
-  // word-sorted slot of each lane's token (for the second z store), requested with the word ids
-  int ip0 = (lane < len0) ? p.inv_perm[start0 + lane] : 0;
-  int ip1 = (lane < len1) ? p.inv_perm[start1 + lane] : 0;
-  int ip2 = 0;
-  double tv0[NT], tv1[NT], tv2[NT];
-  load_theta(doc0, tv0);
-  load_theta(doc1, tv1);                                           // doc1 == 0 (a valid row) when there is no next chunk
+    for (int kb = 0; kb < KMAX; kb += 16) {
+      if (live) {                                                  // wave-uniform
+        uint32_t bits = 0;
 #pragma unroll
-  for (int t = 0; t < NT; ++t) tv2[t] = 0.0;
-  const unsigned char *ra[8], *ran[8];                             // DMA row addresses: this chunk, next chunk
-  row_addresses(w0, ra);
-  row_addresses(w1, ran);
-  int g = 0;                                                       // ring slot of this chunk's slice 0
-  static_for<0, kAhead>([&](auto sc) { issue_slice(sc, decltype(sc)::value & (kRingSlots - 1), ra); });
-
-  for (;;) {
-    const bool has1 = c + stride < C, has2 = c + 2 * stride < C;
-    g = __builtin_amdgcn_readfirstlane(g);                         // wave-uniform by construction: keep it scalar
-    // this chunk's theta row: registers -> LDS (requested two chunks ago)
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-      if (t * 64 + lane < KMAX) reinterpret_cast<double *>(thb)[t * 64 + lane] = tv0[t];   // 0.0 beyond K
-
-    double sc[KMAX];
-    double sum = 0.0;
-    if (GGS_ABL & 4) {
-      sum = 1.0;
-#pragma unroll
-      for (int k = 0; k < KMAX; ++k) sc[k] = 0.01;
-    }
-    static_for<0, NS>([&](auto sidx) {
-      constexpr int s = decltype(sidx)::value;
-      const int cur = (g + s) & (kRingSlots - 1);
-      const int nxt = (g + s + kAhead) & (kRingSlots - 1);          // freed by the slice scored last step
-      // keep kAhead slices in flight: slice s + kAhead of this chunk, or of the next one
-      if constexpr (s + kAhead < NS) issue_slice(std::integral_constant<int, s + kAhead>{}, nxt, ra);
-      else if (has1) issue_slice(std::integral_constant<int, s + kAhead - NS>{}, nxt, ran);
-      // LDS-DMA completion is tracked by vmcnt in issue order.  With kAhead slices (8 DMAs each)
-      // issued after slice s, "at most 8*kAhead outstanding" means slice s has landed; at the tail
-      // of the last chunk fewer slices follow.  One wave per workgroup: no hardware barrier, only
-      // a compiler fence so that no LDS read moves above the wait.
-      if (GGS_ABL & 1) {}
-      else if (has1 || s + kAhead < NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * kAhead) : "memory");
-      else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NS - 1 - s)) : "memory");
-      if ((GGS_ABL & 4) ? false : lane < len0) {
-        const unsigned char *rb = my_row + cur * kSliceBytes;
-        const unsigned char *tb = thb + s * kSliceTopics * 8;
-        // unit u = topics (k, k+1).  All 16 LDS reads of the slice are issued up front (they return
-        // in order), so the chain below starts after one LDS latency and never waits again.
-        D2 ph[kSliceUnits], th[kSliceUnits];
-#pragma unroll
-        for (int u = 0; u < kSliceUnits; ++u)
-          if (s * kSliceTopics + 2 * u + 1 < KMAX) {               // compile time (KMAX is even)
-            ph[u] = lds_d2(rb + (((u + rot) & 7) << 4));
-            th[u] = lds_d2(tb + u * 16);
+        for (int j = 0; j < 16; ++j)
+          if (kb + j < KMAX) {
+            bits = __builtin_amdgcn_alignbit(bits, (uint32_t)hi32(t), 31);   // (bits << 1) | sign(t)
+            t += sc[kb + j];
           }
-#pragma unroll
-        for (int u = 0; u < kSliceUnits; ++u) {
-          constexpr int k0 = s * kSliceTopics;
-          const int k = k0 + 2 * u;
-          if (k + 1 < KMAX) {
-            sc[k] = th[u].a * ph[u].a;
-            sum += sc[k];
-            sc[k + 1] = th[u].b * ph[u].b;
-            sum += sc[k + 1];
-          }
-        }
+        cnt += __popc(bits);
+        live = __any(hi32(t) < 0);
       }
-      asm volatile("" ::: "memory");                               // every read of this ring slot is issued before it is refilled
-    });
-    g = (g + NS) & (kRingSlots - 1);                               // ring slot of the next chunk's slice 0
-
-    // requests for two chunks ahead: younger than every DMA above, so they are only waited for
-    // at the next chunk's slices, after the walk below.
-    if (has2) {
-      if (c + 3 * stride < C) { start3 = cstart[c + 3 * stride]; len3 = clen[c + 3 * stride]; doc3 = cdoc[c + 3 * stride]; }
-      else { start3 = 0; len3 = 0; doc3 = 0; }
-      w2 = (lane < len2) ? p.tok[start2 + lane] : 0;
-      ip2 = (lane < len2) ? p.inv_perm[start2 + lane] : 0;
-      load_theta(doc2, tv2);
     }
-
-    if (lane < len0) {
-      const uint64_t gtok = (uint64_t)(p.tok_base + start0 + lane);
-      const U4 o = philox4x32_10((uint32_t)gtok, (uint32_t)(gtok >> 32), (uint32_t)GGS_PURPOSE_Z << 24, p.iteration,
-                                 (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
-      const double U = u53(o.x, o.y);
-      // The walk of GGS:108-113, negated and in counting form.  t = -(sample): t_0 = 0 - U*sum and
-      // t_{j+1} = t_j + score[j] round exactly as sample_{j+1} = sample_j - score[j] does (round to
-      // nearest is symmetric), x + (-x) gives +0, and scores are >= +0, so t is never -0 and
-      //     sample_j > 0   <=>   the sign bit of t_j is set.
-      // Scores are >= 0, so once the sign clears it stays clear, and
-      // newTopic + 1 == #{j : sample_j > 0} == number of sign bits collected before each subtraction.
-      // One funnel shift per topic collects them; no compare, no carry add.
-      double t = 0.0 - U * sum;
-      int cnt = 0;
-      bool live = true;
-#pragma unroll
-      for (int kb = 0; kb < KMAX; kb += 16) {
-        if (live && !(GGS_ABL & 2)) {                              // wave-uniform
-          uint32_t bits = 0;
-#pragma unroll
-          for (int j = 0; j < 16; ++j)
-            if (kb + j < KMAX) {
-              bits = __builtin_amdgcn_alignbit(bits, (uint32_t)hi32(t), 31);   // (bits << 1) | sign(t)
-              t += sc[kb + j];
-            }
-          cnt += __popc(bits);
-          live = __any(hi32(t) < 0);
-        }
-      }
-      int new_topic = cnt - 1;
-      if (new_topic < 0 || hi32(t) < 0) {                          // GGS:116-118 (and the index past K Java would throw on;
+    int new_topic = cnt - 1;
+    if (new_topic < 0 || hi32(t) < 0) {                            // GGS:116-118 (and the index past K Java would throw on;
                                                                    // only then can cnt have run past K through the padding)
-        atomicOr(p.status, ST_INVALID_TOPIC);
-        new_topic = new_topic < 0 ? 0 : K - 1;
-      }
-      p.z[start0 + lane] = new_topic;
-      p.zw[ip0] = new_topic;
+      if (!GGS_ABL) atomicOr(p.status, ST_INVALID_TOPIC);
+      new_topic = new_topic < 0 ? 0 : K - 1;
     }
-    if (!has1) break;
-    c += stride;
-    start0 = start1; len0 = len1; doc0 = doc1; w0 = w1; ip0 = ip1;
-    start1 = start2; len1 = len2; doc1 = doc2; w1 = w2; ip1 = ip2;
-    start2 = start3; len2 = len3; doc2 = doc3;
+    p.z[idx] = new_topic;
+    p.zw[ip] = new_topic;
+  };
+
+  // ------------------------------------------------------------------ cold chunks
+  auto cold_chunks = [&]() {
+    const int64_t C = p.num_cold;
+    // Source addresses of this lane's 8 DMA rows (m = 0..7): row 8m + lrow of the chunk, unit
+    // (lslot - row/2) mod 8 of slice 0.
+    auto row_addresses = [&](const int w, const unsigned char *(&ra)[8]) {
 #pragma unroll
-    for (int t = 0; t < NT; ++t) { tv0[t] = tv1[t]; tv1[t] = tv2[t]; }
+      for (int m = 0; m < 8; ++m) {
+        const int row = 8 * m + lrow;
+        const int wm = __shfl(w, row) & ((1 << kSlotShift) - 1);   // 0 for rows past the chunk
+        ra[m] = phib + (size_t)wm * rowbytes + (size_t)(((lslot - (row >> 1)) & 7) << 4);
+      }
+    };
+    auto issue_slice = [&](auto sc, const int slot, const unsigned char *const (&ra)[8]) {
+      constexpr int s = decltype(sc)::value;
+      if (GGS_ABL & 1) return;
 #pragma unroll
-    for (int m = 0; m < 8; ++m) ra[m] = ran[m];
-    row_addresses(w1, ran);                                        // w1 was requested a chunk ago
+      for (int m = 0; m < 8; ++m)
+        __builtin_amdgcn_global_load_lds((glb_cvoid_t *)ra[m], (lds_void_t *)(ring + slot * kSliceBytes + m * 1024 - s * 128), 16, s * 128, 0);
+    };
+
+    // ---- prologue.  Suffix 0 = this chunk, 1 = next, 2 = the one after.
+    int64_t c = wid;
+    if (c >= C) return;
+    int w0 = p.ct_tok[c * 64 + lane], id0 = p.ct_idx[c * 64 + lane], ip0 = p.ct_ip[c * 64 + lane];
+    int w1 = 0, id1 = -1, ip1 = 0, w2 = 0, id2 = -1, ip2 = 0;
+    double tv0[kChunkDocs][NT], tv1[kChunkDocs][NT], tv2[kChunkDocs][NT];
+    load_theta(cdocs[2 * c], cdocs[2 * c + 1], tv0);
+    if (c + stride < C) {
+      const int64_t c1 = c + stride;
+      w1 = p.ct_tok[c1 * 64 + lane]; id1 = p.ct_idx[c1 * 64 + lane]; ip1 = p.ct_ip[c1 * 64 + lane];
+      load_theta(cdocs[2 * c1], cdocs[2 * c1 + 1], tv1);
+    } else {
+      load_theta(0, 0, tv1);
+    }
+#pragma unroll
+    for (int r = 0; r < kChunkDocs; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) tv2[r][t] = 0.0;
+    const unsigned char *ra[8], *ran[8];                           // DMA row addresses: this chunk, next chunk
+    row_addresses(w0, ra);
+    row_addresses(w1, ran);
+    int g = 0;                                                     // ring slot of this chunk's slice 0
+    static_for<0, kAhead>([&](auto sc) { issue_slice(sc, decltype(sc)::value & (kRingSlots - 1), ra); });
+
+    for (;;) {
+      const bool has1 = c + stride < C, has2 = c + 2 * stride < C;
+      g = __builtin_amdgcn_readfirstlane(g);                       // wave-uniform by construction: keep it scalar
+      stage_theta(tv0);                                            // requested two chunks ago
+      const unsigned char *trow = thb + ((unsigned)w0 >> kSlotShift) * kThetaRow;   // this lane's document
+
+      double sc[KMAX];
+      double sum = 0.0;
+      static_for<0, NS>([&](auto sidx) {
+        constexpr int s = decltype(sidx)::value;
+        const int cur = (g + s) & (kRingSlots - 1);
+        const int nxt = (g + s + kAhead) & (kRingSlots - 1);        // freed by the slice scored last step
+        // keep kAhead slices in flight: slice s + kAhead of this chunk, or of the next one
+        if constexpr (s + kAhead < NS) issue_slice(std::integral_constant<int, s + kAhead>{}, nxt, ra);
+        else if (has1) issue_slice(std::integral_constant<int, s + kAhead - NS>{}, nxt, ran);
+        // LDS-DMA completion is tracked by vmcnt in issue order.  With kAhead slices (8 DMAs each)
+        // issued after slice s, "at most 8*kAhead outstanding" means slice s has landed; at the tail
+        // of the last chunk fewer slices follow.  The waves of the workgroup never meet in the
+        // chunk loop: no hardware barrier, only a compiler fence so that no LDS read moves above the wait.
+        if (GGS_ABL & (1 | 8)) {}
+        else if (has1 || s + kAhead < NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * kAhead) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (NS - 1 - s)) : "memory");
+        if (id0 >= 0) {
+          const unsigned char *rb = my_row + cur * kSliceBytes;
+          // unit u = topics (k, k+1).  All 16 LDS reads of the slice are issued up front (they return
+          // in order), so the chain below starts after one LDS latency and never waits again.
+          D2 ph[kSliceUnits], th[kSliceUnits];
+#pragma unroll
+          for (int u = 0; u < kSliceUnits; ++u)
+            if (s * kSliceTopics + 2 * u + 1 < KMAX) {             // compile time (KMAX is even)
+              ph[u] = lds_d2(rb + (((u + rot) & 7) << 4));
+              th[u] = lds_d2(trow + s * (kSliceTopics * 8) + u * 16);
+            }
+#pragma unroll
+          for (int u = 0; u < kSliceUnits; ++u) {
+            constexpr int k0 = s * kSliceTopics;
+            const int k = k0 + 2 * u;
+            if (k + 1 < KMAX) {
+              sc[k] = th[u].a * ph[u].a;
+              sum += sc[k];
+              sc[k + 1] = th[u].b * ph[u].b;
+              sum += sc[k + 1];
+            }
+          }
+        }
+        asm volatile("" ::: "memory");                             // every read of this ring slot is issued before it is refilled
+      });
+      g = (g + NS) & (kRingSlots - 1);                             // ring slot of the next chunk's slice 0
+
+      // requests for two chunks ahead: younger than every DMA above, so they are only waited for
+      // at the next chunk's slices, after the walk below.
+      if (has2) {
+        const int64_t c2 = c + 2 * stride;
+        w2 = p.ct_tok[c2 * 64 + lane]; id2 = p.ct_idx[c2 * 64 + lane]; ip2 = p.ct_ip[c2 * 64 + lane];
+        load_theta(cdocs[2 * c2], cdocs[2 * c2 + 1], tv2);
+      } else {
+        w2 = 0; id2 = -1; ip2 = 0;
+      }
+
+      finish(sc, sum, id0, ip0);
+      if (!has1) break;
+      c += stride;
+      w0 = w1; id0 = id1; ip0 = ip1;
+      w1 = w2; id1 = id2; ip1 = ip2;
+#pragma unroll
+      for (int r = 0; r < kChunkDocs; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { tv0[r][t] = tv1[r][t]; tv1[r][t] = tv2[r][t]; }
+#pragma unroll
+      for (int m = 0; m < 8; ++m) ra[m] = ran[m];
+      row_addresses(w1, ran);                                      // w1 was requested a chunk ago
+    }
+  };
+
+  // ------------------------------------------------------------------ hot chunks: phi from the LDS table
+  auto hot_chunks = [&]() {
+    const int64_t C = p.num_chunks;
+    int64_t c = p.num_cold + wid;
+    if (c >= C) return;
+    int w0 = p.ct_tok[c * 64 + lane], id0 = p.ct_idx[c * 64 + lane], ip0 = p.ct_ip[c * 64 + lane];
+    double tv0[kChunkDocs][NT];
+    load_theta(cdocs[2 * c], cdocs[2 * c + 1], tv0);
+    for (;;) {
+      const bool has1 = c + stride < C;
+      int w1 = 0, id1 = -1, ip1 = 0;
+      double tv1[kChunkDocs][NT];
+      if (has1) {                                                  // the next chunk's operands land during this chunk's arithmetic
+        const int64_t c1 = c + stride;
+        w1 = p.ct_tok[c1 * 64 + lane]; id1 = p.ct_idx[c1 * 64 + lane]; ip1 = p.ct_ip[c1 * 64 + lane];
+        load_theta(cdocs[2 * c1], cdocs[2 * c1 + 1], tv1);
+      } else {
+        load_theta(0, 0, tv1);
+      }
+      stage_theta(tv0);
+      const unsigned char *trow = thb + ((unsigned)w0 >> kSlotShift) * kThetaRow;
+      const unsigned char *hrow = smem + p.hot_off + (w0 & ((1 << kSlotShift) - 1)) * p.hot_pitch;   // table row (plain unit order)
+
+      double sc[KMAX];
+      double sum = 0.0;
+      if (id0 >= 0) {
+        static_for<0, NS>([&](auto sidx) {
+          constexpr int s = decltype(sidx)::value;
+          D2 ph[kSliceUnits], th[kSliceUnits];
+#pragma unroll
+          for (int u = 0; u < kSliceUnits; ++u)
+            if (s * kSliceTopics + 2 * u + 1 < KMAX) {
+              ph[u] = lds_d2(hrow + s * (kSliceTopics * 8) + u * 16);
+              th[u] = lds_d2(trow + s * (kSliceTopics * 8) + u * 16);
+            }
+#pragma unroll
+          for (int u = 0; u < kSliceUnits; ++u) {
+            constexpr int k0 = s * kSliceTopics;
+            const int k = k0 + 2 * u;
+            if (k + 1 < KMAX) {
+              sc[k] = th[u].a * ph[u].a;
+              sum += sc[k];
+              sc[k + 1] = th[u].b * ph[u].b;
+              sum += sc[k + 1];
+            }
+          }
+        });
+      }
+      finish(sc, sum, id0, ip0);
+      if (!has1) break;
+      c += stride;
+      w0 = w1; id0 = id1; ip0 = ip1;
+#pragma unroll
+      for (int r = 0; r < kChunkDocs; ++r)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) tv0[r][t] = tv1[r][t];
+    }
+  };
+
+  // odd waves start with their hot chunks: fewer waves at the address unit at any time
+#pragma unroll 1
+  for (int phase = 0; phase < 2; ++phase) {
+    if ((phase ^ wave) & 1) hot_chunks();
+    else cold_chunks();
   }
 }
 

@@ -431,7 +431,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       // 64-token chunks, the same 4-slot ring + the theta row zero-padded to whole slices; no
       // score registers, so 8 waves per CU fit the register file and LDS bounds the residency
       h->z_tile_tokens = 64;
-      h->z_lds = kRingSlots * kSliceBytes + ((h->K + kSliceTopics - 1) / kSliceTopics) * kSliceTopics * 8;
+      h->z_lds = kStreamRingSlots * kSliceBytes + ((h->K + kSliceTopics - 1) / kSliceTopics) * kSliceTopics * 8;
       if (h->z_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);   // K > ~16000: the theta row itself would need slicing
       h->z_waves_per_cu = std::max(1, std::min(8, kMaxLdsBytes / alloc_of(h->z_lds)));
       if (const char *e = std::getenv("GGS_DEBUG_WPC")) h->z_waves_per_cu = std::max(1, std::atoi(e));

@@ -11,7 +11,7 @@
 //                phiT rows are copied into LDS once per launch -- one table per workgroup
 //                (4 waves, one per SIMD, one workgroup per CU) -- and a hot chunk reads phi there:
 //                no global traffic at all.
-//   cold chunks  everything else.  Their phiT rows are streamed through a per-wave 4-slot LDS
+//   cold chunks  everything else.  Their phiT rows are streamed through a per-wave 3-slot LDS
 //                ring in slices of 16 topics (128 B per row, 8 KiB per slice) by LDS-DMA, kept
 //                kAhead slices ahead of the arithmetic, across chunk boundaries.
 //
@@ -58,7 +58,10 @@ namespace ggs {
 constexpr int kSliceTopics = 16;
 constexpr int kSliceUnits = 8;            // 16-byte units per row per slice
 constexpr int kSliceBytes = 64 * 128;     // 64 rows x 16 topics x 8 B
-constexpr int kRingSlots = 4;
+#ifndef GGS_RING_SLOTS
+#define GGS_RING_SLOTS 3
+#endif
+constexpr int kRingSlots = GGS_RING_SLOTS;
 constexpr int kSlicedMaxTopics = 192;     // 384 score registers (VGPR + AGPR) + working set < 512
 constexpr int kPhiTailPadBytes = 256;     // zeroed bytes after the last phiT row (see above)
 constexpr int kSlicedWaves = 4;           // waves per workgroup (one per SIMD), sharing the hot-word table
@@ -79,7 +82,7 @@ __device__ __forceinline__ void static_for(F &&f) {
 template <int KMAX>
 __global__ __launch_bounds__(kSlicedWaves * 64) void z_sliced_kernel(ZParams p) {
   constexpr int NS = (KMAX + kSliceTopics - 1) / kSliceTopics;     // slices per chunk
-  constexpr int kAhead = NS < 3 ? NS : 3;                          // slices in flight beyond the one being scored
+  constexpr int kAhead = NS < kRingSlots - 1 ? NS : kRingSlots - 1;   // slices in flight beyond the one being scored
   constexpr int NT = (KMAX + 63) / 64;                             // 64-topic pieces of a theta row
   constexpr int kThetaRow = KMAX * 8;                              // bytes of one theta row in LDS
   extern __shared__ __align__(16) unsigned char smem[];
@@ -209,7 +212,7 @@ __global__ __launch_bounds__(kSlicedWaves * 64) void z_sliced_kernel(ZParams p) 
     row_addresses(w0, ra);
     row_addresses(w1, ran);
     int g = 0;                                                     // ring slot of this chunk's slice 0
-    static_for<0, kAhead>([&](auto sc) { issue_slice(sc, decltype(sc)::value & (kRingSlots - 1), ra); });
+    static_for<0, kAhead>([&](auto sc) { issue_slice(sc, decltype(sc)::value % kRingSlots, ra); });
 
     for (;;) {
       const bool has1 = c + stride < C, has2 = c + 2 * stride < C;
@@ -221,8 +224,8 @@ __global__ __launch_bounds__(kSlicedWaves * 64) void z_sliced_kernel(ZParams p) 
       double sum = 0.0;
       static_for<0, NS>([&](auto sidx) {
         constexpr int s = decltype(sidx)::value;
-        const int cur = (g + s) & (kRingSlots - 1);
-        const int nxt = (g + s + kAhead) & (kRingSlots - 1);        // freed by the slice scored last step
+        const int cur = (g + s) % kRingSlots;
+        const int nxt = (g + s + kAhead) % kRingSlots;        // freed by the slice scored last step
         // keep kAhead slices in flight: slice s + kAhead of this chunk, or of the next one
         if constexpr (s + kAhead < NS) issue_slice(std::integral_constant<int, s + kAhead>{}, nxt, ra);
         else if (has1) issue_slice(std::integral_constant<int, s + kAhead - NS>{}, nxt, ran);
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(kSlicedWaves * 64) void z_sliced_kernel(ZParams p) 
         }
         asm volatile("" ::: "memory");                             // every read of this ring slot is issued before it is refilled
       });
-      g = (g + NS) & (kRingSlots - 1);                             // ring slot of the next chunk's slice 0
+      g = (g + NS) % kRingSlots;                             // ring slot of the next chunk's slice 0
 
       // requests for two chunks ahead: younger than every DMA above, so they are only waited for
       // at the next chunk's slices, after the walk below.

@@ -21,6 +21,8 @@
 
 namespace ggs {
 
+constexpr int kStreamRingSlots = 4;
+
 __global__ __launch_bounds__(64) void z_stream_kernel(ZParams p) {
   constexpr int kAhead = 3;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -28,7 +30,7 @@ __global__ __launch_bounds__(64) void z_stream_kernel(ZParams p) {
   const int K = p.K, Kp = p.Kp;
   const int NS = (K + kSliceTopics - 1) / kSliceTopics;            // slices per pass (host guarantees NS >= 3)
   const int KT = NS * kSliceTopics;                                // theta row in LDS, zero padded
-  double *thb = reinterpret_cast<double *>(smem + kRingSlots * kSliceBytes);
+  double *thb = reinterpret_cast<double *>(smem + kStreamRingSlots * kSliceBytes);
   const unsigned char *phib = reinterpret_cast<const unsigned char *>(p.phiT);
   const size_t rowbytes = (size_t)Kp * 8;
   const const_i64_t *cstart = (const const_i64_t *)p.chunk_start;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(64) void z_stream_kernel(ZParams p) {
   row_addresses(w0, ra);
   int g = 0;                                                       // ring slot of this chunk's first slice
 #pragma unroll
-  for (int s = 0; s < kAhead; ++s) issue_slice(s, (g + s) & (kRingSlots - 1), ra);
+  for (int s = 0; s < kAhead; ++s) issue_slice(s, (g + s) & (kStreamRingSlots - 1), ra);
 
   for (;;) {
     const bool has1 = c + 1 < cend;
@@ -109,8 +111,8 @@ __global__ __launch_bounds__(64) void z_stream_kernel(ZParams p) {
     int cnt = 0;
     for (int j = 0; j < 2 * NS; ++j) {
       const int s = j < NS ? j : j - NS;
-      const int cur = (g + j) & (kRingSlots - 1);
-      const int nxt = (g + j + kAhead) & (kRingSlots - 1);
+      const int cur = (g + j) & (kStreamRingSlots - 1);
+      const int nxt = (g + j + kAhead) & (kStreamRingSlots - 1);
       const int ja = j + kAhead;
       if (ja < 2 * NS) issue_slice(ja < NS ? ja : ja - NS, nxt, ra);
       else if (has1) issue_slice(ja - 2 * NS, nxt, ran);
@@ -155,7 +157,7 @@ __global__ __launch_bounds__(64) void z_stream_kernel(ZParams p) {
       }
       asm volatile("" ::: "memory");                               // every read of this ring slot is issued before it is refilled
     }
-    g = (g + 2 * NS) & (kRingSlots - 1);
+    g = (g + 2 * NS) & (kStreamRingSlots - 1);
 
     if (lane < len0) {
       int new_topic = cnt - 1;

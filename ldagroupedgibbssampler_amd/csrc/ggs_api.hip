@@ -420,8 +420,9 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     constexpr int kGranule = 2048;
     auto alloc_of = [&](int bytes) { return (bytes + kGranule - 1) / kGranule * kGranule; };
     const int pitch = h->pitch16 * 16, thbytes = ((h->Kp * 8 + 15) / 16) * 16;
-    h->z_sliced = h->K <= kSlicedMaxTopics;
-    h->z_stream = !h->z_sliced;
+    // the sliced kernel tags chunk tokens (word ids) in bit 30
+    h->z_sliced = h->K <= kSlicedMaxTopics && h->V < (1 << kSlotShift);
+    h->z_stream = !h->z_sliced && h->K > 2 * kSliceTopics;
     if (const char *e = std::getenv("GGS_DEBUG_ZKERNEL")) {          // 0: whole-row tile kernel, 2: streaming kernel where it applies
       const int mode = std::atoi(e);
       h->z_sliced = h->z_sliced && mode == 1;
@@ -446,7 +447,6 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       h->wave_lds = h->ring_base + kRingSlots * kSliceBytes;
       h->hot_pitch = ((h->K + 7) / 8) * 64 + 16;                     // KMAX doubles + one unit: an odd number of 16-byte units
       h->hot_cap = std::min(255, (kMaxLdsBytes - kSlicedWaves * h->wave_lds) / h->hot_pitch);
-      if (h->V >= (1 << kSlotShift)) return bail(GGS_ERR_UNSUPPORTED);   // the document slot shares the chunk token word with the word id
       if (const char *e = std::getenv("GGS_DEBUG_HOT")) h->hot_cap = std::max(0, std::min(h->hot_cap, std::atoi(e)));
       h->z_lds = kSlicedWaves * h->wave_lds + h->hot_cap * h->hot_pitch;
       h->z_waves_per_cu = kSlicedWaves;

@@ -156,13 +156,13 @@ int launch_count_rebuild(ggs_handle *h) {
 // out[k] = sum over v, in index order, of src[v][k] (MAGNITUDE: of beta + src[v][k]) -- the exact
 // parallel formulation of ggs_exact_sum.hpp, or the element-by-element chain it replaces
 template <typename T, bool MAGNITUDE>
-void launch_column_sum(ggs_handle *h, const T *src, int32_t pitch, double *out) {
+void launch_column_sum(ggs_handle *h, const T *src, int32_t pitch, double *out, int32_t *n_k = nullptr) {
   if (!h->exact_sum) {
     hipLaunchKernelGGL((column_chain_kernel<T, MAGNITUDE>), dim3((h->K + 7) / 8), dim3(256), 0, h->stream, src, pitch, h->K, h->V, h->beta, out);
     return;
   }
   SumParams sp{};
-  sp.src = src; sp.pref = h->d_sum_pref; sp.fn = h->d_sum_fn; sp.out = out; sp.beta = h->beta;
+  sp.src = src; sp.pref = h->d_sum_pref; sp.fn = h->d_sum_fn; sp.out = out; sp.beta = h->beta; sp.n_k = n_k;
   sp.pitch = pitch; sp.K = h->K; sp.V = h->V; sp.nseg = h->sum_nseg;
   const dim3 rows((unsigned)h->sum_nseg, (unsigned)((h->K + kSumBlock - 1) / kSumBlock));
   hipLaunchKernelGGL((sum_seg_kernel<T, MAGNITUDE>), rows, dim3(kSumBlock), 0, h->stream, sp);
@@ -172,10 +172,14 @@ void launch_column_sum(ggs_handle *h, const T *src, int32_t pitch, double *out) 
 }
 
 int launch_magnitude(ggs_handle *h) {
-  launch_column_sum<int32_t, true>(h, h->d_n_wk, h->K, h->d_mag);
   HIP_TRY(h, hipMemsetAsync(h->d_n_k, 0, sizeof(int32_t) * (size_t)h->K, h->stream));
-  hipLaunchKernelGGL(topic_totals_kernel, dim3(grid_for((int64_t)h->K * h->V, 256, 16)), dim3(256), (size_t)h->K * sizeof(int32_t), h->stream, h->d_n_wk,
-                     h->K, h->V, h->d_n_k);
+  if (h->exact_sum) {
+    launch_column_sum<int32_t, true>(h, h->d_n_wk, h->K, h->d_mag, h->d_n_k);   // tokensPerTopic falls out of the first pass
+  } else {
+    launch_column_sum<int32_t, true>(h, h->d_n_wk, h->K, h->d_mag);
+    hipLaunchKernelGGL(topic_totals_kernel, dim3(grid_for((int64_t)h->K * h->V, 256, 16)), dim3(256), (size_t)h->K * sizeof(int32_t), h->stream, h->d_n_wk,
+                       h->K, h->V, h->d_n_k);
+  }
   HIP_TRY(h, hipGetLastError());
   return GGS_OK;
 }

@@ -303,11 +303,13 @@ __device__ __forceinline__ double prgamma(DrawStream &r, double alpha) {
 }
 // ParallelRandoms.java:60-70 with beta = 1, lambda = 0
 // One prgamma instance for both branches: a wave usually mixes shapes below and above 1 (sparse
-// counts), and two inlined copies would run one after the other.
+// counts), and two inlined copies would run one after the other.  The boost uniform is the
+// element's first draw whatever the shape (stream layout, see oracle/ggs_oracle.c rgamma): every
+// lane is then at the same stream position at every call site and new Philox blocks are needed
+// by all lanes together.
 __device__ __forceinline__ double rgamma(DrawStream &r, double alpha) {
   const bool boost = alpha < 1;
-  double u = 1.0;
-  if (boost) u = r.next_double();                    // drawn BEFORE the Marsaglia-Tsang loop, as at ParallelRandoms.java:62
+  const double u = r.next_double();                  // drawn BEFORE the Marsaglia-Tsang loop, as at ParallelRandoms.java:62
   const double g = prgamma(r, boost ? 1 + alpha : alpha);
   return boost ? g * strict_pow(u, 1.0 / alpha) : g;
 }

@@ -44,6 +44,7 @@ struct SumParams {
   double *pref;           // [nseg + 1][K] guessed running sum at each segment start
   double *fn;             // [nseg][K][4]: D1, H, D2, e (as a double; kSumDirty = none)
   double *out;            // [K]
+  int32_t *n_k;           // MAGNITUDE only, optional: += column sums of the counts (zeroed by the caller)
   double beta;
   int32_t pitch, K, V, nseg;
 };
@@ -63,16 +64,22 @@ __global__ __launch_bounds__(kSumBlock) void sum_seg_kernel(SumParams p) {
   const T *src = static_cast<const T *>(p.src);
   const int v0 = i * kSumSegRows;
   double a = 0.0;
+  int32_t cnt = 0;
   // 16 loads in flight; rows past V are clamped and contribute + 0.0
 #pragma unroll 1
   for (int r0 = 0; r0 < kSumSegRows; r0 += 16) {
-    double xs[16];
+    T xs[16];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) xs[j] = sum_elem<T, MAGNITUDE>(src, (size_t)min(v0 + r0 + j, p.V - 1) * p.pitch + k, p.beta);
+    for (int j = 0; j < 16; ++j) xs[j] = src[(size_t)min(v0 + r0 + j, p.V - 1) * p.pitch + k];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) a += (v0 + r0 + j < p.V) ? xs[j] : 0.0;
+    for (int j = 0; j < 16; ++j)
+      if (v0 + r0 + j < p.V) {
+        a += MAGNITUDE ? (p.beta + (double)xs[j]) : (double)xs[j];
+        if (MAGNITUDE) cnt += (int32_t)xs[j];
+      }
   }
   p.pref[(size_t)i * p.K + k] = a;
+  if (MAGNITUDE && p.n_k && cnt) atomicAdd(&p.n_k[k], cnt);      // tokensPerTopic on the way (integers: any order)
 }
 
 // one wave per topic: exclusive prefix over the segment sums, in place; pref[nseg][k] = total

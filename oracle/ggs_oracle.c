@@ -402,12 +402,14 @@ static double prgamma(draw_rng *r, double alpha) {
 }
 /* ParallelRandoms.java:60-70 rgamma(alpha, beta=1, lambda=0).  The trailing
  * "*beta + lambda" with beta=1, lambda=0 is the identity on non-negative
- * doubles and is kept for the record. */
+ * doubles and is kept for the record.
+ * Stream layout (ours -- the reference's generator cannot be seeded): the uniform of the
+ * alpha < 1 boost is the element's FIRST draw and is taken for every shape, used or not, so
+ * that all elements sit at the same position of their Philox stream when the
+ * Marsaglia-Tsang loop starts (on the GPU the lanes of a wave then need new blocks together). */
 static double rgamma(draw_rng *r, double alpha) {
-  if (alpha < 1) {
-    double u = draw_next_double(r);
-    return ((prgamma(r, 1 + alpha) * orc_pow(u, 1.0 / alpha)) * 1.0) + 0.0;
-  }
+  double u = draw_next_double(r);
+  if (alpha < 1) return ((prgamma(r, 1 + alpha) * orc_pow(u, 1.0 / alpha)) * 1.0) + 0.0;
   return (prgamma(r, alpha) * 1.0) + 0.0;
 }
 

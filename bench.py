@@ -44,7 +44,7 @@ def measured_traffic(kernel_prefix):
         return None
     fetch = write = None
     for line in open(files[-1]):
-        if not line.startswith(kernel_prefix):
+        if kernel_prefix not in line.split("{")[0]:
             continue
         try:
             d = ast.literal_eval(line[line.index("{"):line.rindex("}") + 1])
@@ -105,6 +105,7 @@ def main():
     ap.add_argument("--seed", type=int, default=2019)
     ap.add_argument("--cpu-sample-docs", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scheme", default="ggs", choices=["ggs", "pcgs"], help="ggs = the headline path; pcgs = the partially collapsed z loop (SURVEY 8f-1), for comparison")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the doc-sharded path (process group + RCCL all-reduce) even with one rank; for testing")
     args = ap.parse_args()
@@ -138,7 +139,8 @@ def main():
     corpus = synthetic_lda_corpus(args.docs, args.types, args.mean_len, true_topics=100, seed=args.seed)
     z0 = java_lcg_initial_z(corpus.num_tokens, K, args.seed)
 
-    h = native.GGSHandle(K, corpus.num_types, args.alpha, args.beta, args.seed, device_id=local_rank)
+    h = native.GGSHandle(K, corpus.num_types, args.alpha, args.beta, args.seed, device_id=local_rank,
+                         flags=native.FLAG_PCGS if args.scheme == "pcgs" else 0)
     if sharded:
         sh = ShardedGGS(h, TorchHipExchange, corpus, rank, world)
         sh.set_z_global(z0)
@@ -175,8 +177,9 @@ def main():
         btok = algorithmic_bytes_per_token(K)
         z_ms = tm["z_ms"] / max(tm["sweeps"], 1)            # HIP events on the handle's stream, over the timed region
         achieved = n_local * btok / (z_ms * 1e-3) / 1e9 if z_ms > 0 else 0.0
+        zkernel = "pcgs_z_kernel" if args.scheme == "pcgs" else ("z_sliced_kernel<%d>" % (8 * ((K + 7) // 8)) if K <= 192 else "z_stream_kernel")
         line = {
-            "metric": "M tokens sampled/sec (whole node) per Gibbs sweep at K=%d" % K,
+            "metric": "M tokens sampled/sec (whole node) per Gibbs sweep at K=%d" % K + ("" if args.scheme == "ggs" else " (scheme=%s)" % args.scheme),
             "value": round(corpus.num_tokens * args.steps / dt / 1e6, 3),
             "unit": "M tokens/s",
             "n_gpus": world,
@@ -195,12 +198,12 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "z_sliced_kernel<%d>" % (8 * ((K + 7) // 8)) if K <= 192 else "z_kernel",
+                "kernel": zkernel,
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic("void ggs::z_sliced_kernel" if K <= 192 else "void ggs::z_kernel"),
+                "traffic": measured_traffic("ggs::" + zkernel.split("<")[0]),
                 "bytes_per_token": btok,
                 "tokens_per_launch": n_local,
                 "avg_launch_ms": round(z_ms, 4),

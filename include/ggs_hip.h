@@ -45,7 +45,11 @@ enum {
 enum {
   GGS_FLAG_PARANOID = 1 << 0,     /* run ggs_check_invariants after every sweep
                                      (ParanoidUncollapsedParallelLDA.java:14-55)   */
-  GGS_FLAG_SAVE_PHI_MEAN = 1 << 1 /* cfg key save_phi_mean, UPLDA:205,1331-1335    */
+  GGS_FLAG_SAVE_PHI_MEAN = 1 << 1,/* cfg key save_phi_mean, UPLDA:205,1331-1335    */
+  GGS_FLAG_PCGS = 1 << 2          /* scheme=pcgs (LDAPartiallyCollapsedGibbsSampler): the z step is UPLDA:1466-1544,
+                                     score = (n_dk + alpha_k)*phi[k][w], sequential inside a document; no theta draw;
+                                     counts, Phi draw and exchange exactly as for ggs.  Any K up to
+                                     ~450 (the per-document counts live in LDS) and documents shorter than 32768. */
 };
 
 /* RNG stream addressing.  The reference draws from ThreadLocalRandom and a

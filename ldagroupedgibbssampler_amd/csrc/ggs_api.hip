@@ -16,6 +16,7 @@
 #include "ggs_z_sliced.hpp"
 #include "ggs_z_stream.hpp"
 #include "ggs_exact_sum.hpp"
+#include "ggs_z_pcgs.hpp"
 
 using namespace ggs;
 
@@ -54,6 +55,8 @@ struct ggs_handle {
   // sliced z kernel (ggs_z_sliced.hpp): its chunk lists (cold chunks first), the hot-word table's word ids, LDS layout
   int32_t *d_ct_tok = nullptr, *d_ct_idx = nullptr, *d_ct_ip = nullptr, *d_c_docs = nullptr, *d_hot_words = nullptr;
   int64_t Cs = 0, Cc = 0;                              // sliced chunks in all, cold ones
+  int32_t *d_order = nullptr;                          // scheme=pcgs: local documents, longest first
+  int32_t pcgs_lds = 0, pcgs_waves_per_cu = 0, max_doc_len = 0;
   int32_t hot_cap = 0, num_hot = 0, hot_pitch = 0, wave_lds = 0, ring_base = 0;
   int32_t *d_perm = nullptr, *d_inv_perm = nullptr, *d_zw = nullptr, *d_seg_word = nullptr, *d_seg_begin = nullptr;
   // theta of the current / last z step, and the buffer the next iteration's theta is drawn into
@@ -249,6 +252,20 @@ const void *sliced_kernel_for(int K) {
   }
 }
 
+int launch_pcgs_z(ggs_handle *h) {
+  if (h->N == 0) return GGS_OK;
+  PcgsParams pp{};
+  pp.tok = h->d_tok; pp.inv_perm = h->d_inv_perm; pp.z = h->d_z; pp.zw = h->d_zw; pp.doc_ptr = h->d_doc_ptr; pp.order = h->d_order;
+  pp.alpha = h->d_alpha; pp.phiT = h->d_phiT; pp.status = h->d_status;
+  pp.num_docs = h->D; pp.tok_base = h->tok_base; pp.seed = h->seed; pp.iteration = (uint32_t)h->iteration;
+  pp.K = h->K; pp.Kp = h->Kp;
+  const int64_t groups = (h->D + 63) / 64;
+  const dim3 grid((unsigned)std::min<int64_t>(groups, (int64_t)h->num_cus * h->pcgs_waves_per_cu)), block(64);
+  hipLaunchKernelGGL(pcgs_z_kernel, grid, block, (size_t)h->pcgs_lds, h->stream, pp);
+  HIP_TRY(h, hipGetLastError());
+  return GGS_OK;
+}
+
 int launch_z(ggs_handle *h) {
   if (h->C == 0) return GGS_OK;
   ZParams zp{};
@@ -321,6 +338,16 @@ int drop_theta_ahead(ggs_handle *h) {
 
 int z_phase(ggs_handle *h) {
   int rc;
+  if (h->flags & GGS_FLAG_PCGS) {                       // no theta: it is integrated out (UPLDA:1509-1513)
+    h->consumed_ahead = false;
+    HIP_TRY(h, hipEventRecord(h->ev.e[0], h->stream));
+    HIP_TRY(h, hipEventRecord(h->ev.e[1], h->stream));
+    if ((rc = launch_pcgs_z(h))) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev.e[2], h->stream));
+    if ((rc = launch_count_rebuild(h))) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev.e[3], h->stream));
+    return GGS_OK;
+  }
   h->consumed_ahead = h->theta_ahead_iter == (int64_t)h->iteration;
   if (h->consumed_ahead) {
     HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_theta1[h->ahead_slot], 0));   // drawn during the previous iteration's Phi phase
@@ -500,6 +527,15 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       hipMemset(h->d_n_k, 0, sizeof(int32_t) * h->K) != hipSuccess || hipMemset(h->d_status, 0, 16) != hipSuccess ||
       (h->d_phi_mean && hipMemset(h->d_phi_mean, 0, sizeof(double) * kv) != hipSuccess))
     return bail(GGS_ERR_HIP);
+  if (h->flags & GGS_FLAG_PCGS) {
+    // pcgs_z_kernel: slice ring + alpha row + int16 [KT][64] document counts per single-wave workgroup
+    const int ns = std::max(3, (h->K + kSliceTopics - 1) / kSliceTopics), kt = ns * kSliceTopics;
+    h->pcgs_lds = kStreamRingSlots * kSliceBytes + kt * 8 + kt * 128;
+    if (h->pcgs_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);
+    h->pcgs_waves_per_cu = std::max(1, std::min(8, kMaxLdsBytes / ((h->pcgs_lds + 2047) / 2048 * 2048)));
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(pcgs_z_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, h->pcgs_lds) != hipSuccess)
+      return bail(GGS_ERR_HIP);
+  }
   for (auto &e : h->ev.e)
     if (hipEventCreate(&e) != hipSuccess) return bail(GGS_ERR_HIP);
   h->ev.ok = true;
@@ -524,7 +560,7 @@ void ggs_destroy(ggs_handle *h) {
   (void)hipDeviceSynchronize();
   void *bufs[] = {h->d_doc_ptr, h->d_chunk_start, h->d_tok, h->d_z, h->d_chunk_doc, h->d_chunk_len, h->d_alpha, h->d_theta, h->d_theta_next,
                   h->d_phiT, h->d_mag, h->d_tot, h->d_phi_mean, h->d_n_wk, h->d_n_k, h->d_perm, h->d_inv_perm, h->d_zw, h->d_seg_word, h->d_seg_begin,
-                  h->d_status, h->d_scratch, h->d_sum_pref, h->d_sum_fn, h->d_ct_tok, h->d_ct_idx, h->d_ct_ip, h->d_c_docs, h->d_hot_words};
+                  h->d_status, h->d_scratch, h->d_sum_pref, h->d_sum_fn, h->d_ct_tok, h->d_ct_idx, h->d_ct_ip, h->d_c_docs, h->d_hot_words, h->d_order};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (h->ev.ok)
@@ -600,6 +636,16 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
     }
     // a segment ends where the next begins, or at the end of its word's run
     // (seg_begin[s+1] is the next segment's start, which is exactly that)
+  }
+  if (h->flags & GGS_FLAG_PCGS) {
+    // documents longest first: the 64 of a pcgs wave are then equally long
+    std::vector<int32_t> order((size_t)D);
+    int64_t longest = 0;
+    for (int64_t d = 0; d < D; ++d) { order[(size_t)d] = (int32_t)d; longest = std::max(longest, doc_ptr[d + 1] - doc_ptr[d]); }
+    if (longest > kPcgsMaxDocLen) return set_err(h, GGS_ERR_UNSUPPORTED, "scheme=pcgs keeps per-document counts as int16: documents must be shorter than 32768 tokens");
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return doc_ptr[a + 1] - doc_ptr[a] > doc_ptr[b + 1] - doc_ptr[b]; });
+    if ((rc = dev_alloc(h, &h->d_order, (size_t)D))) return rc;
+    if (D) HIP_TRY(h, hipMemcpy(h->d_order, order.data(), sizeof(int32_t) * (size_t)D, hipMemcpyHostToDevice));
   }
   h->D = D; h->N = N; h->C = (int64_t)cstart.size(); h->S = (int64_t)seg_word.size(); h->doc_base = doc_base; h->tok_base = tok_base;
   if ((rc = dev_alloc(h, &h->d_doc_ptr, (size_t)D + 1)) || (rc = dev_alloc(h, &h->d_tok, (size_t)N)) || (rc = dev_alloc(h, &h->d_z, (size_t)N)) ||

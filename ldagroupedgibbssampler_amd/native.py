@@ -8,7 +8,7 @@ from . import _lib
 OK = 0
 ERR_NEGATIVE_COUNT, ERR_INVALID_TOPIC, ERR_RNG_EXHAUSTED, ERR_BAD_ARG = 1, 2, 3, 4
 ERR_HIP, ERR_STATE, ERR_UNSUPPORTED, ERR_INVARIANT = 5, 6, 7, 8
-FLAG_PARANOID, FLAG_SAVE_PHI_MEAN = 1, 2
+FLAG_PARANOID, FLAG_SAVE_PHI_MEAN, FLAG_PCGS = 1, 2, 4
 PURPOSE_Z, PURPOSE_THETA, PURPOSE_PHI, PURPOSE_INIT_PHI = 1, 2, 3, 4
 
 

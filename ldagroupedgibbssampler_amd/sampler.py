@@ -101,6 +101,7 @@ def model_log_likelihood(n_dk, n_wk, n_k, alpha, beta):
 class LDAGroupedGibbsSampler:
     """scheme=ggs on MI355X.  One instance drives one GPU (doc-sharded runs wrap the same
     native handle with ldagroupedgibbssampler_amd.sharded.ShardedGGS)."""
+    _scheme_flags = 0
 
     def __init__(self, config):
         self.config = config
@@ -134,7 +135,7 @@ class LDAGroupedGibbsSampler:
         if not isinstance(training, Corpus):
             raise TypeError("addInstances expects a ldagroupedgibbssampler_amd.corpus.Corpus")
         cfg = self.config
-        flags = (native.FLAG_PARANOID if cfg.paranoid else 0) | (native.FLAG_SAVE_PHI_MEAN if cfg.save_phi_mean else 0)
+        flags = (native.FLAG_PARANOID if cfg.paranoid else 0) | (native.FLAG_SAVE_PHI_MEAN if cfg.save_phi_mean else 0) | self._scheme_flags
         burn_in = int((cfg.phi_mean_burnin / 100.0) * cfg.iterations)        # UPLDA:206-207
         self._h = native.GGSHandle(self.numTopics, training.num_types, self.alpha, self.beta, self.startSeed,
                                    device_id=cfg.device_id, flags=flags, phi_burn_in=burn_in, phi_mean_thin=cfg.phi_mean_thin)
@@ -316,9 +317,20 @@ class LDAGroupedGibbsSampler:
             raise RuntimeError("addInstances has not been called")
 
 
+class LDAPartiallyCollapsedGibbsSampler(LDAGroupedGibbsSampler):
+    """scheme=pcgs (topics/LDAPartiallyCollapsedGibbsSampler.java): the same driver, counts and Phi draw;
+    the z step is UPLDA:1466-1544 (theta integrated out, sequential inside a document).  SURVEY 8(f)-1."""
+    _scheme_flags = native.FLAG_PCGS
+
+    def getTheta(self):
+        raise NotImplementedError("scheme=pcgs never draws theta; use getThetaEstimate() (UPLDA:716-720 does the same)")
+
+
 def create_model(config, scheme=None):
-    """The `case "ggs"` of tui/ParallelLDA.createModel (ParallelLDA.java:401-490)."""
+    """The `case "ggs"` / `case "pcgs"` of tui/ParallelLDA.createModel (ParallelLDA.java:401-490)."""
     scheme = scheme or config.scheme
     if scheme == "ggs":
         return LDAGroupedGibbsSampler(config)
-    raise ValueError("scheme %r is not provided by this build (only the GGS hot path is in scope)" % scheme)
+    if scheme == "pcgs":
+        return LDAPartiallyCollapsedGibbsSampler(config)
+    raise ValueError("scheme %r is not provided by this build (only the ggs and pcgs z loops are in scope)" % scheme)

@@ -486,6 +486,7 @@ struct orc_state {
   int save_phi_mean, phi_burn_in, phi_thin;
   int32_t iteration;  /* currentIteration */
   int threads;
+  int scheme;         /* 0 = ggs (LDAGroupedGibbsSampler), 1 = pcgs (LDAPartiallyCollapsedGibbsSampler) */
   jrandom collapsed_rng; int collapsed_rng_ready;
   char err[256];
 };
@@ -539,6 +540,7 @@ void orc_set_phi_mean_gating(orc_state *s, int save, int burn_in, int thin) {
   s->save_phi_mean = save; s->phi_burn_in = burn_in; s->phi_thin = thin;
   if (save && !s->phi_mean) s->phi_mean = calloc((size_t)s->K * s->V, sizeof(double));
 }
+void orc_set_scheme(orc_state *s, int scheme) { s->scheme = scheme == 1 ? 1 : 0; }
 void orc_set_threads(orc_state *s, int threads) { s->threads = threads > 0 ? threads : 1; }
 void orc_set_iteration(orc_state *s, int32_t it) { s->iteration = it; }
 int32_t orc_get_iteration(const orc_state *s) { return s->iteration; }
@@ -674,6 +676,59 @@ static int ggs_doc_step(orc_state *s, int64_t d, int32_t *localTopicCounts, doub
   return ORC_OK;
 }
 
+/* UPLDA:1466-1544 sampleTopicAssignmentsParallel: the z loop of scheme=pcgs (and of
+ * "uncollapsed").  theta is integrated out: score = (n_dk + alpha_k) * phi[k][w] with the
+ * document's counts updated token by token, so the tokens of one document are strictly
+ * sequential; documents are independent given Phi.  Same per-token Philox uniform as the GGS
+ * path (purpose Z, element = global token index). */
+static int pcgs_doc_step(orc_state *s, int64_t d, int32_t *localTopicCounts, double *topicTermScores) {
+  const int32_t K = s->K, V = s->V;
+  const int64_t b = s->doc_ptr[d], e = s->doc_ptr[d + 1];
+  const int64_t docLength = e - b;
+  if (docLength == 0) return ORC_OK;                              /* UPLDA:1474 */
+  const int32_t *tokenSequence = s->tokens + b;
+  int32_t *oneDocTopics = s->z + b;
+  memset(localTopicCounts, 0, sizeof(int32_t) * K);
+  for (int64_t position = 0; position < docLength; position++)   /* UPLDA:1482-1485 */
+    localTopicCounts[oneDocTopics[position]]++;
+  for (int64_t position = 0; position < docLength; position++) { /* UPLDA:1491-1543 */
+    int32_t type = tokenSequence[position];
+    int32_t oldTopic = oneDocTopics[position];
+    localTopicCounts[oldTopic]--;
+    if (localTopicCounts[oldTopic] < 0) return fail(s, ORC_ERR_NEGATIVE_COUNT, "Counts cannot be negative!");
+#pragma omp atomic
+    s->delta[(size_t)oldTopic * V + type] -= 1;                  /* decrement(), UPLDA:1553-1556 */
+    double sum = 0.0;
+    for (int32_t topic = 0; topic < K; topic++) {                /* UPLDA:1509-1513 */
+      double score = (localTopicCounts[topic] + s->alpha[topic]) * s->phi[(size_t)topic * V + type];
+      topicTermScores[topic] = score;
+      sum += score;
+    }
+    draw_rng r; draw_init(&r, s->seed, (uint32_t)s->iteration, ORC_PURPOSE_Z, (uint64_t)(s->tok_base + b + position));
+    double U = draw_next_double(&r);                             /* UPLDA:1519 */
+    double sample = U * sum;
+    int32_t newTopic = -1;
+    while (sample > 0.0) {                                       /* UPLDA:1523-1526 */
+      newTopic++;
+      if (newTopic >= K) break;   /* Java: ArrayIndexOutOfBoundsException */
+      sample -= topicTermScores[newTopic];
+    }
+    if (newTopic < 0 || newTopic >= K) {                         /* UPLDA:1529-1531 */
+      newTopic = newTopic < 0 ? 0 : K - 1;
+      oneDocTopics[position] = newTopic;
+      localTopicCounts[newTopic]++;
+#pragma omp atomic
+      s->delta[(size_t)newTopic * V + type] += 1;
+      return fail(s, ORC_ERR_INVALID_TOPIC, "UncollapsedParallelLDA: New valid topic not sampled.");
+    }
+    oneDocTopics[position] = newTopic;
+    localTopicCounts[newTopic]++;
+#pragma omp atomic
+    s->delta[(size_t)newTopic * V + type] += 1;                  /* increment(), UPLDA:1547-1551 */
+  }
+  return ORC_OK;
+}
+
 /* UPLDA:1434-1437 loopOverBatches: the fork-join halving down to
  * document_sampler_split_limit (100) docs is restated as dynamic chunks of 100
  * documents; every result is schedule-independent because the RNG is
@@ -689,7 +744,7 @@ int orc_z_step(orc_state *s) {
     double *tp = malloc(sizeof(double) * K), *th = malloc(sizeof(double) * K), *sc = malloc(sizeof(double) * K);
 #pragma omp for schedule(dynamic, 100)
     for (int64_t d = 0; d < s->D; d++) {
-      int e = ggs_doc_step(s, d, ltc, tp, th, sc);
+      int e = s->scheme == 1 ? pcgs_doc_step(s, d, ltc, sc) : ggs_doc_step(s, d, ltc, tp, th, sc);
       if (e) {
 #pragma omp atomic write
         err = e;

@@ -17,6 +17,7 @@
  *   topics/UncollapsedParallelLDA.java:357-482  init z, count build
  *   topics/UncollapsedParallelLDA.java:1107-1221 delta merge
  *   topics/ModifiedSimpleLDA.java:158-226       count-form (collapsed) step
+ *   topics/UncollapsedParallelLDA.java:1466-1544 the z loop of scheme=pcgs (partially collapsed)
  *
  * PARITY STATUS: the reference's GGS path draws from
  * ThreadLocalRandom / a nanoTime-seeded xorshift and therefore has no
@@ -91,6 +92,8 @@ int orc_init_z_java_lcg(orc_state *s, int32_t seed);   /* UPLDA:398-406,458-460 
 int orc_set_z(orc_state *s, const int32_t *z, int redraw_phi); /* UPLDA:1797-1843 */
 int orc_init_phi(orc_state *s);                        /* UPLDA:1287-1294       */
 void orc_set_phi_mean_gating(orc_state *s, int save, int burn_in, int thin);
+/* 0 = ggs (default), 1 = pcgs: UPLDA:1466-1544 z loop (theta integrated out), same Phi draw */
+void orc_set_scheme(orc_state *s, int scheme);
 void orc_set_threads(orc_state *s, int threads);
 void orc_set_iteration(orc_state *s, int32_t it);
 int32_t orc_get_iteration(const orc_state *s);

@@ -61,6 +61,7 @@ def lib():
         "orc_init_phi": (C.c_int, [vp]),
         "orc_set_phi_mean_gating": (None, [vp, C.c_int, C.c_int, C.c_int]),
         "orc_set_threads": (None, [vp, C.c_int]),
+        "orc_set_scheme": (None, [vp, C.c_int]),
         "orc_set_iteration": (None, [vp, C.c_int32]),
         "orc_get_iteration": (C.c_int32, [vp]),
         "orc_sweep": (C.c_int, [vp, C.c_int32]),
@@ -230,6 +231,10 @@ class OracleSampler:
 
     def set_threads(self, n):
         lib().orc_set_threads(self._h, n)
+
+    def set_scheme(self, scheme):
+        """'ggs' (default) or 'pcgs' (UPLDA:1466-1544 z loop, same Phi draw)."""
+        lib().orc_set_scheme(self._h, {"ggs": 0, "pcgs": 1}[scheme])
 
     def set_iteration(self, it):
         lib().orc_set_iteration(self._h, it)

@@ -190,3 +190,26 @@ def test_log_likelihood_within_one_percent_across_rng_streams(oracle):
     ll_cpu = model_log_likelihood(o.get_doc_topic_counts(), o.get_type_topic_counts(), o.get_topic_totals(), alpha, beta)
     assert ll_hip > ll0 + 0.02 * abs(ll0)                   # the chain did move uphill from the random start
     assert abs(ll_hip - ll_cpu) <= 0.01 * abs(ll_cpu), (ll_hip, ll_cpu)
+
+
+def test_registry_knows_pcgs():
+    from ldagroupedgibbssampler_amd.sampler import LDAPartiallyCollapsedGibbsSampler
+    m = create_model(SimpleLDAConfiguration(topics=4, seed=1, scheme="pcgs"))
+    assert isinstance(m, LDAPartiallyCollapsedGibbsSampler) and m.getNoTopics() == 4
+    with pytest.raises(NotImplementedError):
+        m.getTheta()
+
+
+@pytest.mark.gpu
+def test_python_mirror_pcgs_matches_oracle(oracle, cats):
+    m = create_model(SimpleLDAConfiguration(topics=5, alpha=0.5, beta=0.1, seed=31, iterations=3, exec_time=1800, paranoid=True), "pcgs")
+    m.addInstances(cats)
+    m.sample(3)
+    o = oracle.OracleSampler(5, cats.num_types, 0.5, 0.1, 31)
+    o.set_scheme("pcgs")
+    o.set_corpus(cats.doc_ptr, cats.tokens)
+    o.init_z_java_lcg(31)
+    o.init_phi()
+    o.sweep(3)
+    assert np.array_equal(np.concatenate(m.getZIndicators()), o.get_z())
+    assert np.array_equal(m.getPhi().view(np.int64), o.get_phi().view(np.int64))

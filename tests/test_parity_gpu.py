@@ -235,7 +235,8 @@ def test_phi_mean_gating(native, oracle):
     assert_bit_equal(gm, om, "phi mean")
 
 
-def test_sharded_via_torch(native, oracle):
+@pytest.mark.parametrize("scheme", ["ggs", "pcgs"])
+def test_sharded_via_torch(native, oracle, scheme):
     """Three doc shards on one GPU, the count/delta exchange done on the device buffers
     through torch (what ldagroupedgibbssampler_amd.sharded does over RCCL) == one handle ==
     the oracle: the doc-sharded decomposition is exact, not AD-LDA."""
@@ -243,13 +244,18 @@ def test_sharded_via_torch(native, oracle):
     from ldagroupedgibbssampler_amd.sharded import wrap_device_int32
     c = random_corpus(203, 300, 120, seed=21, empty_every=11)
     K, alpha, beta, seed = 12, 0.1, 0.01, 99
-    ref, o = make_pair(native, oracle, c, K, alpha, beta, seed, zseed=3)
+    flags = native.FLAG_PCGS if scheme == "pcgs" else 0
+    ref, o = make_pair(native, oracle, c, K, alpha, beta, seed, flags=flags)
+    o.set_scheme(scheme)
+    for s in (ref, o):
+        s.init_z_java_lcg(3)
+        s.init_phi()
     z0 = ref.get_z()
     bounds = even_split(c.num_docs, 3)
     shards = []
     for r in range(3):
         sub, db, tb = c.shard(bounds[r], bounds[r + 1])
-        h = native.GGSHandle(K, c.num_types, alpha, beta, seed)
+        h = native.GGSHandle(K, c.num_types, alpha, beta, seed, flags=flags)
         h.set_corpus(sub.doc_ptr, sub.tokens, db, tb)
         h.set_global_token_count(c.num_tokens)
         h.set_z(z0[tb:tb + sub.num_tokens], redraw_phi=False)
@@ -281,8 +287,9 @@ def test_sharded_via_torch(native, oracle):
         assert_bit_equal(h.get_type_topic_counts(), o.get_type_topic_counts(), "sharded n_wk")
         assert_bit_equal(h.get_phi(), o.get_phi(), "sharded phi")
         h.check_invariants()
-    th = np.concatenate([h.get_theta() for h, _, _ in shards])
-    assert_bit_equal(th, o.get_theta(), "sharded theta")
+    if scheme == "ggs":
+        th = np.concatenate([h.get_theta() for h, _, _ in shards])
+        assert_bit_equal(th, o.get_theta(), "sharded theta")
 
 
 def test_error_behaviour(native):
@@ -439,3 +446,40 @@ def test_long_vocabulary(native, oracle, beta):
     g.sweep(3)
     o.sweep(3)
     compare_state(g, o, "long vocabulary")
+
+
+# ---------------------------------------------------------------- scheme=pcgs
+@pytest.mark.parametrize("K,alpha,beta", [(3, 5.0, 7.0), (7, 0.1, 0.01), (20, 0.5, 0.1), (40, 0.1, 0.01), (100, 0.1, 0.01), (200, 0.05, 0.01)])
+def test_pcgs_matches_oracle(native, oracle, K, alpha, beta):
+    """UPLDA:1466-1544 z loop (theta integrated out, sequential inside a document) + the shared count
+    rebuild and Phi draw, against the oracle's restatement: integer and fp64 state bit for bit."""
+    c = random_corpus(333, 400, 170, seed=K, empty_every=9)      # 333 documents: five full lane groups and a ragged one
+    g = native.GGSHandle(K, c.num_types, alpha, beta, 77 + K, flags=native.FLAG_PARANOID | native.FLAG_PCGS)
+    o = oracle.OracleSampler(K, c.num_types, alpha, beta, 77 + K, threads=4)
+    o.set_scheme("pcgs")
+    for s in (g, o):
+        s.set_corpus(c.doc_ptr, c.tokens)
+        s.init_z_java_lcg(K)
+        s.init_phi()
+    compare_state(g, o, "pcgs K=%d init" % K, theta=False)
+    for it in range(3):
+        g.sweep(1)
+        o.sweep(1)
+        compare_state(g, o, "pcgs K=%d sweep %d" % (K, it + 1), theta=False)
+
+
+def test_pcgs_on_cats(native, oracle, cats):
+    """cats: 23 documents of very different lengths, so the lanes of the one group finish at different steps."""
+    K = 20
+    o = oracle.OracleSampler(K, cats.num_types, 5.0, 7.0, 2019, threads=2)
+    o.set_scheme("pcgs")
+    o.set_corpus(cats.doc_ptr, cats.tokens)
+    o.init_z_java_lcg(2019)
+    o.init_phi()
+    g = native.GGSHandle(K, cats.num_types, 5.0, 7.0, 2019, flags=native.FLAG_PCGS)
+    g.set_corpus(cats.doc_ptr, cats.tokens)
+    g.init_z_java_lcg(2019)
+    g.init_phi()
+    o.sweep(3)
+    g.sweep(3)
+    compare_state(g, o, "pcgs cats", theta=False)

@@ -41,6 +41,7 @@ struct LDAConfiguration {
   int phi_mean_burnin = 0;         // percent of iterations
   int phi_mean_thin = 1;
   bool paranoid = false;
+  bool pcgs = false;              // scheme=pcgs instead of ggs (ParallelLDA.java:414-416): the z step of UPLDA:1466-1544
   int device_id = 0;
 };
 
@@ -69,7 +70,8 @@ class LDAGroupedGibbsSampler {
     c.num_topics = config_.topics; c.num_types = training.num_types; c.device_id = config_.device_id;
     c.alpha = nullptr; c.alpha_scalar = config_.alpha; c.beta = config_.beta;
     c.seed = (uint64_t)(int64_t)startSeed_;
-    c.flags = (config_.paranoid ? GGS_FLAG_PARANOID : 0) | (config_.save_phi_mean ? GGS_FLAG_SAVE_PHI_MEAN : 0);
+    c.flags = (config_.paranoid ? GGS_FLAG_PARANOID : 0) | (config_.save_phi_mean ? GGS_FLAG_SAVE_PHI_MEAN : 0) |
+              (config_.pcgs ? GGS_FLAG_PCGS : 0);
     c.phi_burn_in = (int32_t)(((double)config_.phi_mean_burnin / 100) * config_.iterations);   // UPLDA:206-207
     c.phi_mean_thin = config_.phi_mean_thin;
     int rc = ggs_create(&c, &h_);

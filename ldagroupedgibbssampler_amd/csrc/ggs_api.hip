@@ -25,9 +25,13 @@ namespace {
 constexpr int kThetaBlock = 256;
 constexpr int kMaxLdsBytes = 160 * 1024;
 
+// The phase events of one sweep.  Sweeps are settled (waited for, checked, timed) in batches, so a ring of them:
+// sweep i records into slot i % kEvRing; the theta drawn ahead for sweep i + 1 records th0/th1 of THAT slot.
+constexpr int kEvRing = 8;
 struct Events {
-  hipEvent_t e[6];
-  bool ok = false;
+  hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t th0 = nullptr, th1 = nullptr;   // side-stream theta draw consumed by this sweep
+  bool used_ahead = false;
 };
 
 }  // namespace
@@ -64,9 +68,7 @@ struct ggs_handle {
   // on z_t only, GGS:57-72)
   double *d_theta_next = nullptr;
   hipStream_t side = nullptr;
-  hipEvent_t ev_theta0[2] = {nullptr, nullptr}, ev_theta1[2] = {nullptr, nullptr};   // ping-pong: one pair being timed, one being recorded
-  int ahead_slot = 0, consumed_slot = 0;
-  bool overlap_theta = true, consumed_ahead = false;
+  bool overlap_theta = true;
   int64_t theta_ahead_iter = INT64_MIN;     // iteration the side-stream theta was drawn for, or none
   double *d_alpha = nullptr, *d_theta = nullptr, *d_phiT = nullptr, *d_mag = nullptr, *d_tot = nullptr, *d_phi_mean = nullptr;
   int32_t *d_n_wk = nullptr, *d_n_k = nullptr;
@@ -77,7 +79,8 @@ struct ggs_handle {
   void *d_scratch = nullptr;
   size_t scratch_bytes = 0;
 
-  Events ev;
+  Events evs[kEvRing];
+  int ev_head = 0, ev_pending = 0;                     // slot of the sweep in progress; sweeps enqueued but not settled
   ggs_timings tm{};
   std::string err;
 };
@@ -336,70 +339,87 @@ int drop_theta_ahead(ggs_handle *h) {
   return GGS_OK;
 }
 
-int z_phase(ggs_handle *h) {
-  int rc;
-  if (h->flags & GGS_FLAG_PCGS) {                       // no theta: it is integrated out (UPLDA:1509-1513)
-    h->consumed_ahead = false;
-    HIP_TRY(h, hipEventRecord(h->ev.e[0], h->stream));
-    HIP_TRY(h, hipEventRecord(h->ev.e[1], h->stream));
-    if ((rc = launch_pcgs_z(h))) return rc;
-    HIP_TRY(h, hipEventRecord(h->ev.e[2], h->stream));
-    if ((rc = launch_count_rebuild(h))) return rc;
-    HIP_TRY(h, hipEventRecord(h->ev.e[3], h->stream));
-    return GGS_OK;
+// waits for every enqueued sweep and adds its phase times to the timings
+int settle_sweeps(ggs_handle *h) {
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  for (int j = h->ev_pending - 1; j >= 0; --j) {
+    const Events &E = h->evs[((h->ev_head - j) % kEvRing + kEvRing) % kEvRing];
+    float ms = 0;
+    // a consumed ahead-draw: the stream waited on th1 before the z kernel, so both side-stream events are complete;
+    // their span is the duration of a kernel that ran beside the previous sweep's Phi phase
+    if (E.used_ahead) { HIP_TRY(h, hipEventElapsedTime(&ms, E.th0, E.th1)); }
+    else { HIP_TRY(h, hipEventElapsedTime(&ms, E.e[0], E.e[1])); }
+    h->tm.theta_ms += ms;
+    HIP_TRY(h, hipEventElapsedTime(&ms, E.e[1], E.e[2])); h->tm.z_ms += ms;
+    HIP_TRY(h, hipEventElapsedTime(&ms, E.e[2], E.e[3])); h->tm.merge_ms += ms;
+    HIP_TRY(h, hipEventElapsedTime(&ms, E.e[4], E.e[5])); h->tm.phi_ms += ms;
+    h->tm.sweeps += 1;
+    h->tm.tokens_sampled += h->N;
   }
-  h->consumed_ahead = h->theta_ahead_iter == (int64_t)h->iteration;
-  if (h->consumed_ahead) {
-    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_theta1[h->ahead_slot], 0));   // drawn during the previous iteration's Phi phase
-    h->consumed_slot = h->ahead_slot;
-    std::swap(h->d_theta, h->d_theta_next);
-  } else {
-    if (h->side) HIP_TRY(h, hipStreamSynchronize(h->side));
-    HIP_TRY(h, hipEventRecord(h->ev.e[0], h->stream));
-    if ((rc = launch_theta(h, h->stream, h->d_theta, h->iteration))) return rc;
-  }
-  HIP_TRY(h, hipEventRecord(h->ev.e[1], h->stream));
-  if ((rc = launch_z(h))) return rc;
-  HIP_TRY(h, hipEventRecord(h->ev.e[2], h->stream));
-  h->theta_ahead_iter = INT64_MIN;
-  if (h->overlap_theta && h->side && h->D > 0) {
-    // theta of iteration t+1 from the z just drawn, concurrent with the counts and the Phi draw
-    HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev.e[2], 0));
-    h->ahead_slot ^= 1;
-    HIP_TRY(h, hipEventRecord(h->ev_theta0[h->ahead_slot], h->side));
-    if ((rc = launch_theta(h, h->side, h->d_theta_next, h->iteration + 1))) return rc;
-    HIP_TRY(h, hipEventRecord(h->ev_theta1[h->ahead_slot], h->side));
-    h->theta_ahead_iter = (int64_t)h->iteration + 1;
-  }
-  if ((rc = launch_count_rebuild(h))) return rc;   // this shard's counts; summed across shards by the caller
-  HIP_TRY(h, hipEventRecord(h->ev.e[3], h->stream));
+  h->ev_pending = 0;
   return GGS_OK;
 }
 
-int finish_sweep(ggs_handle *h, bool with_phi) {
+int z_phase(ggs_handle *h) {
   int rc;
-  HIP_TRY(h, hipEventRecord(h->ev.e[4], h->stream));
+  if (h->ev_pending >= kEvRing - 2 && (rc = settle_sweeps(h))) return rc;   // keep this slot and the next one free
+  h->ev_head = (h->ev_head + 1) % kEvRing;
+  Events &E = h->evs[h->ev_head];
+  if (h->flags & GGS_FLAG_PCGS) {                       // no theta: it is integrated out (UPLDA:1509-1513)
+    E.used_ahead = false;
+    HIP_TRY(h, hipEventRecord(E.e[0], h->stream));
+    HIP_TRY(h, hipEventRecord(E.e[1], h->stream));
+    if ((rc = launch_pcgs_z(h))) return rc;
+    HIP_TRY(h, hipEventRecord(E.e[2], h->stream));
+    if ((rc = launch_count_rebuild(h))) return rc;
+    HIP_TRY(h, hipEventRecord(E.e[3], h->stream));
+    return GGS_OK;
+  }
+  E.used_ahead = h->theta_ahead_iter == (int64_t)h->iteration;
+  if (E.used_ahead) {
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, E.th1, 0));   // drawn during the previous iteration's Phi phase
+    std::swap(h->d_theta, h->d_theta_next);
+  } else {
+    if (h->side) HIP_TRY(h, hipStreamSynchronize(h->side));
+    HIP_TRY(h, hipEventRecord(E.e[0], h->stream));
+    if ((rc = launch_theta(h, h->stream, h->d_theta, h->iteration))) return rc;
+  }
+  HIP_TRY(h, hipEventRecord(E.e[1], h->stream));
+  if ((rc = launch_z(h))) return rc;
+  HIP_TRY(h, hipEventRecord(E.e[2], h->stream));
+  h->theta_ahead_iter = INT64_MIN;
+  if (h->overlap_theta && h->side && h->D > 0) {
+    // theta of iteration t+1 from the z just drawn, concurrent with the counts and the Phi draw
+    Events &N = h->evs[(h->ev_head + 1) % kEvRing];
+    HIP_TRY(h, hipStreamWaitEvent(h->side, E.e[2], 0));
+    HIP_TRY(h, hipEventRecord(N.th0, h->side));
+    if ((rc = launch_theta(h, h->side, h->d_theta_next, h->iteration + 1))) return rc;
+    HIP_TRY(h, hipEventRecord(N.th1, h->side));
+    h->theta_ahead_iter = (int64_t)h->iteration + 1;
+  }
+  if ((rc = launch_count_rebuild(h))) return rc;   // this shard's counts; summed across shards by the caller
+  HIP_TRY(h, hipEventRecord(E.e[3], h->stream));
+  return GGS_OK;
+}
+
+// `settle` = wait for the device, raise what the sweeps flagged and add their phase times to the timings.  A batch
+// (ggs_sweep with n_sweeps > 1) settles once, after its last sweep: the device flags are sticky, and the ~40 us host
+// round trip per sweep is 2 % of a 1.9 ms sweep.
+int finish_sweep(ggs_handle *h, bool with_phi, bool settle = true) {
+  int rc;
+  Events &E = h->evs[h->ev_head];
+  HIP_TRY(h, hipEventRecord(E.e[4], h->stream));
   bool acc = false;
   if (with_phi) {
     acc = (h->flags & GGS_FLAG_SAVE_PHI_MEAN) && sample_phi_this_iteration(h);
     if ((rc = launch_phi(h, false, acc))) return rc;
   }
-  HIP_TRY(h, hipEventRecord(h->ev.e[5], h->stream));
-  if ((rc = check_status(h))) return rc;   // synchronises the stream
+  HIP_TRY(h, hipEventRecord(E.e[5], h->stream));
   if (acc) h->n_sampled_phi++;             // GGS:168-170
-  float ms = 0;
-  if (h->consumed_ahead) {
-    // the stream waited on ev_theta1 before the z kernel, so both side-stream events are complete;
-    // their span is the duration of a kernel that ran beside the previous iteration's Phi phase
-    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev_theta0[h->consumed_slot], h->ev_theta1[h->consumed_slot])); h->tm.theta_ms += ms;
-  } else {
-    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev.e[0], h->ev.e[1])); h->tm.theta_ms += ms;
-  }
-  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev.e[1], h->ev.e[2])); h->tm.z_ms += ms;
-  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev.e[2], h->ev.e[3])); h->tm.merge_ms += ms;
-  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev.e[4], h->ev.e[5])); h->tm.phi_ms += ms;
-  h->tm.sweeps += 1;
-  h->tm.tokens_sampled += h->N;
+  h->ev_pending += 1;
+  if (!settle && !(h->flags & GGS_FLAG_PARANOID)) return GGS_OK;
+  if ((rc = check_status(h))) return rc;   // synchronises the stream
+  if ((rc = settle_sweeps(h))) return rc;
   if (h->flags & GGS_FLAG_PARANOID) return ggs_check_invariants(h);
   return GGS_OK;
 }
@@ -536,9 +556,11 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(pcgs_z_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, h->pcgs_lds) != hipSuccess)
       return bail(GGS_ERR_HIP);
   }
-  for (auto &e : h->ev.e)
-    if (hipEventCreate(&e) != hipSuccess) return bail(GGS_ERR_HIP);
-  h->ev.ok = true;
+  for (auto &E : h->evs) {
+    for (auto &e : E.e)
+      if (hipEventCreate(&e) != hipSuccess) return bail(GGS_ERR_HIP);
+    if (hipEventCreate(&E.th0) != hipSuccess || hipEventCreate(&E.th1) != hipSuccess) return bail(GGS_ERR_HIP);
+  }
   if (const char *e = std::getenv("GGS_DEBUG_NO_OVERLAP")) h->overlap_theta = std::atoi(e) == 0;
   {
     // lowest priority: the theta draw fills whatever the Phi phase (on the caller's stream) leaves idle
@@ -548,8 +570,6 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     // serialises with the legacy default stream, so the overlap is lost -- priority alone it is)
     if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo) != hipSuccess) return bail(GGS_ERR_HIP);
   }
-  for (int i = 0; i < 2; ++i)
-    if (hipEventCreate(&h->ev_theta0[i]) != hipSuccess || hipEventCreate(&h->ev_theta1[i]) != hipSuccess) return bail(GGS_ERR_HIP);
   *out = h;
   return GGS_OK;
 }
@@ -563,11 +583,11 @@ void ggs_destroy(ggs_handle *h) {
                   h->d_status, h->d_scratch, h->d_sum_pref, h->d_sum_fn, h->d_ct_tok, h->d_ct_idx, h->d_ct_ip, h->d_c_docs, h->d_hot_words, h->d_order};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
-  if (h->ev.ok)
-    for (auto &e : h->ev.e) (void)hipEventDestroy(e);
-  for (int i = 0; i < 2; ++i) {
-    if (h->ev_theta0[i]) (void)hipEventDestroy(h->ev_theta0[i]);
-    if (h->ev_theta1[i]) (void)hipEventDestroy(h->ev_theta1[i]);
+  for (auto &E : h->evs) {
+    for (auto &e : E.e)
+      if (e) (void)hipEventDestroy(e);
+    if (E.th0) (void)hipEventDestroy(E.th0);
+    if (E.th1) (void)hipEventDestroy(E.th1);
   }
   if (h->side) (void)hipStreamDestroy(h->side);
   delete h;
@@ -789,7 +809,8 @@ int ggs_sweep(ggs_handle *h, int32_t n_sweeps) {
   for (int32_t i = 0; i < n_sweeps; ++i) {
     int rc = ggs_sweep_begin(h);
     if (rc) return rc;
-    if ((rc = ggs_sweep_end(h))) return rc;
+    h->in_sweep = false;
+    if ((rc = finish_sweep(h, true, i == n_sweeps - 1))) return rc;
   }
   return GGS_OK;
 }

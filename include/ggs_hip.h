@@ -176,6 +176,14 @@ int ggs_debug_philox(int32_t device_id, int64_t n, const uint32_t *ctr /*n*4*/, 
 int ggs_debug_math(int32_t device_id, int32_t op /*0 log,1 pow,2 sqrt,3 div*/, int64_t n, const double *x, const double *y, double *out);
 int ggs_debug_draw(int32_t device_id, int32_t kind /*0 uniform,1 gaussian,2 gamma*/, uint64_t seed, uint32_t iteration,
                    uint32_t purpose, uint64_t elem0, int64_t n, const double *shape, double *out, int32_t *status);
+/* replaces: modelLogLikelihood (UPLDA:1644-1758), the Dirichlet-multinomial log likelihood of the current topic
+ * assignments, split where a doc-sharded run splits it: doc_side covers THIS handle's documents (sum_d [...] +
+ * D*lgS(alphaSum), UPLDA:1674-1694) and topic_side the (replicated) type-topic counts (UPLDA:1701-1747); the model's
+ * value is the sum of every shard's doc_side plus one topic_side.  lgS = MALLET Dirichlet.logGammaStirling.  A
+ * diagnostic: partial sums are reduced in a fixed tree, so the value is run-to-run identical and within ~1e-12
+ * relative of the Java loop's running sum, not bit-equal to it.  Needs tokensPerTopic up to date (any completed sweep,
+ * ggs_init_phi or ggs_set_z with redraw). */
+int ggs_model_log_likelihood(ggs_handle *h, double *doc_side, double *topic_side);
 /* out[k] = x[0][k] + x[1][k] + ... in index order (exactly one of x / counts given; with counts the addends are
  * beta + counts[v][k]): the Phi normalisers' exact parallel column sum on its own, for adversarial inputs */
 int ggs_debug_column_sum(int32_t device_id, int32_t V, int32_t K, const double *x /*V*K or NULL*/, const int32_t *counts /*V*K or NULL*/,

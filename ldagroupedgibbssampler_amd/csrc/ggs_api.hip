@@ -17,6 +17,7 @@
 #include "ggs_z_stream.hpp"
 #include "ggs_exact_sum.hpp"
 #include "ggs_z_pcgs.hpp"
+#include "ggs_loglik.hpp"
 
 using namespace ggs;
 
@@ -933,6 +934,32 @@ int ggs_get_doc_topic_counts(ggs_handle *h, int64_t doc_begin, int64_t doc_end, 
   hipLaunchKernelGGL(doc_topic_kernel, dim3((unsigned)nd), dim3(64), 0, h->stream, h->d_doc_ptr, h->d_z, doc_begin, h->K, static_cast<int32_t *>(h->d_scratch));
   HIP_TRY(h, hipGetLastError());
   return copy_out(h, n_dk, h->d_scratch, bytes);
+}
+int ggs_model_log_likelihood(ggs_handle *h, double *doc_side, double *topic_side) {
+  int rc = require_ready(h, false);
+  if (rc) return rc;
+  if (!doc_side || !topic_side) return set_err(h, GGS_ERR_BAD_ARG, "null output");
+  const int K = h->K;
+  const int64_t doc_blocks = (h->D + kLLBlock / 64 - 1) / (kLLBlock / 64), type_blocks = 1024;
+  const size_t bytes = 32 + sizeof(double) * (size_t)(doc_blocks + type_blocks);
+  if ((rc = ensure_scratch(h, bytes))) return rc;
+  auto *d_out = static_cast<double *>(h->d_scratch);                       // [0] document side, [1] topic side
+  auto *d_nz = reinterpret_cast<unsigned long long *>(d_out + 2);
+  double *d_doc = d_out + 4, *d_type = d_doc + doc_blocks;
+  HIP_TRY(h, hipMemsetAsync(h->d_scratch, 0, 32, h->stream));
+  double alpha_sum = 0;
+  for (int k = 0; k < K; ++k) alpha_sum += h->alpha[k];
+  if (doc_blocks)
+    hipLaunchKernelGGL(ll_docs_kernel, dim3((unsigned)doc_blocks), dim3(kLLBlock), (size_t)(kLLBlock / 64) * K * sizeof(int32_t), h->stream, h->d_doc_ptr,
+                       h->d_z, h->d_alpha, alpha_sum, h->D, K, d_doc);
+  hipLaunchKernelGGL(ll_types_kernel, dim3((unsigned)type_blocks), dim3(kLLBlock), 0, h->stream, h->d_n_wk, (int64_t)K * h->V, h->beta, d_type, d_nz);
+  hipLaunchKernelGGL(ll_finish_kernel, dim3(1), dim3(kLLBlock), 0, h->stream, d_doc, doc_blocks, d_type, type_blocks, h->d_n_k, K, h->beta * h->V,
+                     alpha_sum, h->beta, h->D, d_nz, d_out);
+  HIP_TRY(h, hipGetLastError());
+  double out[2];
+  if ((rc = copy_out(h, out, d_out, sizeof out))) return rc;
+  *doc_side = out[0]; *topic_side = out[1];
+  return GGS_OK;
 }
 int ggs_get_timings(ggs_handle *h, ggs_timings *out) { if (!h || !out) return GGS_ERR_BAD_ARG; *out = h->tm; return GGS_OK; }
 int ggs_reset_timings(ggs_handle *h) { if (!h) return GGS_ERR_BAD_ARG; h->tm = ggs_timings{}; return GGS_OK; }

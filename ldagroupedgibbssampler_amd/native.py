@@ -187,6 +187,12 @@ class GGSHandle:
     def check_invariants(self):
         self._chk(self._L.ggs_check_invariants(self._h))
 
+    def model_log_likelihood(self):
+        """(document side, topic side) of modelLogLikelihood (UPLDA:1644-1758), computed on the device."""
+        a, b = C.c_double(), C.c_double()
+        self._chk(self._L.ggs_model_log_likelihood(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def launch_info(self):
         c, l, b = C.c_int64(), C.c_int32(), C.c_int32()
         self._chk(self._L.ggs_get_launch_info(self._h, C.byref(c), C.byref(l), C.byref(b)))

@@ -253,9 +253,11 @@ class LDAGroupedGibbsSampler:
         return self._h.get_theta()
 
     def modelLogLikelihood(self):
-        """UPLDA:1644-1758, computed on the host from copied-back counts (a diagnostic)."""
-        return model_log_likelihood(self.getDocumentTopicMatrix(), self.getTypeTopicMatrix(), self.getTopicTotals(),
-                                    self.alpha, self.beta)
+        """UPLDA:1644-1758, on the device (ggs_model_log_likelihood): nothing is copied back but two doubles.
+        model_log_likelihood() above is the host-side formula the tests check it against."""
+        self._need_data()
+        doc_side, topic_side = self._h.model_log_likelihood()
+        return doc_side + topic_side
 
     def getBeta(self):
         return self.beta

@@ -878,6 +878,54 @@ int orc_collapsed_sweep(orc_state *s, int32_t seed_if_first, int32_t n_sweeps) {
 /* ------------------------------------------------------------------------ */
 /* getters (layouts of the Java getters: MSLDA:464-477, UPLDA:226-234, ...)  */
 /* ------------------------------------------------------------------------ */
+/* MALLET 2.0.8 cc.mallet.types.Dirichlet.logGammaStirling (not under /root/reference; restated from its
+ * published source): shift z up to >= 2, Stirling series, undo the shift.  Math.log is restated with the
+ * fdlibm log used everywhere else here. */
+static double log_gamma_stirling(double z) {
+  const double HALF_LOG_TWO_PI = 0.91893853320467274178;
+  int shift = 0;
+  while (z < 2) { z++; shift++; }
+  double result = HALF_LOG_TWO_PI + (z - 0.5) * orc_log(z) - z + 1 / (12 * z) - 1 / (360 * z * z * z) + 1 / (1260 * z * z * z * z * z);
+  while (shift > 0) { shift--; z--; result -= orc_log(z); }
+  return result;
+}
+
+/* UPLDA:1644-1758 modelLogLikelihood, in the Java loop order (one running double), split into the part that
+ * runs over this state's documents (:1674-1694) and the part that runs over the type-topic counts (:1701-1747). */
+void orc_model_log_likelihood(const orc_state *s, double *doc_side, double *topic_side) {
+  const int32_t K = s->K, V = s->V;
+  double alphaSum = 0;
+  for (int32_t k = 0; k < K; k++) alphaSum += s->alpha[k];
+  int32_t *topicCounts = calloc((size_t)K, sizeof(int32_t));
+  double *topicLogGammas = malloc(sizeof(double) * (size_t)K);
+  for (int32_t k = 0; k < K; k++) topicLogGammas[k] = log_gamma_stirling(s->alpha[k]);
+  double ll = 0.0;
+  for (int64_t d = 0; d < s->D; d++) {
+    const int64_t b = s->doc_ptr[d], e = s->doc_ptr[d + 1];
+    for (int64_t i = b; i < e; i++) topicCounts[s->z[i]]++;
+    for (int32_t k = 0; k < K; k++)
+      if (topicCounts[k] > 0) ll += (log_gamma_stirling(s->alpha[k] + topicCounts[k]) - topicLogGammas[k]);
+    ll -= log_gamma_stirling(alphaSum + (double)(e - b));
+    memset(topicCounts, 0, sizeof(int32_t) * (size_t)K);
+  }
+  ll += s->D * log_gamma_stirling(alphaSum);
+  *doc_side = ll;
+  ll = 0.0;
+  int64_t nonZeroTypeTopics = 0;
+  for (int32_t w = 0; w < V; w++)
+    for (int32_t k = 0; k < K; k++) {
+      int32_t c = s->n_wk[(size_t)w * K + k];
+      if (c == 0) continue;
+      nonZeroTypeTopics++;
+      ll += log_gamma_stirling(s->beta + c);
+    }
+  for (int32_t k = 0; k < K; k++) ll -= log_gamma_stirling((s->beta * V) + s->n_k[k]);
+  ll += log_gamma_stirling(s->beta * V) * K;
+  ll -= log_gamma_stirling(s->beta) * nonZeroTypeTopics;
+  *topic_side = ll;
+  free(topicCounts); free(topicLogGammas);
+}
+
 void orc_get_z(const orc_state *s, int32_t *z) { memcpy(z, s->z, sizeof(int32_t) * s->N); }
 void orc_get_type_topic_counts(const orc_state *s, int32_t *o) { memcpy(o, s->n_wk, sizeof(int32_t) * (size_t)s->K * s->V); }
 void orc_get_topic_type_counts(const orc_state *s, int32_t *o) { memcpy(o, s->n_kw, sizeof(int32_t) * (size_t)s->K * s->V); }

@@ -483,3 +483,31 @@ def test_pcgs_on_cats(native, oracle, cats):
     o.sweep(3)
     g.sweep(3)
     compare_state(g, o, "pcgs cats", theta=False)
+
+
+# ---------------------------------------------------------------- model log likelihood on the device
+def test_model_log_likelihood_on_device(native, oracle, cats):
+    """ggs_model_log_likelihood against the oracle's Java-order loop (UPLDA:1644-1758, MALLET logGammaStirling):
+    same terms, reduced in a fixed tree instead of one running double => 1e-11 relative (stated tolerance);
+    run-to-run identical; additive over document shards; and within 1e-6 of scipy's exact lgamma formula."""
+    from ldagroupedgibbssampler_amd.sampler import model_log_likelihood
+    for corpus, K, alpha, beta in ((cats, 20, 5.0, 7.0), (random_corpus(700, 900, 120, seed=4, empty_every=13), 33, 0.1, 0.01)):
+        g, o = make_pair(native, oracle, corpus, K, alpha, beta, 5, zseed=6)
+        g.sweep(3)
+        o.sweep(3)
+        gd, gt = g.model_log_likelihood()
+        od, ot = o.model_log_likelihood()
+        assert abs(gd - od) <= 1e-11 * abs(od) and abs(gt - ot) <= 1e-11 * abs(ot), ((gd, od), (gt, ot))
+        assert g.model_log_likelihood() == (gd, gt)
+        exact = model_log_likelihood(o.get_doc_topic_counts(), o.get_type_topic_counts(), o.get_topic_totals(), alpha, beta)
+        assert abs((gd + gt) - exact) <= 1e-6 * abs(exact)
+        # two document shards with the same z and counts: the document sides add up, the topic side is shared
+        cut = corpus.num_docs // 3
+        parts = []
+        for lo, hi in ((0, cut), (cut, corpus.num_docs)):
+            sub, db, tb = corpus.shard(lo, hi)
+            h = native.GGSHandle(K, corpus.num_types, alpha, beta, 5)
+            h.set_corpus(sub.doc_ptr, sub.tokens, db, tb)
+            h.set_z(o.get_z()[tb:tb + sub.num_tokens], redraw_phi=False)
+            parts.append(h.model_log_likelihood()[0])
+        assert abs(sum(parts) - od) <= 1e-11 * abs(od)

@@ -428,6 +428,10 @@ def test_exact_parallel_column_sum_adversarial(native):
     for V in (1, 63, 64, 65, 129, 4097):
         cases.append(("V=%d" % V, rng.gamma(0.3, size=(V, 3))))
     cases.append(("K=200", rng.gamma(0.05, size=(3000, 200))))
+    cases.append(("V=150001: three super-groups of 1024 segments", rng.gamma(0.01 + (rng.random((150001, 3)) < 0.02) * 5.0)))
+    x = rng.gamma(2.0, size=(70000, 2))
+    x[65536:, 0] *= 1e6                                                  # binade jumps right after the first super-group
+    cases.append(("jump at a super-group boundary", x))
     for tag, x in cases:
         assert_bit_equal(native.debug_column_sum(x=x), _sequential_column_sum(x), "column sum: " + tag)
     for beta in (0.01, 0.5, 7.0):

@@ -550,8 +550,8 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     return bail(GGS_ERR_HIP);
   if (h->flags & GGS_FLAG_PCGS) {
     // pcgs_z_kernel: slice ring + alpha row + int16 [KT][64] document counts per single-wave workgroup
-    const int ns = std::max(3, (h->K + kSliceTopics - 1) / kSliceTopics), kt = ns * kSliceTopics;
-    h->pcgs_lds = kStreamRingSlots * kSliceBytes + kt * 8 + kt * 128;
+    const int ns = std::max(kPcgsRingSlots - 1, (h->K + kSliceTopics - 1) / kSliceTopics), kt = ns * kSliceTopics;
+    h->pcgs_lds = kPcgsRingSlots * kSliceBytes + kt * 8 + kt * 128;
     if (h->pcgs_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);
     h->pcgs_waves_per_cu = std::max(1, std::min(8, kMaxLdsBytes / ((h->pcgs_lds + 2047) / 2048 * 2048)));
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(pcgs_z_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, h->pcgs_lds) != hipSuccess)

@@ -9,7 +9,7 @@
 // by length, longest first, so the 64 of a group are equally long) and walks their tokens in
 // lockstep -- step t handles token t of each of the 64 documents, which is exactly the access
 // pattern of a GGS chunk (64 tokens, 64 different phiT rows).  The rows stream through the
-// 4-slot LDS ring of ggs_z_stream.hpp twice per step (pass 1 sums, pass 2 re-multiplies and
+// slice ring of ggs_z_stream.hpp (3 slots here) twice per step (pass 1 sums, pass 2 re-multiplies and
 // walks; the product (n + alpha) * phi is the same two roundings in both passes: int + double,
 // then the multiply), the next step's first slices are in flight while this step ends.
 // Per-lane state: the document's K topic counts, int16, in LDS as [k][lane] (lane-contiguous,
@@ -35,15 +35,16 @@ struct PcgsParams {
 };
 
 constexpr int kPcgsMaxDocLen = 32767;  // counts are int16
+constexpr int kPcgsRingSlots = 3;      // two slices ahead: 24 KiB of ring, so that four waves fit a CU at K = 100
 
 __global__ __launch_bounds__(64) void pcgs_z_kernel(PcgsParams p) {
-  constexpr int kAhead = 3;
+  constexpr int kAhead = kPcgsRingSlots - 1;
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
   const int K = p.K;
-  const int NS = max(3, (K + kSliceTopics - 1) / kSliceTopics);    // slices per pass; at least kAhead (padding topics score 0)
+  const int NS = max(kAhead, (K + kSliceTopics - 1) / kSliceTopics);   // slices per pass; at least kAhead (padding topics score 0)
   const int KT = NS * kSliceTopics;
-  double *alb = reinterpret_cast<double *>(smem + kStreamRingSlots * kSliceBytes);   // alpha, zero padded to KT
+  double *alb = reinterpret_cast<double *>(smem + kPcgsRingSlots * kSliceBytes);   // alpha, zero padded to KT
   int16_t *cnt = reinterpret_cast<int16_t *>(alb + KT);                              // [KT][64]
   const unsigned char *phib = reinterpret_cast<const unsigned char *>(p.phiT);
   const size_t rowbytes = (size_t)p.Kp * 8;
@@ -100,18 +101,15 @@ __global__ __launch_bounds__(64) void pcgs_z_kernel(PcgsParams p) {
       int newc = 0;
       for (int j = 0; j < 2 * NS; ++j) {
         const int s = j < NS ? j : j - NS;
-        const int cur = (gs + j) & (kStreamRingSlots - 1);
-        const int nxt = (gs + j + kAhead) & (kStreamRingSlots - 1);
+        const int cur = (gs + j) % kPcgsRingSlots;
+        const int nxt = (gs + j + kAhead) % kPcgsRingSlots;
         const int ja = j + kAhead;
         if (ja < 2 * NS) issue_slice(ja < NS ? ja : ja - NS, nxt, ra);
         else if (has1) issue_slice(ja - 2 * NS, nxt, ran);
-        if (has1 || ja < 2 * NS) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-        else {
-          const int rem = 2 * NS - 1 - j;
-          if (rem == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-          else if (rem == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        // all but the youngest 8*kAhead DMAs done => slice j has landed; at the tail of the last step fewer follow
+        if (has1 || ja < 2 * NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * kAhead) : "memory");
+        else if (2 * NS - 1 - j == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (active) {
           const unsigned char *rb = my_row + cur * kSliceBytes;
           const unsigned char *ab = reinterpret_cast<const unsigned char *>(alb) + s * kSliceTopics * 8;
@@ -151,7 +149,7 @@ __global__ __launch_bounds__(64) void pcgs_z_kernel(PcgsParams p) {
         }
         asm volatile("" ::: "memory");
       }
-      gs = (gs + 2 * NS) & (kStreamRingSlots - 1);
+      gs = (gs + 2 * NS) % kPcgsRingSlots;
 
       if (active) {
         int new_topic = newc - 1;

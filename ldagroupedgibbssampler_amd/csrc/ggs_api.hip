@@ -481,7 +481,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       h->z_stream = mode == 2 ? h->K > 2 * kSliceTopics : (h->z_stream && mode != 0);
     }
     if (h->z_stream) {
-      // 64-token chunks, the same 4-slot ring + the theta row zero-padded to whole slices; no
+      // 64-token chunks, a 2-slot slice ring + the theta row zero-padded to whole slices; no
       // score registers, so 8 waves per CU fit the register file and LDS bounds the residency
       h->z_tile_tokens = 64;
       h->z_lds = kStreamRingSlots * kSliceBytes + ((h->K + kSliceTopics - 1) / kSliceTopics) * kSliceTopics * 8;
@@ -489,7 +489,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       h->z_waves_per_cu = std::max(1, std::min(8, kMaxLdsBytes / alloc_of(h->z_lds)));
       if (const char *e = std::getenv("GGS_DEBUG_WPC")) h->z_waves_per_cu = std::max(1, std::atoi(e));
     } else if (h->z_sliced) {
-      // 64-token chunks, a 4-slot ring of 16-topic slices + the theta row; one wave per SIMD
+      // 64-token chunks, per wave the two theta rows and the slice ring, per workgroup (4 waves, one per SIMD) the hot-word table
       // (the score registers take most of the 512-entry file)
       h->z_tile_tokens = 64;
       const int kmax = ((h->K + 7) / 8) * 8, ns = (kmax + kSliceTopics - 1) / kSliceTopics;

@@ -4,7 +4,8 @@
 //
 // Same machinery as ggs_z_sliced.hpp -- persistent single-wave workgroups striding the chunk
 // table, lane t owns token t of a <= 64-token chunk of ONE document, phiT rows streamed by
-// LDS-DMA through a 4-slot ring of 16-topic slices (8 KiB) kept 3 slices ahead, the same
+// LDS-DMA through a 2-slot ring of 16-topic slices (8 KiB), one slice ahead (measured: a small ring
+// that lets 6-8 waves share a CU beats a deep one with 4 -- two waves per SIMD issue 1.7x what one does), the same
 // per-row rotation for conflict-free reads -- but the row is streamed TWICE per chunk:
 //
 //   pass 1 (slices 0..NS-1):  sum += theta[k]*phi[k][w_t], k ascending          (GGS:96-101)
@@ -21,10 +22,13 @@
 
 namespace ggs {
 
-constexpr int kStreamRingSlots = 4;
+#ifndef GGS_STREAM_RING
+#define GGS_STREAM_RING 2
+#endif
+constexpr int kStreamRingSlots = GGS_STREAM_RING;
 
 __global__ __launch_bounds__(64) void z_stream_kernel(ZParams p) {
-  constexpr int kAhead = 3;
+  constexpr int kAhead = kStreamRingSlots - 1;
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
   const int K = p.K, Kp = p.Kp;
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(64) void z_stream_kernel(ZParams p) {
   row_addresses(w0, ra);
   int g = 0;                                                       // ring slot of this chunk's first slice
 #pragma unroll
-  for (int s = 0; s < kAhead; ++s) issue_slice(s, (g + s) & (kStreamRingSlots - 1), ra);
+  for (int s = 0; s < kAhead; ++s) issue_slice(s, (g + s) % kStreamRingSlots, ra);
 
   for (;;) {
     const bool has1 = c + 1 < cend;
@@ -111,17 +115,17 @@ __global__ __launch_bounds__(64) void z_stream_kernel(ZParams p) {
     int cnt = 0;
     for (int j = 0; j < 2 * NS; ++j) {
       const int s = j < NS ? j : j - NS;
-      const int cur = (g + j) & (kStreamRingSlots - 1);
-      const int nxt = (g + j + kAhead) & (kStreamRingSlots - 1);
+      const int cur = (g + j) % kStreamRingSlots;
+      const int nxt = (g + j + kAhead) % kStreamRingSlots;
       const int ja = j + kAhead;
       if (ja < 2 * NS) issue_slice(ja < NS ? ja : ja - NS, nxt, ra);
       else if (has1) issue_slice(ja - 2 * NS, nxt, ran);
       // all but the youngest 8*kAhead DMAs done => slice j has landed; at the tail of the last
       // chunk fewer slices follow it
-      if (has1 || ja < 2 * NS) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      if (has1 || ja < 2 * NS) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * kAhead) : "memory");
       else {
-        const int rem = 2 * NS - 1 - j;                            // 0, 1 or 2 slices still behind this one
-        if (rem == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        const int rem = 2 * NS - 1 - j;                            // slices still behind this one: fewer than kAhead
+        if (rem >= 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
         else if (rem == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       }
@@ -157,7 +161,7 @@ __global__ __launch_bounds__(64) void z_stream_kernel(ZParams p) {
       }
       asm volatile("" ::: "memory");                               // every read of this ring slot is issued before it is refilled
     }
-    g = (g + 2 * NS) & (kStreamRingSlots - 1);
+    g = (g + 2 * NS) % kStreamRingSlots;
 
     if (lane < len0) {
       int new_topic = cnt - 1;

@@ -142,7 +142,7 @@ def test_wide_topic_rows_use_the_streaming_kernel(native, oracle, K):
     round of theta staging)."""
     c = random_corpus(120, 300, 150, seed=K, empty_every=9)
     g, o = make_pair(native, oracle, c, K, 0.1, 0.01, 7 + K, flags=native.FLAG_PARANOID, zseed=K)
-    assert g.launch_info()["lds_bytes_z"] == 4 * 8192 + (K + 15) // 16 * 128
+    assert g.launch_info()["lds_bytes_z"] == 2 * 8192 + (K + 15) // 16 * 128
     g.sweep(2)
     o.sweep(2)
     compare_state(g, o, "wide K=%d" % K)

@@ -515,10 +515,14 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
   }
   {
     int B = 64;
-    auto lds_of = [&](int b) { const int bp = b | 1; return (int)((size_t)h->K * bp * 12 + (size_t)b * 20); };
-    while (B > 1 && lds_of(B) > 64 * 1024) B >>= 1;
+    auto lds_of = [&](int b) { const int bp = b | 1; return (int)((size_t)h->K * bp * 8 + (size_t)b * 20); };
+    while (B > 1 && lds_of(B) > 32 * 1024) B >>= 1;
     if (lds_of(B) > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);
-    h->theta_docs_per_block = B; h->theta_lds = lds_of(B);
+    // The request is padded to a quarter of the CU's LDS: at most 4 workgroups (16 waves) of the theta draw per CU.
+    // It runs on the side stream beside the Phi phase, which is the critical path; stream priority orders dispatch,
+    // not running waves, and measured with 5-6 resident workgroups theta finishes early (0.53 ms instead of 0.75)
+    // while the Phi phase it starves gets longer (0.67 -> 0.72 ms).
+    h->theta_docs_per_block = B; h->theta_lds = std::max(lds_of(B), kMaxLdsBytes / 4 - 1024);
   }
   if (h->z_sliced && hipFuncSetAttribute(sliced_kernel_for(h->K), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess)
     return bail(GGS_ERR_HIP);

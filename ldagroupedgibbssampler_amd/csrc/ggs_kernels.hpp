@@ -48,8 +48,9 @@ enum StatusBits : uint32_t {
 //   phase 3  all lanes: Gamma(partition*magnitude) draws, one (doc, k) pair each
 //   phase 4  one lane per document: sum of the gammas, in k order
 //   phase 5  all lanes: normalise, clamp <=0 to Double.MIN_VALUE, coalesced store
-// LDS: hist int32 [K][BP], gam fp64 [K][BP], BP = docs_per_block | 1 (odd => the
-// k-major walks of phases 2, 4, 5 are bank-conflict free).
+// LDS: one 8-byte cell per (k, document), [K][BP] with BP = docs_per_block | 1 (odd => the
+// k-major walks of phases 2, 4, 5 are bank-conflict free): the count n_dk (int32, low word) until
+// its lane has drawn the gamma that replaces it.
 // ------------------------------------------------------------------------------
 struct ThetaParams {
   const int64_t *doc_ptr;
@@ -68,16 +69,16 @@ __global__ __launch_bounds__(BLOCK) void theta_kernel(ThetaParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int K = p.K, B = p.docs_per_block, BP = B | 1;
   double *gam = reinterpret_cast<double *>(smem);                    // [K][BP]
+  int32_t *hist = reinterpret_cast<int32_t *>(smem);                 // the same cells: count in word 0 of cell i = hist[2 * i]
   double *mag = gam + (size_t)K * BP;                                // [B]
   double *tot = mag + B;                                             // [B]
-  int32_t *hist = reinterpret_cast<int32_t *>(tot + B);              // [K][BP]
-  int32_t *len = hist + (size_t)K * BP;                              // [B]
+  int32_t *len = reinterpret_cast<int32_t *>(tot + B);               // [B]
 
   const int tid = threadIdx.x;
   const int64_t d0 = (int64_t)blockIdx.x * B;
   const int nb = (int)min((int64_t)B, p.num_docs - d0);
 
-  for (int i = tid; i < K * BP; i += BLOCK) hist[i] = 0;
+  for (int i = tid; i < K * BP; i += BLOCK) hist[2 * i] = 0;
   __syncthreads();
 
   constexpr int NW = BLOCK / 64;
@@ -85,13 +86,13 @@ __global__ __launch_bounds__(BLOCK) void theta_kernel(ThetaParams p) {
   for (int b = wave; b < nb; b += NW) {
     const int64_t beg = p.doc_ptr[d0 + b], end = p.doc_ptr[d0 + b + 1];
     if (lane == 0) len[b] = (int32_t)(end - beg);
-    for (int64_t i = beg + lane; i < end; i += 64) atomicAdd(&hist[p.z[i] * BP + b], 1);
+    for (int64_t i = beg + lane; i < end; i += 64) atomicAdd(&hist[2 * (p.z[i] * BP + b)], 1);
   }
   __syncthreads();
 
   if (tid < nb && len[tid] > 0) {
     double m = 0;
-    for (int k = 0; k < K; ++k) m += (double)hist[k * BP + tid] + p.alpha[k];  // Dirichlet(double[]): magnitude
+    for (int k = 0; k < K; ++k) m += (double)hist[2 * (k * BP + tid)] + p.alpha[k];  // Dirichlet(double[]): magnitude
     mag[tid] = m;
   }
   __syncthreads();
@@ -99,7 +100,7 @@ __global__ __launch_bounds__(BLOCK) void theta_kernel(ThetaParams p) {
   for (int i = tid; i < nb * K; i += BLOCK) {
     const int k = i / nb, b = i - k * nb;
     if (len[b] == 0) continue;                                       // GGS:52-53
-    const double pk = (double)hist[k * BP + b] + p.alpha[k];         // GGS:68
+    const double pk = (double)hist[2 * (k * BP + b)] + p.alpha[k];   // GGS:68
     const double m = mag[b];
     const double shape = (pk / m) * m;                               // partition[i] * magnitude
     double g;

@@ -331,6 +331,21 @@ def test_error_behaviour(native):
         g.sweep(1)
     assert e.value.code == native.ERR_INVALID_TOPIC
     assert "Topic sampled is invalid" in str(e.value)
+    # scheme=pcgs limits: the per-document counts live in LDS as int16
+    with pytest.raises(native.GGSError) as e:
+        native.GGSHandle(1100, 10, 0.1, 0.1, 1, flags=native.FLAG_PCGS)
+    assert e.value.code == native.ERR_UNSUPPORTED
+    p = native.GGSHandle(4, 20, 0.1, 0.1, 1, flags=native.FLAG_PCGS)
+    with pytest.raises(native.GGSError) as e:
+        p.set_corpus(np.array([0, 40000], np.int64), np.zeros(40000, np.int32))
+    assert e.value.code == native.ERR_UNSUPPORTED and "32768" in str(e.value)
+    p.set_corpus(c.doc_ptr, c.tokens)
+    p.init_z_java_lcg(1)
+    p.init_phi()
+    p.set_phi(np.zeros((4, 20)))
+    with pytest.raises(native.GGSError) as e:
+        p.sweep(1)                                     # UPLDA:1529-1531
+    assert e.value.code == native.ERR_INVALID_TOPIC
 
 
 # ---------------------------------------------------------------- full size (properties only)

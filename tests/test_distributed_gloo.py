@@ -21,8 +21,9 @@ class OracleEngine:
     after sweep_begin / set_z(redraw=False) the exchange buffer holds THIS shard's
     contribution; after the all-reduce, sweep_end / init_phi proceed on corpus-wide counts."""
 
-    def __init__(self, oracle, K, V, alpha, beta, seed):
+    def __init__(self, oracle, K, V, alpha, beta, seed, scheme="ggs"):
         self.o = oracle.OracleSampler(K, V, alpha, beta, seed)
+        self.o.set_scheme(scheme)
         self.K, self.V = K, V
         self.buf = np.zeros((V, K), np.int32)        # what the exchange all-reduces
         self._mode = None
@@ -70,7 +71,7 @@ class GlooExchange:
     allreduce_startup = allreduce_sweep
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, scheme):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from ldagroupedgibbssampler_amd.corpus import random_corpus
@@ -81,7 +82,7 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     c = random_corpus(157, 120, 60, seed=17, empty_every=10)
     K, alpha, beta, seed = 9, 0.1, 0.01, 4242
-    eng = OracleEngine(O, K, c.num_types, alpha, beta, seed)
+    eng = OracleEngine(O, K, c.num_types, alpha, beta, seed, scheme)
     sh = ShardedGGS(eng, GlooExchange, c, rank, world)
     sh.set_z_global(java_lcg_initial_z(c.num_tokens, K, 77))
     sh.sweep(3)
@@ -90,7 +91,8 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_sweep_equals_unsharded(oracle, tmp_path):
+@pytest.mark.parametrize("scheme", ["ggs", "pcgs"])
+def test_two_rank_sharded_sweep_equals_unsharded(oracle, tmp_path, scheme):
     import torch.multiprocessing as mp
     from ldagroupedgibbssampler_amd.corpus import even_split, random_corpus
     from ldagroupedgibbssampler_amd.sharded import java_lcg_initial_z
@@ -99,11 +101,12 @@ def test_two_rank_sharded_sweep_equals_unsharded(oracle, tmp_path):
     port = s.getsockname()[1]
     s.close()
     world = 2
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path), scheme), nprocs=world, join=True)
 
     c = random_corpus(157, 120, 60, seed=17, empty_every=10)
     K = 9
     ref = oracle.OracleSampler(K, c.num_types, 0.1, 0.01, 4242)
+    ref.set_scheme(scheme)
     ref.set_corpus(c.doc_ptr, c.tokens)
     ref.set_z(java_lcg_initial_z(c.num_tokens, K, 77), redraw_phi=True)
     ref.sweep(3)
@@ -111,7 +114,8 @@ def test_two_rank_sharded_sweep_equals_unsharded(oracle, tmp_path):
     bounds = even_split(c.num_docs, world)
     assert [int(p["doc_base"]) for p in parts] == bounds[:-1]
     assert np.array_equal(np.concatenate([p["z"] for p in parts]), ref.get_z())
-    assert np.array_equal(np.concatenate([p["theta"] for p in parts]).view(np.int64), ref.get_theta().view(np.int64))
+    if scheme == "ggs":
+        assert np.array_equal(np.concatenate([p["theta"] for p in parts]).view(np.int64), ref.get_theta().view(np.int64))
     for p in parts:
         assert np.array_equal(p["nwk"], ref.get_type_topic_counts())
         assert np.array_equal(p["phi"].view(np.int64), ref.get_phi().view(np.int64))

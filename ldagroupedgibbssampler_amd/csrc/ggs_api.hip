@@ -69,6 +69,10 @@ struct ggs_handle {
   // on z_t only, GGS:57-72)
   double *d_theta_next = nullptr;
   hipStream_t side = nullptr;
+  hipStream_t side_hot = nullptr;                      // z_hot_kernel runs here, beside z_sliced_kernel on the main stream
+  hipEvent_t ev_hot_fork = nullptr, ev_hot_join = nullptr;
+  bool z_split = true;                                 // GGS_DEBUG_SPLIT=0: one kernel takes cold and hot chunks in turn
+  int32_t hot_wave_lds = 0;
   bool overlap_theta = true;
   int64_t theta_ahead_iter = INT64_MIN;     // iteration the side-stream theta was drawn for, or none
   double *d_alpha = nullptr, *d_theta = nullptr, *d_phiT = nullptr, *d_mag = nullptr, *d_tot = nullptr, *d_phi_mean = nullptr;
@@ -226,35 +230,24 @@ int launch_theta(ggs_handle *h, hipStream_t stream, double *dst, int32_t iterati
   return GGS_OK;
 }
 
-// z_sliced_kernel<KMAX> for KMAX = K rounded up to a multiple of 8
-const void *sliced_kernel_for(int K) {
-  switch ((K + 7) / 8) {
-    case 1: return reinterpret_cast<const void *>(z_sliced_kernel<8>);
-    case 2: return reinterpret_cast<const void *>(z_sliced_kernel<16>);
-    case 3: return reinterpret_cast<const void *>(z_sliced_kernel<24>);
-    case 4: return reinterpret_cast<const void *>(z_sliced_kernel<32>);
-    case 5: return reinterpret_cast<const void *>(z_sliced_kernel<40>);
-    case 6: return reinterpret_cast<const void *>(z_sliced_kernel<48>);
-    case 7: return reinterpret_cast<const void *>(z_sliced_kernel<56>);
-    case 8: return reinterpret_cast<const void *>(z_sliced_kernel<64>);
-    case 9: return reinterpret_cast<const void *>(z_sliced_kernel<72>);
-    case 10: return reinterpret_cast<const void *>(z_sliced_kernel<80>);
-    case 11: return reinterpret_cast<const void *>(z_sliced_kernel<88>);
-    case 12: return reinterpret_cast<const void *>(z_sliced_kernel<96>);
-    case 13: return reinterpret_cast<const void *>(z_sliced_kernel<104>);
-    case 14: return reinterpret_cast<const void *>(z_sliced_kernel<112>);
-    case 15: return reinterpret_cast<const void *>(z_sliced_kernel<120>);
-    case 16: return reinterpret_cast<const void *>(z_sliced_kernel<128>);
-    case 17: return reinterpret_cast<const void *>(z_sliced_kernel<136>);
-    case 18: return reinterpret_cast<const void *>(z_sliced_kernel<144>);
-    case 19: return reinterpret_cast<const void *>(z_sliced_kernel<152>);
-    case 20: return reinterpret_cast<const void *>(z_sliced_kernel<160>);
-    case 21: return reinterpret_cast<const void *>(z_sliced_kernel<168>);
-    case 22: return reinterpret_cast<const void *>(z_sliced_kernel<176>);
-    case 23: return reinterpret_cast<const void *>(z_sliced_kernel<184>);
-    default: return reinterpret_cast<const void *>(z_sliced_kernel<192>);
+// z_sliced_kernel<KMAX> / z_hot_kernel<KMAX> for KMAX = K rounded up to a multiple of 8
+#define GGS_KMAX_SWITCH(KERNEL)                                                                                                     \
+  switch ((K + 7) / 8) {                                                                                                            \
+    case 1: return reinterpret_cast<const void *>(KERNEL<8>);      case 2: return reinterpret_cast<const void *>(KERNEL<16>);       \
+    case 3: return reinterpret_cast<const void *>(KERNEL<24>);     case 4: return reinterpret_cast<const void *>(KERNEL<32>);       \
+    case 5: return reinterpret_cast<const void *>(KERNEL<40>);     case 6: return reinterpret_cast<const void *>(KERNEL<48>);       \
+    case 7: return reinterpret_cast<const void *>(KERNEL<56>);     case 8: return reinterpret_cast<const void *>(KERNEL<64>);       \
+    case 9: return reinterpret_cast<const void *>(KERNEL<72>);     case 10: return reinterpret_cast<const void *>(KERNEL<80>);      \
+    case 11: return reinterpret_cast<const void *>(KERNEL<88>);    case 12: return reinterpret_cast<const void *>(KERNEL<96>);      \
+    case 13: return reinterpret_cast<const void *>(KERNEL<104>);   case 14: return reinterpret_cast<const void *>(KERNEL<112>);     \
+    case 15: return reinterpret_cast<const void *>(KERNEL<120>);   case 16: return reinterpret_cast<const void *>(KERNEL<128>);     \
+    case 17: return reinterpret_cast<const void *>(KERNEL<136>);   case 18: return reinterpret_cast<const void *>(KERNEL<144>);     \
+    case 19: return reinterpret_cast<const void *>(KERNEL<152>);   case 20: return reinterpret_cast<const void *>(KERNEL<160>);     \
+    case 21: return reinterpret_cast<const void *>(KERNEL<168>);   case 22: return reinterpret_cast<const void *>(KERNEL<176>);     \
+    case 23: return reinterpret_cast<const void *>(KERNEL<184>);   default: return reinterpret_cast<const void *>(KERNEL<192>);     \
   }
-}
+const void *sliced_kernel_for(int K) { GGS_KMAX_SWITCH(z_sliced_kernel) }
+const void *hot_kernel_for(int K) { GGS_KMAX_SWITCH(z_hot_kernel) }
 
 int launch_pcgs_z(ggs_handle *h) {
   if (h->N == 0) return GGS_OK;
@@ -289,9 +282,25 @@ int launch_z(ggs_handle *h) {
     // one 4-wave workgroup per CU (a wave per SIMD), persistent; the hot-word table fills the LDS the rings leave
     zp.num_chunks = h->Cs;
     void *args[] = {&zp};
-    const int64_t most = std::max(h->Cc, h->Cs - h->Cc);
-    const dim3 sgrid((unsigned)std::min<int64_t>((most + kSlicedWaves - 1) / kSlicedWaves, (int64_t)h->num_cus)), sblock(kSlicedWaves * 64);
-    HIP_TRY(h, hipLaunchKernel(sliced_kernel_for(h->K), sgrid, sblock, args, (size_t)(kSlicedWaves * h->wave_lds + h->num_hot * h->hot_pitch), h->stream));
+    const dim3 sblock(kSlicedWaves * 64);
+    auto grid_of = [&](int64_t chunks) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((chunks + kSlicedWaves - 1) / kSlicedWaves, (int64_t)h->num_cus))); };
+    if (h->z_split && h->Cs > h->Cc && h->Cc > 0) {
+      // cold chunks on the main stream, hot chunks beside them (z_hot_kernel): two waves per SIMD
+      ZParams hp = zp;
+      hp.wave_lds = h->hot_wave_lds; hp.hot_off = kSlicedWaves * h->hot_wave_lds;
+      void *hargs[] = {&hp};
+      HIP_TRY(h, hipEventRecord(h->ev_hot_fork, h->stream));
+      HIP_TRY(h, hipStreamWaitEvent(h->side_hot, h->ev_hot_fork, 0));
+      zp.num_chunks = h->Cc; zp.num_hot = 0;
+      static const int only = std::getenv("GGS_DEBUG_ONLY") ? std::atoi(std::getenv("GGS_DEBUG_ONLY")) : 0;   // timing experiments: 1 cold only, 2 hot only
+      if (only != 2) HIP_TRY(h, hipLaunchKernel(sliced_kernel_for(h->K), grid_of(h->Cc), sblock, args, (size_t)(kSlicedWaves * h->wave_lds), h->stream));
+      if (only != 1) HIP_TRY(h, hipLaunchKernel(hot_kernel_for(h->K), grid_of(h->Cs - h->Cc), sblock, hargs, (size_t)(hp.hot_off + h->num_hot * h->hot_pitch), h->side_hot));
+      HIP_TRY(h, hipEventRecord(h->ev_hot_join, h->side_hot));
+      HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_hot_join, 0));
+    } else {
+      HIP_TRY(h, hipLaunchKernel(sliced_kernel_for(h->K), grid_of(std::max(h->Cc, h->Cs - h->Cc)), sblock, args,
+                                 (size_t)(kSlicedWaves * h->wave_lds + h->num_hot * h->hot_pitch), h->stream));
+    }
   } else if (h->z_stream) hipLaunchKernelGGL(z_stream_kernel, grid, block, h->z_lds, h->stream, zp);
   else if (nt <= 1) hipLaunchKernelGGL(z_kernel<1>, grid, block, h->z_lds, h->stream, zp);
   else if (nt <= 2) hipLaunchKernelGGL(z_kernel<2>, grid, block, h->z_lds, h->stream, zp);
@@ -498,7 +507,12 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       h->ring_base = (std::max(kChunkDocs * kmax * 8, ns * 128) + 255) / 256 * 256;
       h->wave_lds = h->ring_base + kRingSlots * kSliceBytes;
       h->hot_pitch = ((h->K + 7) / 8) * 64 + 16;                     // KMAX doubles + one unit: an odd number of 16-byte units
-      h->hot_cap = std::min(255, (kMaxLdsBytes - kSlicedWaves * h->wave_lds) / h->hot_pitch);
+      if (const char *e = std::getenv("GGS_DEBUG_SPLIT")) h->z_split = std::atoi(e) != 0;
+      h->hot_wave_lds = (kChunkDocs * kmax * 8 + 255) / 256 * 256;   // z_hot_kernel: two theta rows per wave, then the table
+      // split: the two workgroups must fit one CU together, each request rounded up to the LDS allocation granule
+      h->hot_cap = h->z_split ? (kMaxLdsBytes - alloc_of(kSlicedWaves * h->wave_lds) - kSlicedWaves * h->hot_wave_lds) / kGranule * kGranule / h->hot_pitch
+                              : (kMaxLdsBytes - kSlicedWaves * h->wave_lds) / h->hot_pitch;
+      h->hot_cap = std::max(0, std::min(255, h->hot_cap));
       if (const char *e = std::getenv("GGS_DEBUG_HOT")) h->hot_cap = std::max(0, std::min(h->hot_cap, std::atoi(e)));
       h->z_lds = kSlicedWaves * h->wave_lds + h->hot_cap * h->hot_pitch;
       h->z_waves_per_cu = kSlicedWaves;
@@ -524,7 +538,8 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     // while the Phi phase it starves gets longer (0.67 -> 0.72 ms).
     h->theta_docs_per_block = B; h->theta_lds = std::max(lds_of(B), kMaxLdsBytes / 4 - 1024);
   }
-  if (h->z_sliced && hipFuncSetAttribute(sliced_kernel_for(h->K), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess)
+  if (h->z_sliced && (hipFuncSetAttribute(sliced_kernel_for(h->K), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess ||
+                      hipFuncSetAttribute(hot_kernel_for(h->K), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess))
     return bail(GGS_ERR_HIP);
   const void *zk[] = {reinterpret_cast<const void *>(z_kernel<1>), reinterpret_cast<const void *>(z_kernel<2>),
                       reinterpret_cast<const void *>(z_kernel<4>), reinterpret_cast<const void *>(z_kernel<8>),
@@ -574,6 +589,9 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     // (a CU-masked side stream was tried: hipExtStreamCreateWithCUMask gives a blocking stream that
     // serialises with the legacy default stream, so the overlap is lost -- priority alone it is)
     if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo) != hipSuccess) return bail(GGS_ERR_HIP);
+    if (hipStreamCreateWithFlags(&h->side_hot, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&h->ev_hot_fork) != hipSuccess ||
+        hipEventCreate(&h->ev_hot_join) != hipSuccess)
+      return bail(GGS_ERR_HIP);
   }
   *out = h;
   return GGS_OK;
@@ -595,6 +613,9 @@ void ggs_destroy(ggs_handle *h) {
     if (E.th1) (void)hipEventDestroy(E.th1);
   }
   if (h->side) (void)hipStreamDestroy(h->side);
+  if (h->side_hot) (void)hipStreamDestroy(h->side_hot);
+  if (h->ev_hot_fork) (void)hipEventDestroy(h->ev_hot_fork);
+  if (h->ev_hot_join) (void)hipEventDestroy(h->ev_hot_join);
   delete h;
 }
 

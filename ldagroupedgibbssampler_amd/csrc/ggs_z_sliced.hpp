@@ -355,4 +355,135 @@ __global__ __launch_bounds__(kSlicedWaves * 64) void z_sliced_kernel(ZParams p) 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// z_hot_kernel: the hot chunks on their own, launched on a second stream BESIDE z_sliced_kernel (which
+// then takes the cold chunks only).  A lone wave issues one VALU instruction per ~8 cycles and sits out
+// its own DMA issue; a second wave on the SIMD fills those slots (two waves per SIMD get 1.7x the issue
+// rate of one).  The cold kernel's waves hold 352 of a SIMD's 512 registers, so the guest must live in
+// <= 128 (amdgpu_waves_per_eu(4)): it keeps no score registers and reads its phi rows from the LDS table
+// twice -- pass 1 sums, pass 2 re-multiplies (the same single IEEE product) and walks.  One 4-wave
+// workgroup per CU; its LDS (the table + 2 theta rows per wave) is what the cold kernel's rings leave.
+// If the two kernels happen not to share the CUs the results are the same and the hot chunks simply run
+// before or after the cold ones.
+template <int KMAX>
+__global__ __launch_bounds__(kSlicedWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void z_hot_kernel(ZParams p) {
+  constexpr int NS = (KMAX + kSliceTopics - 1) / kSliceTopics;
+  constexpr int NT = (KMAX + 63) / 64;
+  constexpr int kThetaRow = KMAX * 8;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int K = p.K;
+  unsigned char *thb = smem + wave * p.wave_lds;                   // this wave's kChunkDocs theta rows
+  const unsigned char *phib = reinterpret_cast<const unsigned char *>(p.phiT);
+  const size_t rowbytes = (size_t)p.Kp * 8;
+  const const_i32_t *cdocs = (const const_i32_t *)p.c_docs;
+  const int64_t stride = (int64_t)gridDim.x * kSlicedWaves;
+  const int64_t C = p.num_chunks;
+  {
+    constexpr int upr = KMAX / 2;
+    for (int i = threadIdx.x; i < p.num_hot * upr; i += kSlicedWaves * 64) {
+      const int r = i / upr, u = i - r * upr;
+      *reinterpret_cast<D2 *>(smem + p.hot_off + r * p.hot_pitch + u * 16) =
+          *reinterpret_cast<const D2 *>(phib + (size_t)p.hot_words[r] * rowbytes + (size_t)u * 16);
+    }
+  }
+  __syncthreads();
+  auto load_theta = [&](const int d0, const int d1, double (&tv)[kChunkDocs][NT]) {
+    const double *t0 = p.theta + (size_t)d0 * K, *t1 = p.theta + (size_t)d1 * K;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      tv[0][t] = (t * 64 + lane < K) ? t0[t * 64 + lane] : 0.0;
+      tv[1][t] = (t * 64 + lane < K) ? t1[t * 64 + lane] : 0.0;
+    }
+  };
+  int64_t c = p.num_cold + (int64_t)blockIdx.x * kSlicedWaves + wave;
+  if (c >= C) return;
+  int w0 = p.ct_tok[c * 64 + lane], id0 = p.ct_idx[c * 64 + lane], ip0 = p.ct_ip[c * 64 + lane];
+  double tv0[kChunkDocs][NT];
+  load_theta(cdocs[2 * c], cdocs[2 * c + 1], tv0);
+  for (;;) {
+    const bool has1 = c + stride < C;
+    int w1 = 0, id1 = -1, ip1 = 0;
+    double tv1[kChunkDocs][NT];
+    if (has1) {
+      const int64_t c1 = c + stride;
+      w1 = p.ct_tok[c1 * 64 + lane]; id1 = p.ct_idx[c1 * 64 + lane]; ip1 = p.ct_ip[c1 * 64 + lane];
+      load_theta(cdocs[2 * c1], cdocs[2 * c1 + 1], tv1);
+    } else {
+      load_theta(0, 0, tv1);
+    }
+#pragma unroll
+    for (int r = 0; r < kChunkDocs; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+        if (t * 64 + lane < KMAX) reinterpret_cast<double *>(thb + r * kThetaRow)[t * 64 + lane] = tv0[r][t];
+    const unsigned char *trow = thb + ((unsigned)w0 >> kSlotShift) * kThetaRow;
+    const unsigned char *hrow = smem + p.hot_off + (w0 & ((1 << kSlotShift) - 1)) * p.hot_pitch;
+    if (id0 >= 0) {
+      double sum = 0.0;
+      static_for<0, NS>([&](auto sidx) {                           // GGS:96-101
+        constexpr int s = decltype(sidx)::value;
+        D2 ph[kSliceUnits], th[kSliceUnits];
+#pragma unroll
+        for (int u = 0; u < kSliceUnits; ++u)
+          if (s * kSliceTopics + 2 * u + 1 < KMAX) {
+            ph[u] = lds_d2(hrow + s * (kSliceTopics * 8) + u * 16);
+            th[u] = lds_d2(trow + s * (kSliceTopics * 8) + u * 16);
+          }
+#pragma unroll
+        for (int u = 0; u < kSliceUnits; ++u)
+          if (s * kSliceTopics + 2 * u + 1 < KMAX) {
+            sum += th[u].a * ph[u].a;
+            sum += th[u].b * ph[u].b;
+          }
+        asm volatile("" ::: "memory");                             // one slice's reads in flight at a time: the register budget is 128
+      });
+      const uint64_t gtok = (uint64_t)(p.tok_base + id0);
+      const U4 o = philox4x32_10((uint32_t)gtok, (uint32_t)(gtok >> 32), (uint32_t)GGS_PURPOSE_Z << 24, p.iteration,
+                                 (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
+      double t = 0.0 - u53(o.x, o.y) * sum;                        // the negated walk of z_sliced_kernel's finish()
+      int cnt = 0;
+      bool live = true;
+      static_for<0, NS>([&](auto sidx) {                           // GGS:108-113
+        constexpr int s = decltype(sidx)::value;
+        if (live) {                                                // wave-uniform
+          D2 ph[kSliceUnits], th[kSliceUnits];
+#pragma unroll
+          for (int u = 0; u < kSliceUnits; ++u)
+            if (s * kSliceTopics + 2 * u + 1 < KMAX) {
+              ph[u] = lds_d2(hrow + s * (kSliceTopics * 8) + u * 16);
+              th[u] = lds_d2(trow + s * (kSliceTopics * 8) + u * 16);
+            }
+          uint32_t bits = 0;
+#pragma unroll
+          for (int u = 0; u < kSliceUnits; ++u)
+            if (s * kSliceTopics + 2 * u + 1 < KMAX) {
+              bits = __builtin_amdgcn_alignbit(bits, (uint32_t)hi32(t), 31);
+              t += th[u].a * ph[u].a;
+              bits = __builtin_amdgcn_alignbit(bits, (uint32_t)hi32(t), 31);
+              t += th[u].b * ph[u].b;
+            }
+          cnt += __popc(bits);
+          live = __any(hi32(t) < 0);
+          asm volatile("" ::: "memory");
+        }
+      });
+      int new_topic = cnt - 1;
+      if (new_topic < 0 || hi32(t) < 0) {                          // GGS:116-118
+        atomicOr(p.status, ST_INVALID_TOPIC);
+        new_topic = new_topic < 0 ? 0 : K - 1;
+      }
+      p.z[id0] = new_topic;
+      p.zw[ip0] = new_topic;
+    }
+    if (!has1) break;
+    c += stride;
+    w0 = w1; id0 = id1; ip0 = ip1;
+#pragma unroll
+    for (int r = 0; r < kChunkDocs; ++r)
+#pragma unroll
+      for (int t = 0; t < NT; ++t) tv0[r][t] = tv1[r][t];
+  }
+}
+
 }  // namespace ggs

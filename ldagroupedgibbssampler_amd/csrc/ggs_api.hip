@@ -157,8 +157,9 @@ int launch_count_rebuild(ggs_handle *h) {
   HIP_TRY(h, hipMemsetAsync(h->d_n_wk, 0, kv * sizeof(int32_t), h->stream));
   if (h->S > 0) {
     CountParams cp{};
-    cp.zw = h->d_zw; cp.seg_word = h->d_seg_word; cp.seg_begin = h->d_seg_begin; cp.n_wk = h->d_n_wk; cp.K = h->K;
-    hipLaunchKernelGGL(count_sorted_kernel, dim3((unsigned)h->S), dim3(256), (size_t)h->K * sizeof(int32_t), h->stream, cp);
+    cp.zw = h->d_zw; cp.seg_word = h->d_seg_word; cp.seg_begin = h->d_seg_begin; cp.n_wk = h->d_n_wk; cp.K = h->K; cp.num_segs = (int32_t)h->S;
+    hipLaunchKernelGGL(count_sorted_kernel, dim3((unsigned)((h->S + kCountSegsPerBlock - 1) / kCountSegsPerBlock)), dim3(256), (size_t)h->K * sizeof(int32_t),
+                       h->stream, cp);
   }
   HIP_TRY(h, hipGetLastError());
   return GGS_OK;

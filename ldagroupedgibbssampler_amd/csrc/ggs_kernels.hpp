@@ -149,31 +149,37 @@ struct CountParams {
   const int32_t *seg_word;   // [S]
   const int32_t *seg_begin;  // [S+1] offsets into zw
   int32_t *n_wk;
-  int32_t K;
+  int32_t K, num_segs;
 };
+
+constexpr int kCountSegsPerBlock = 8;   // most words are rare: a workgroup per <= 256-token segment would be mostly dispatch overhead
 
 __global__ __launch_bounds__(256) void count_sorted_kernel(CountParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   int32_t *hist = reinterpret_cast<int32_t *>(smem);
-  const int seg = blockIdx.x, tid = threadIdx.x, K = p.K;
-  const int beg = p.seg_begin[seg], end = p.seg_begin[seg + 1];
-  int32_t *row = p.n_wk + (size_t)p.seg_word[seg] * K;
-  if (end - beg <= 256) {                    // wave-uniform per block
-    if (beg + tid < end) atomicAdd(&row[p.zw[beg + tid]], 1);
-    return;
-  }
-  for (int k = tid; k < K; k += 256) hist[k] = 0;
-  __syncthreads();
-  int i = beg + tid;
-  for (; i + 768 < end; i += 1024) {
-    const int k0 = p.zw[i], k1 = p.zw[i + 256], k2 = p.zw[i + 512], k3 = p.zw[i + 768];
-    atomicAdd(&hist[k0], 1); atomicAdd(&hist[k1], 1); atomicAdd(&hist[k2], 1); atomicAdd(&hist[k3], 1);
-  }
-  for (; i < end; i += 256) atomicAdd(&hist[p.zw[i]], 1);
-  __syncthreads();
-  for (int k = tid; k < K; k += 256) {
-    const int32_t cnt = hist[k];
-    if (cnt) atomicAdd(&row[k], cnt);
+  const int tid = threadIdx.x, K = p.K;
+  const int seg0 = blockIdx.x * kCountSegsPerBlock, seg1 = min(seg0 + kCountSegsPerBlock, p.num_segs);
+  for (int seg = seg0; seg < seg1; ++seg) {
+    const int beg = p.seg_begin[seg], end = p.seg_begin[seg + 1];
+    int32_t *row = p.n_wk + (size_t)p.seg_word[seg] * K;
+    if (end - beg <= 256) {                    // uniform per block
+      if (beg + tid < end) atomicAdd(&row[p.zw[beg + tid]], 1);
+      continue;
+    }
+    for (int k = tid; k < K; k += 256) hist[k] = 0;
+    __syncthreads();
+    int i = beg + tid;
+    for (; i + 768 < end; i += 1024) {
+      const int k0 = p.zw[i], k1 = p.zw[i + 256], k2 = p.zw[i + 512], k3 = p.zw[i + 768];
+      atomicAdd(&hist[k0], 1); atomicAdd(&hist[k1], 1); atomicAdd(&hist[k2], 1); atomicAdd(&hist[k3], 1);
+    }
+    for (; i < end; i += 256) atomicAdd(&hist[p.zw[i]], 1);
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) {
+      const int32_t cnt = hist[k];
+      if (cnt) atomicAdd(&row[k], cnt);
+    }
+    __syncthreads();                           // hist is reused by the next segment
   }
 }
 

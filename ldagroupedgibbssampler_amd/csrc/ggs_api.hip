@@ -72,6 +72,7 @@ struct ggs_handle {
   hipStream_t side_hot = nullptr;                      // z_hot_kernel runs here, beside z_sliced_kernel on the main stream
   hipEvent_t ev_hot_fork = nullptr, ev_hot_join = nullptr;
   bool z_split = true;                                 // GGS_DEBUG_SPLIT=0: one kernel takes cold and hot chunks in turn
+  bool z_split_allowed = true, z_split_tried = false;  // the first z step of a corpus times both forms and keeps the faster
   int32_t hot_wave_lds = 0;
   bool overlap_theta = true;
   int64_t theta_ahead_iter = INT64_MIN;     // iteration the side-stream theta was drawn for, or none
@@ -264,7 +265,7 @@ int launch_pcgs_z(ggs_handle *h) {
   return GGS_OK;
 }
 
-int launch_z(ggs_handle *h) {
+int launch_z(ggs_handle *h, bool force_fused = false) {
   if (h->C == 0) return GGS_OK;
   ZParams zp{};
   zp.tok = h->d_tok; zp.inv_perm = h->d_inv_perm; zp.z = h->d_z; zp.zw = h->d_zw; zp.chunk_start = h->d_chunk_start; zp.chunk_doc = h->d_chunk_doc; zp.chunk_len = h->d_chunk_len;
@@ -285,7 +286,7 @@ int launch_z(ggs_handle *h) {
     void *args[] = {&zp};
     const dim3 sblock(kSlicedWaves * 64);
     auto grid_of = [&](int64_t chunks) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((chunks + kSlicedWaves - 1) / kSlicedWaves, (int64_t)h->num_cus))); };
-    if (h->z_split && h->Cs > h->Cc && h->Cc > 0) {
+    if (h->z_split && !force_fused && h->Cs > h->Cc && h->Cc > 0) {
       // cold chunks on the main stream, hot chunks beside them (z_hot_kernel): two waves per SIMD
       ZParams hp = zp;
       hp.wave_lds = h->hot_wave_lds; hp.hot_off = kSlicedWaves * h->hot_wave_lds;
@@ -396,6 +397,26 @@ int z_phase(ggs_handle *h) {
     if ((rc = launch_theta(h, h->stream, h->d_theta, h->iteration))) return rc;
   }
   HIP_TRY(h, hipEventRecord(E.e[1], h->stream));
+  if (h->z_sliced && h->z_split && !h->z_split_tried && h->Cs > h->Cc && h->Cc > 0) {
+    // Whether the guest kernel really runs beside the cold one depends on how the runtime maps streams to hardware
+    // queues (measured: beside each other in a plain process, one after the other under torchrun + RCCL).  Both forms
+    // write the same z, so the first z step of a corpus simply runs twice, timed, and the slower form is dropped.
+    h->z_split_tried = true;
+    float t_split = 0, t_fused = 0;
+    hipEvent_t t0 = nullptr, t1 = nullptr, t2 = nullptr;
+    if (hipEventCreate(&t0) != hipSuccess || hipEventCreate(&t1) != hipSuccess || hipEventCreate(&t2) != hipSuccess) return set_err(h, GGS_ERR_HIP, "hipEventCreate");
+    HIP_TRY(h, hipEventRecord(t0, h->stream));
+    if ((rc = launch_z(h, false))) return rc;
+    HIP_TRY(h, hipEventRecord(t1, h->stream));
+    if ((rc = launch_z(h, true))) return rc;
+    HIP_TRY(h, hipEventRecord(t2, h->stream));
+    HIP_TRY(h, hipEventSynchronize(t2));
+    HIP_TRY(h, hipEventElapsedTime(&t_split, t0, t1));
+    HIP_TRY(h, hipEventElapsedTime(&t_fused, t1, t2));
+    (void)hipEventDestroy(t0); (void)hipEventDestroy(t1); (void)hipEventDestroy(t2);
+    if (t_fused < t_split) h->z_split = false;
+    HIP_TRY(h, hipEventRecord(E.e[1], h->stream));          // this sweep's z time: one launch of the form kept
+  }
   if ((rc = launch_z(h))) return rc;
   HIP_TRY(h, hipEventRecord(E.e[2], h->stream));
   h->theta_ahead_iter = INT64_MIN;
@@ -509,6 +530,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       h->wave_lds = h->ring_base + kRingSlots * kSliceBytes;
       h->hot_pitch = ((h->K + 7) / 8) * 64 + 16;                     // KMAX doubles + one unit: an odd number of 16-byte units
       if (const char *e = std::getenv("GGS_DEBUG_SPLIT")) h->z_split = std::atoi(e) != 0;
+      h->z_split_allowed = h->z_split;
       h->hot_wave_lds = (kChunkDocs * kmax * 8 + 255) / 256 * 256;   // z_hot_kernel: two theta rows per wave, then the table
       // split: the two workgroups must fit one CU together, each request rounded up to the LDS allocation granule
       h->hot_cap = h->z_split ? (kMaxLdsBytes - alloc_of(kSlicedWaves * h->wave_lds) - kSlicedWaves * h->hot_wave_lds) / kGranule * kGranule / h->hot_pitch
@@ -771,6 +793,7 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
     HIP_TRY(h, hipMemcpy(h->d_chunk_len, clen.data(), sizeof(int32_t) * clen.size(), hipMemcpyHostToDevice));
   }
   h->have_corpus = true; h->have_phi = false; h->in_sweep = false; h->global_tokens = -1;
+  h->z_split = h->z_split_allowed; h->z_split_tried = false;
   return GGS_OK;
 }
 

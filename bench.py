@@ -144,7 +144,10 @@ def main():
     if sharded:
         sh = ShardedGGS(h, TorchHipExchange, corpus, rank, world)
         sh.set_z_global(z0)
-        run = lambda n: sh.sweep(n)  # noqa: E731   (one exchange per sweep: the host is in the loop anyway)
+        def run(n):
+            # one count exchange per sweep, enqueued back to back; the host waits once per batch of 5
+            for i in range(0, n, 5):
+                sh.sweep(min(5, n - i))
         n_local = sh.local.num_tokens
     else:
         h.set_corpus(corpus.doc_ptr, corpus.tokens)

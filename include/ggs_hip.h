@@ -135,6 +135,10 @@ int ggs_sweep(ggs_handle *h, int32_t n_sweeps);
  *   end   = samplePhi on the corpus-wide counts (UPLDA:664-687) */
 int ggs_sweep_begin(ggs_handle *h);
 int ggs_sweep_end(ggs_handle *h);
+/* ggs_sweep_end without the wait: the Phi draw is enqueued and the call returns; errors the sweep flags on the
+ * device (they are sticky) and its phase times surface at the next ggs_sweep_end / ggs_sweep / ggs_synchronize-
+ * then-getter.  For a doc-sharded loop that exchanges counts every sweep but looks at the result every n. */
+int ggs_sweep_end_async(ggs_handle *h);
 /* replaces: sampleZGivenPhi (UPLDA:975-1014): z step + updateCounts, Phi kept */
 int ggs_sample_z_given_phi(ggs_handle *h, int32_t n_sweeps);
 /* Device pointer / element count of the int32 [V][K] type-topic counts

@@ -855,6 +855,14 @@ int ggs_sweep_end(ggs_handle *h) {
   return finish_sweep(h, true);
 }
 
+int ggs_sweep_end_async(ggs_handle *h) {
+  int rc = require_ready(h, true);
+  if (rc) return rc;
+  if (!h->in_sweep) return set_err(h, GGS_ERR_STATE, "ggs_sweep_end_async without ggs_sweep_begin");
+  h->in_sweep = false;
+  return finish_sweep(h, true, false);
+}
+
 int ggs_sweep(ggs_handle *h, int32_t n_sweeps) {
   for (int32_t i = 0; i < n_sweeps; ++i) {
     int rc = ggs_sweep_begin(h);

@@ -114,6 +114,9 @@ class GGSHandle:
     def sweep_begin(self):
         self._chk(self._L.ggs_sweep_begin(self._h))
 
+    def sweep_end_async(self):
+        self._chk(self._L.ggs_sweep_end_async(self._h))
+
     def sweep_end(self):
         self._chk(self._L.ggs_sweep_end(self._h))
 

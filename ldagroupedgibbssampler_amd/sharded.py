@@ -76,10 +76,12 @@ class ShardedGGS:
         self.engine.init_phi()
 
     def sweep(self, n=1):
-        for _ in range(n):
+        """n sweeps, one count exchange each; only the last one is waited for (device-side error flags are sticky)."""
+        end_async = getattr(self.engine, "sweep_end_async", self.engine.sweep_end)
+        for i in range(n):
             self.engine.sweep_begin()
             self.exchange.allreduce_sweep()
-            self.engine.sweep_end()
+            (self.engine.sweep_end if i == n - 1 else end_async)()
 
 
 def java_lcg_initial_z(num_tokens, num_topics, seed):

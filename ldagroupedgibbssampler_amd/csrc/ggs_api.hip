@@ -764,6 +764,20 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
         if (r >= 0) hot.add(r, (int32_t)i, (int32_t)d);
         else cold.add(tokens[i], (int32_t)i, (int32_t)d);
       }
+    // Lanes of a chunk in (document, row) order: the 16 lanes one LDS pass serves then mostly read the same theta row
+    // and, in hot chunks, few distinct table rows (tokens of one word share a row: a broadcast, not a bank conflict).
+    auto sort_lanes = [](Builder &b) {
+      std::vector<std::pair<uint32_t, int32_t>> tmp(64);
+      for (size_t c0 = 0; c0 < b.tok.size(); c0 += 64) {
+        int n = 0;
+        while (n < 64 && b.idx[c0 + (size_t)n] >= 0) ++n;                 // active lanes are a prefix
+        for (int j = 0; j < n; ++j) tmp[(size_t)j] = {(uint32_t)b.tok[c0 + (size_t)j], b.idx[c0 + (size_t)j]};
+        std::sort(tmp.begin(), tmp.begin() + n);
+        for (int j = 0; j < n; ++j) { b.tok[c0 + (size_t)j] = (int32_t)tmp[(size_t)j].first; b.idx[c0 + (size_t)j] = tmp[(size_t)j].second; }
+      }
+    };
+    sort_lanes(cold);
+    sort_lanes(hot);
     h->Cc = (int64_t)(cold.docs.size() / 2);
     h->Cs = h->Cc + (int64_t)(hot.docs.size() / 2);
     cold.tok.insert(cold.tok.end(), hot.tok.begin(), hot.tok.end());

@@ -3,7 +3,9 @@
 // Device layouts (private to the library):
 //   tok[N]            int32   word ids, CSR order
 //   z[N]              int32   topic assignments
-//   chunk_*[C]                z-kernel work items: <=64 consecutive tokens of ONE document
+//   chunk_*[C]                work items of the K > 192 z kernels: <=64 consecutive tokens of ONE document
+//   ct_*[Cs][64], c_docs      work items of the sliced z kernels: <=64 tokens of <=2 documents, cold chunks first,
+//                             then the chunks of the hot words (ggs_z_sliced.hpp)
 //   perm[N]           int32   token indices sorted by word id (built once on the host)
 //   inv_perm[N]       int32   its inverse: position of token i in the word-sorted order
 //   zw[N]             int32   z in word-sorted order (zw[inv_perm[i]] == z[i]), written by the
@@ -16,10 +18,11 @@
 //   n_wk[V][K]        int32   typeTopicCounts layout (MSLDA:73)
 //   n_k[K]            int32   tokensPerTopic
 //
-// Java keeps every running sum sequential in index order (sum += ...), and so do
-// these kernels: wherever the reference adds K or V doubles one after another, ONE
-// lane walks them in that order.  Parallelism comes from doing many such walks side
-// by side (one lane per token / document / topic), never from re-associating a sum.
+// Java keeps every running sum sequential in index order (sum += ...), and these kernels produce
+// the same bits: the K-long sums (scores of a token, gammas of a document) are walked by ONE lane
+// each, in that order, many side by side (one lane per token / document); the two V-long sums of
+// the Phi draw are computed in parallel by ggs_exact_sum.hpp, which proves step by step that its
+// result is the sequential one.
 //
 // The reference's AtomicInteger delta matrix + merge (UPLDA:1547-1557, 1107-1221) exists to
 // let JVM threads share counts; its net effect per sweep is n_wk = histogram of (word, z).
@@ -185,14 +188,16 @@ __global__ __launch_bounds__(256) void count_sorted_kernel(CountParams p) {
 
 // ------------------------------------------------------------------------------
 // K6/K8: Phi draw (GGS:182-198 / MarsagliaSparseDirichlet.java:31-55).
-//   column_chain<int32,true>   magnitude_k = sum_v (beta + n_kv), v ascending (the
+//   column sum <int32,true>    magnitude_k = sum_v (beta + n_kv), v ascending (the
 //                              Dirichlet(double[]) constructor); also tokensPerTopic
 //   phi_gamma                  lane per (v,k): Gamma(partition*magnitude) -> phiT (unnormalised)
-//   column_chain<double,false> sum_v gamma, v ascending (ParallelDirichlet.java:53-57)
+//   column sum <double,false>  sum_v gamma, v ascending (ParallelDirichlet.java:53-57)
 //   phi_normalise              lane per (v,k): divide, clamp, optional running phiMean +=
+// The column sums are the exact parallel ones of ggs_exact_sum.hpp.  column_chain_kernel below is
+// what they replaced, kept as the element-by-element cross-check (GGS_DEBUG_CHAIN=1):
 //
-// column_chain: a sum over V in index order is one dependent fp64 add chain per topic --
-// it cannot be split, only fed (8 cycles per add for a lone wave: >= 0.17 ms at V = 50k).
+// column_chain: a sum over V in index order walked as one dependent fp64 add chain per topic
+// (8 cycles per add for a lone wave: >= 0.17 ms at V = 50k, 0.28 ms measured).
 // One workgroup owns 8 adjacent topics (a 64-byte / 32-byte slice of every row).  Waves 1-3
 // are loaders: they stream [384 rows x 8 topics] tiles into a double-buffered LDS ring with
 // plain coalesced loads and do the per-element part of the sum (beta + count) on the way;

@@ -188,6 +188,14 @@ int ggs_debug_draw(int32_t device_id, int32_t kind /*0 uniform,1 gaussian,2 gamm
  * relative of the Java loop's running sum, not bit-equal to it.  Needs tokensPerTopic up to date (any completed sweep,
  * ggs_init_phi or ggs_set_z with redraw). */
 int ggs_model_log_likelihood(ggs_handle *h, double *doc_side, double *topic_side);
+/* replaces: computeLogPosterior (UPLDA:1573-1634, the LDA log posterior of Doss and George 2025, logged every
+ * diagnostic iteration, UPLDA:820-821) for scheme ggs: doc_side = sum over THIS handle's tokens of
+ * log(phi[z][w] + 1e-12) + sum_d sum_k (n_dk + alpha_k - 1) log(theta[d][k] + 1e-12) with theta = the rows the last z
+ * step used (thetaMatrix); topic_side = (beta - 1) sum_{k,v} log(phi[k][v] + 1e-12); the value is the sum over the
+ * shards' doc_side plus one topic_side.  (The Java loop fills a dense K x V matrix per document -- D*K*V operations
+ * -- to compute what is a sum over tokens.)  Same accuracy contract as ggs_model_log_likelihood.
+ * GGS_ERR_UNSUPPORTED for scheme pcgs, whose diagnostic theta is a fresh random draw (UPLDA:712-714). */
+int ggs_log_posterior(ggs_handle *h, double *doc_side, double *topic_side);
 /* out[k] = x[0][k] + x[1][k] + ... in index order (exactly one of x / counts given; with counts the addends are
  * beta + counts[v][k]): the Phi normalisers' exact parallel column sum on its own, for adversarial inputs */
 int ggs_debug_column_sum(int32_t device_id, int32_t V, int32_t K, const double *x /*V*K or NULL*/, const int32_t *counts /*V*K or NULL*/,

@@ -90,6 +90,7 @@ SIGNATURES = {
     "ggs_debug_draw": (C.c_int, [C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int64,
                                  _dp, _dp, _ip]),
     "ggs_model_log_likelihood": (C.c_int, [_vp, _dp, _dp]),
+    "ggs_log_posterior": (C.c_int, [_vp, _dp, _dp]),
     "ggs_debug_column_sum": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _ip, C.c_double, _dp]),
 }
 

@@ -1033,6 +1033,28 @@ int ggs_model_log_likelihood(ggs_handle *h, double *doc_side, double *topic_side
   *doc_side = out[0]; *topic_side = out[1];
   return GGS_OK;
 }
+int ggs_log_posterior(ggs_handle *h, double *doc_side, double *topic_side) {
+  int rc = require_ready(h, true);
+  if (rc) return rc;
+  if (!doc_side || !topic_side) return set_err(h, GGS_ERR_BAD_ARG, "null output");
+  if (h->flags & GGS_FLAG_PCGS) return set_err(h, GGS_ERR_UNSUPPORTED, "scheme=pcgs draws its diagnostic theta afresh (UPLDA:712-714); only ggs keeps thetaMatrix");
+  const int K = h->K;
+  const int64_t doc_blocks = (h->D + kLLBlock / 64 - 1) / (kLLBlock / 64), phi_blocks = 1024;
+  const size_t bytes = 32 + sizeof(double) * (size_t)(doc_blocks + phi_blocks);
+  if ((rc = ensure_scratch(h, bytes))) return rc;
+  auto *d_out = static_cast<double *>(h->d_scratch);
+  double *d_doc = d_out + 4, *d_phi = d_doc + doc_blocks;
+  if (doc_blocks)
+    hipLaunchKernelGGL(lp_docs_kernel, dim3((unsigned)doc_blocks), dim3(kLLBlock), (size_t)(kLLBlock / 64) * K * sizeof(int32_t), h->stream, h->d_doc_ptr,
+                       h->d_tok, h->d_z, h->d_alpha, h->d_theta, h->d_phiT, h->D, K, h->Kp, d_doc);
+  hipLaunchKernelGGL(lp_phi_kernel, dim3((unsigned)phi_blocks), dim3(kLLBlock), 0, h->stream, h->d_phiT, (int64_t)h->V, K, h->Kp, d_phi);
+  hipLaunchKernelGGL(lp_finish_kernel, dim3(1), dim3(kLLBlock), 0, h->stream, d_doc, doc_blocks, d_phi, phi_blocks, h->beta, d_out);
+  HIP_TRY(h, hipGetLastError());
+  double out[2];
+  if ((rc = copy_out(h, out, d_out, sizeof out))) return rc;
+  *doc_side = out[0]; *topic_side = out[1];
+  return GGS_OK;
+}
 int ggs_get_timings(ggs_handle *h, ggs_timings *out) { if (!h || !out) return GGS_ERR_BAD_ARG; *out = h->tm; return GGS_OK; }
 int ggs_reset_timings(ggs_handle *h) { if (!h) return GGS_ERR_BAD_ARG; h->tm = ggs_timings{}; return GGS_OK; }
 

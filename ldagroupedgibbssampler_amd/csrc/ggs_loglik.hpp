@@ -100,4 +100,66 @@ __global__ __launch_bounds__(kLLBlock) void ll_finish_kernel(const double *doc_p
     out[1] = t + log_gamma_stirling(vbeta) * K - log_gamma_stirling(beta) * (double)*nonzero;              // UPLDA:1742-1747
 }
 
+// ------------------------------------------------------------------------------------------------
+// computeLogPosterior (UPLDA:1573-1634; the LDA log posterior of Doss and George 2025, the quantity the
+// reference's paper tracks).  The Java loop builds a dense K x V count matrix per document; its sum over
+// (k, v) of m_djt * logPhi is simply a sum over the document's tokens:
+//
+//   document side  sum_tokens log(phi[z][w] + EPS) + sum_d sum_k (n_dk + alpha_k - 1) * log(theta[d][k] + EPS)   :1604-1619
+//   topic side     (beta - 1) * sum_{k,v} log(phi[k][v] + EPS)                                                    :1622-1628
+//
+// with EPS = 1e-12 and theta = the rows the last z step used.  Same reduction as above: fixed tree, ~1e-12
+// relative against the Java-order loop.  Documents without tokens have no theta row in the reference either
+// (GGS:52-53 leaves the row as allocated, zeros): their theta term uses log(0 + EPS), as in Java.
+constexpr double kLogPostEps = 1e-12;
+
+__global__ __launch_bounds__(kLLBlock) void lp_docs_kernel(const int64_t *doc_ptr, const int32_t *tok, const int32_t *z, const double *alpha,
+                                                            const double *theta, const double *phiT, int64_t num_docs, int32_t K, int32_t Kp,
+                                                            double *block_out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  __shared__ double wave_part[kLLBlock / 64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int32_t *hist = reinterpret_cast<int32_t *>(smem) + (size_t)wave * K;
+  const int64_t d = (int64_t)blockIdx.x * (kLLBlock / 64) + wave;
+  double v = 0.0;
+  if (d < num_docs) {
+    const int64_t beg = doc_ptr[d], end = doc_ptr[d + 1];
+    for (int k = lane; k < K; k += 64) hist[k] = 0;
+    for (int64_t i = beg + lane; i < end; i += 64) {
+      const int32_t t = z[i];
+      atomicAdd(&hist[t], 1);
+      v += strict_log(phiT[(size_t)tok[i] * Kp + t] + kLogPostEps);
+    }
+    for (int k = lane; k < K; k += 64)
+      v += ((double)hist[k] + alpha[k] - 1.0) * strict_log(theta[(size_t)d * K + k] + kLogPostEps);
+  }
+  const double t = ll_block_sum(v, wave_part);
+  if (threadIdx.x == 0) block_out[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(kLLBlock) void lp_phi_kernel(const double *phiT, int64_t V, int32_t K, int32_t Kp, double *block_out) {
+  __shared__ double wave_part[kLLBlock / 64];
+  double v = 0.0;
+  const int64_t n = V * K, stride = (int64_t)gridDim.x * kLLBlock;
+  for (int64_t i = (int64_t)blockIdx.x * kLLBlock + threadIdx.x; i < n; i += stride) {
+    const int64_t w = i / K;
+    v += strict_log(phiT[w * Kp + (i - w * K)] + kLogPostEps);
+  }
+  const double t = ll_block_sum(v, wave_part);
+  if (threadIdx.x == 0) block_out[blockIdx.x] = t;
+}
+
+__global__ __launch_bounds__(kLLBlock) void lp_finish_kernel(const double *doc_part, int64_t n_doc_part, const double *phi_part, int64_t n_phi_part,
+                                                              double beta, double *out) {
+  __shared__ double wave_part[kLLBlock / 64];
+  double v = 0.0;
+  for (int64_t i = threadIdx.x; i < n_doc_part; i += kLLBlock) v += doc_part[i];
+  double t = ll_block_sum(v, wave_part);
+  if (threadIdx.x == 0) out[0] = t;
+  v = 0.0;
+  for (int64_t i = threadIdx.x; i < n_phi_part; i += kLLBlock) v += phi_part[i];
+  t = ll_block_sum(v, wave_part);
+  if (threadIdx.x == 0) out[1] = (beta - 1.0) * t;
+}
+
 }  // namespace ggs

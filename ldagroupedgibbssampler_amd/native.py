@@ -196,6 +196,12 @@ class GGSHandle:
         self._chk(self._L.ggs_model_log_likelihood(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def log_posterior(self):
+        """(document side, topic side) of computeLogPosterior (UPLDA:1573-1634), computed on the device."""
+        a, b = C.c_double(), C.c_double()
+        self._chk(self._L.ggs_log_posterior(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def launch_info(self):
         c, l, b = C.c_int64(), C.c_int32(), C.c_int32()
         self._chk(self._L.ggs_get_launch_info(self._h, C.byref(c), C.byref(l), C.byref(b)))

@@ -259,6 +259,12 @@ class LDAGroupedGibbsSampler:
         doc_side, topic_side = self._h.model_log_likelihood()
         return doc_side + topic_side
 
+    def computeLogPosterior(self):
+        """UPLDA:1573-1634 (Doss and George 2025), on the device (ggs_log_posterior)."""
+        self._need_data()
+        doc_side, topic_side = self._h.log_posterior()
+        return doc_side + topic_side
+
     def getBeta(self):
         return self.beta
 

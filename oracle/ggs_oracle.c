@@ -926,6 +926,42 @@ void orc_model_log_likelihood(const orc_state *s, double *doc_side, double *topi
   free(topicCounts); free(topicLogGammas);
 }
 
+/* UPLDA:1573-1634 computeLogPosterior in the Java loop order (Math.log restated with the fdlibm log).  The
+ * dense per-document K x V matrix m_djt is kept as the sorted list of the document's (topic, type) pairs: the Java
+ * loop visits k then v ascending and adds count * logPhi for every non-zero cell, and so does this. */
+static int cmp_i64(const void *a, const void *b) { int64_t x = *(const int64_t *)a, y = *(const int64_t *)b; return (x > y) - (x < y); }
+void orc_log_posterior(const orc_state *s, double *doc_side, double *topic_side) {
+  const double EPS = 1e-12;
+  const int32_t K = s->K, V = s->V;
+  double lp = 0.0;
+  double *n_dj = malloc(sizeof(double) * (size_t)K);
+  int64_t maxlen = 1;
+  for (int64_t d = 0; d < s->D; d++) if (s->doc_ptr[d + 1] - s->doc_ptr[d] > maxlen) maxlen = s->doc_ptr[d + 1] - s->doc_ptr[d];
+  int64_t *cell = malloc(sizeof(int64_t) * (size_t)maxlen);
+  for (int64_t d = 0; d < s->D; d++) {
+    const int64_t b = s->doc_ptr[d], e = s->doc_ptr[d + 1];
+    for (int32_t k = 0; k < K; k++) n_dj[k] = 0.0;
+    for (int64_t i = b; i < e; i++) { n_dj[s->z[i]] += 1.0; cell[i - b] = (int64_t)s->z[i] * V + s->tokens[i]; }
+    qsort(cell, (size_t)(e - b), sizeof(int64_t), cmp_i64);
+    for (int64_t i = 0; i < e - b;) {                       /* :1604-1612 */
+      int64_t j = i;
+      while (j < e - b && cell[j] == cell[i]) j++;
+      const int32_t k = (int32_t)(cell[i] / V), v = (int32_t)(cell[i] % V);
+      lp += (double)(j - i) * orc_log(s->phi[(size_t)k * V + v] + EPS);
+      i = j;
+    }
+    for (int32_t k = 0; k < K; k++)                          /* :1615-1618 */
+      lp += (n_dj[k] + s->alpha[k] - 1.0) * orc_log(s->theta[(size_t)d * K + k] + EPS);
+  }
+  *doc_side = lp;
+  lp = 0.0;
+  const double betaMinus1 = s->beta - 1.0;                   /* :1622-1628 */
+  for (int32_t k = 0; k < K; k++)
+    for (int32_t v = 0; v < V; v++) lp += betaMinus1 * orc_log(s->phi[(size_t)k * V + v] + EPS);
+  *topic_side = lp;
+  free(n_dj); free(cell);
+}
+
 void orc_get_z(const orc_state *s, int32_t *z) { memcpy(z, s->z, sizeof(int32_t) * s->N); }
 void orc_get_type_topic_counts(const orc_state *s, int32_t *o) { memcpy(o, s->n_wk, sizeof(int32_t) * (size_t)s->K * s->V); }
 void orc_get_topic_type_counts(const orc_state *s, int32_t *o) { memcpy(o, s->n_kw, sizeof(int32_t) * (size_t)s->K * s->V); }

@@ -92,6 +92,8 @@ int orc_init_z_java_lcg(orc_state *s, int32_t seed);   /* UPLDA:398-406,458-460 
 int orc_set_z(orc_state *s, const int32_t *z, int redraw_phi); /* UPLDA:1797-1843 */
 int orc_init_phi(orc_state *s);                        /* UPLDA:1287-1294       */
 void orc_set_phi_mean_gating(orc_state *s, int save, int burn_in, int thin);
+/* UPLDA:1573-1634 computeLogPosterior in the Java loop order; the value is doc_side + topic_side */
+void orc_log_posterior(const orc_state *s, double *doc_side, double *topic_side);
 /* UPLDA:1644-1758 modelLogLikelihood in the Java loop order; the model's value is doc_side + topic_side */
 void orc_model_log_likelihood(const orc_state *s, double *doc_side, double *topic_side);
 /* 0 = ggs (default), 1 = pcgs: UPLDA:1466-1544 z loop (theta integrated out), same Phi draw */

@@ -63,6 +63,7 @@ def lib():
         "orc_set_threads": (None, [vp, C.c_int]),
         "orc_set_scheme": (None, [vp, C.c_int]),
         "orc_model_log_likelihood": (None, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "orc_log_posterior": (None, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "orc_set_iteration": (None, [vp, C.c_int32]),
         "orc_get_iteration": (C.c_int32, [vp]),
         "orc_sweep": (C.c_int, [vp, C.c_int32]),
@@ -237,6 +238,12 @@ class OracleSampler:
         """(document side, topic side) of UPLDA:1644-1758; their sum is the model log likelihood."""
         a, b = C.c_double(), C.c_double()
         lib().orc_model_log_likelihood(self._h, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def log_posterior(self):
+        """(document side, topic side) of UPLDA:1573-1634; their sum is the log posterior."""
+        a, b = C.c_double(), C.c_double()
+        lib().orc_log_posterior(self._h, C.byref(a), C.byref(b))
         return a.value, b.value
 
     def set_scheme(self, scheme):

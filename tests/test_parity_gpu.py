@@ -533,3 +533,30 @@ def test_model_log_likelihood_on_device(native, oracle, cats):
             h.set_z(o.get_z()[tb:tb + sub.num_tokens], redraw_phi=False)
             parts.append(h.model_log_likelihood()[0])
         assert abs(sum(parts) - od) <= 1e-11 * abs(od)
+
+
+def test_log_posterior_on_device(native, oracle, cats):
+    """ggs_log_posterior (UPLDA:1573-1634, Doss and George 2025) against the oracle's Java-order loop: 1e-11 relative
+    (fixed reduction tree instead of one running double; per-token terms instead of count * logPhi per cell),
+    run-to-run identical, additive over document shards, and against the plain numpy formula."""
+    for corpus, K, alpha, beta in ((cats, 20, 5.0, 7.0), (random_corpus(500, 700, 110, seed=8, empty_every=17), 33, 0.1, 0.01)):
+        g, o = make_pair(native, oracle, corpus, K, alpha, beta, 15, zseed=16)
+        g.sweep(2)
+        o.sweep(2)
+        gd, gt = g.log_posterior()
+        od, ot = o.log_posterior()
+        assert abs(gd - od) <= 1e-11 * abs(od) and abs(gt - ot) <= 1e-11 * abs(ot), ((gd, od), (gt, ot))
+        assert g.log_posterior() == (gd, gt)
+        phi, theta, z = o.get_phi(), o.get_theta(), o.get_z()
+        doc_of = np.repeat(np.arange(corpus.num_docs), np.diff(corpus.doc_ptr))
+        n_dk = o.get_doc_topic_counts().astype(np.float64)
+        direct = (np.log(phi[z, corpus.tokens] + 1e-12).sum() + ((n_dk + alpha - 1.0) * np.log(theta + 1e-12)).sum()
+                  + (beta - 1.0) * np.log(phi + 1e-12).sum())
+        assert doc_of.size == z.size and abs((gd + gt) - direct) <= 1e-9 * abs(direct)
+    p = native.GGSHandle(4, cats.num_types, 0.1, 0.1, 1, flags=native.FLAG_PCGS)
+    p.set_corpus(cats.doc_ptr, cats.tokens)
+    p.init_z_java_lcg(1)
+    p.init_phi()
+    with pytest.raises(native.GGSError) as e:
+        p.log_posterior()
+    assert e.value.code == native.ERR_UNSUPPORTED

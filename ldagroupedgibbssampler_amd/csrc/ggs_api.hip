@@ -613,7 +613,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     // (a CU-masked side stream was tried: hipExtStreamCreateWithCUMask gives a blocking stream that
     // serialises with the legacy default stream, so the overlap is lost -- priority alone it is)
     if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo) != hipSuccess) return bail(GGS_ERR_HIP);
-    if (hipStreamCreateWithFlags(&h->side_hot, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&h->ev_hot_fork) != hipSuccess ||
+    if (hipStreamCreateWithPriority(&h->side_hot, hipStreamNonBlocking, hi) != hipSuccess || hipEventCreate(&h->ev_hot_fork) != hipSuccess ||
         hipEventCreate(&h->ev_hot_join) != hipSuccess)
       return bail(GGS_ERR_HIP);
   }

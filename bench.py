@@ -32,8 +32,8 @@ def algorithmic_bytes_per_token(K):
     return 8 * K + 28
 
 
-def measured_traffic(kernel_prefix):
-    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same
+def measured_traffic(kernel_prefixes):
+    """HBM bytes per z step (summed over its kernels) from the committed PMC passes of this same
     command (profiles/r*_pmc_counters.txt; FETCH_SIZE and WRITE_SIZE are collected in separate
     rocprofv3 runs, in KiB).  gfx950: FETCH_SIZE counts 128-byte requests at 64 bytes for wide
     coalesced reads, so it is doubled (MI355X_MICROARCH.md, HBM).  None if no profile is present."""
@@ -42,19 +42,22 @@ def measured_traffic(kernel_prefix):
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.txt")))
     if not files:
         return None
-    fetch = write = None
-    for line in open(files[-1]):
-        if kernel_prefix not in line.split("{")[0]:
-            continue
-        try:
-            d = ast.literal_eval(line[line.index("{"):line.rindex("}") + 1])
-        except (ValueError, SyntaxError):
-            continue
-        fetch = d.get("FETCH_SIZE", fetch)
-        write = d.get("WRITE_SIZE", write)
-    if fetch is None or write is None:
-        return None
-    return int((2.0 * fetch + write) * 1024)
+    total = 0.0
+    for kernel_prefix in kernel_prefixes:
+        fetch = write = None
+        for line in open(files[-1]):
+            if kernel_prefix not in line.split("{")[0]:
+                continue
+            try:
+                d = ast.literal_eval(line[line.index("{"):line.rindex("}") + 1])
+            except (ValueError, SyntaxError):
+                continue
+            fetch = d.get("FETCH_SIZE", fetch)
+            write = d.get("WRITE_SIZE", write)
+        if fetch is None or write is None:
+            return None
+        total += 2.0 * fetch + write
+    return int(total * 1024)
 
 
 def cpu_baseline(corpus, K, alpha, beta, seed, z0, sample_docs):
@@ -182,7 +185,10 @@ def main():
         btok = algorithmic_bytes_per_token(K)
         z_ms = tm["z_ms"] / max(tm["sweeps"], 1)            # HIP events on the handle's stream, over the timed region
         achieved = n_local * btok / (z_ms * 1e-3) / 1e9 if z_ms > 0 else 0.0
-        zkernel = "pcgs_z_kernel" if args.scheme == "pcgs" else ("z_sliced_kernel<%d>" % (8 * ((K + 7) // 8)) if K <= 192 else "z_stream_kernel")
+        # the z step: for K <= 192 the cold-chunk kernel and, beside it on a second stream, the hot-chunk kernel
+        kmax = 8 * ((K + 7) // 8)
+        zkernels = (["pcgs_z_kernel"] if args.scheme == "pcgs" else
+                    ["z_sliced_kernel<%d>" % kmax, "z_hot_kernel<%d>" % kmax] if K <= 192 else ["z_stream_kernel"])
         line = {
             "metric": "M tokens sampled/sec (whole node) per Gibbs sweep at K=%d" % K + ("" if args.scheme == "ggs" else " (scheme=%s)" % args.scheme),
             "value": round(corpus.num_tokens * args.steps / dt / 1e6, 3),
@@ -203,12 +209,12 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": zkernel,
+                "kernel": " + ".join(zkernels),
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic("ggs::" + zkernel.split("<")[0]),
+                "traffic": measured_traffic(["ggs::" + k.split("<")[0] for k in zkernels]),
                 "bytes_per_token": btok,
                 "tokens_per_launch": n_local,
                 "avg_launch_ms": round(z_ms, 4),

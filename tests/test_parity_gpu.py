@@ -148,13 +148,15 @@ def test_wide_topic_rows_use_the_streaming_kernel(native, oracle, K):
     compare_state(g, o, "wide K=%d" % K)
 
 
-@pytest.mark.parametrize("mode,K", [(2, 33), (2, 48), (2, 100), (2, 192), (0, 5), (0, 100), (0, 257), ("fused", 20), ("fused", 100), ("chain", 9)])
+@pytest.mark.parametrize("mode,K", [(2, 33), (2, 48), (2, 100), (2, 192), (0, 5), (0, 100), (0, 257), ("fused", 20), ("fused", 100), ("chain", 9), ("nohot", 20), ("hot3", 100)])
 def test_alternate_z_kernels_agree(native, oracle, K, mode, monkeypatch):
     """The z kernels are interchangeable: GGS_DEBUG_ZKERNEL=2 forces the streaming kernel below 193 topics,
     =0 the whole-row LDS tile kernel (first-generation, kept as a cross-check); GGS_DEBUG_SPLIT=0 ("fused")
     lets one sliced kernel take cold and hot chunks in turn instead of running z_hot_kernel beside it;
-    GGS_DEBUG_CHAIN=1 ("chain") walks the Phi normalisers element by element instead of the exact parallel sums."""
-    env = {"fused": ("GGS_DEBUG_SPLIT", "0"), "chain": ("GGS_DEBUG_CHAIN", "1")}.get(mode, ("GGS_DEBUG_ZKERNEL", str(mode)))
+    GGS_DEBUG_CHAIN=1 ("chain") walks the Phi normalisers element by element instead of the exact parallel sums;
+    GGS_DEBUG_HOT caps the hot-word table (0: every chunk is a cold chunk; 3: three hot words)."""
+    env = {"fused": ("GGS_DEBUG_SPLIT", "0"), "chain": ("GGS_DEBUG_CHAIN", "1"), "nohot": ("GGS_DEBUG_HOT", "0"),
+           "hot3": ("GGS_DEBUG_HOT", "3")}.get(mode, ("GGS_DEBUG_ZKERNEL", str(mode)))
     monkeypatch.setenv(*env)
     c = random_corpus(150, 400, 140, seed=K + (mode if isinstance(mode, int) else 7), empty_every=11)
     g, o = make_pair(native, oracle, c, K, 0.1, 0.01, 70 + K, flags=native.FLAG_PARANOID, zseed=K)

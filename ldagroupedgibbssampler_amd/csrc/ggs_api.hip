@@ -62,6 +62,7 @@ struct ggs_handle {
   int64_t Cs = 0, Cc = 0;                              // sliced chunks in all, cold ones
   int32_t *d_order = nullptr;                          // scheme=pcgs: local documents, longest first
   int32_t pcgs_lds = 0, pcgs_waves_per_cu = 0, max_doc_len = 0;
+  bool pcgs_sliced = false;                            // K <= 192: scores in registers, one pass over the rows per step
   int32_t hot_cap = 0, num_hot = 0, hot_pitch = 0, wave_lds = 0, ring_base = 0;
   int32_t *d_perm = nullptr, *d_inv_perm = nullptr, *d_zw = nullptr, *d_seg_word = nullptr, *d_seg_begin = nullptr;
   // theta of the current / last z step, and the buffer the next iteration's theta is drawn into
@@ -250,6 +251,7 @@ int launch_theta(ggs_handle *h, hipStream_t stream, double *dst, int32_t iterati
   }
 const void *sliced_kernel_for(int K) { GGS_KMAX_SWITCH(z_sliced_kernel) }
 const void *hot_kernel_for(int K) { GGS_KMAX_SWITCH(z_hot_kernel) }
+const void *pcgs_kernel_for(int K) { GGS_KMAX_SWITCH(pcgs_sliced_kernel) }
 
 int launch_pcgs_z(ggs_handle *h) {
   if (h->N == 0) return GGS_OK;
@@ -260,7 +262,12 @@ int launch_pcgs_z(ggs_handle *h) {
   pp.K = h->K; pp.Kp = h->Kp;
   const int64_t groups = (h->D + 63) / 64;
   const dim3 grid((unsigned)std::min<int64_t>(groups, (int64_t)h->num_cus * h->pcgs_waves_per_cu)), block(64);
-  hipLaunchKernelGGL(pcgs_z_kernel, grid, block, (size_t)h->pcgs_lds, h->stream, pp);
+  if (h->pcgs_sliced) {
+    void *args[] = {&pp};
+    HIP_TRY(h, hipLaunchKernel(pcgs_kernel_for(h->K), grid, block, args, (size_t)h->pcgs_lds, h->stream));
+  } else {
+    hipLaunchKernelGGL(pcgs_z_kernel, grid, block, (size_t)h->pcgs_lds, h->stream, pp);
+  }
   HIP_TRY(h, hipGetLastError());
   return GGS_OK;
 }
@@ -594,10 +601,18 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
   if (h->flags & GGS_FLAG_PCGS) {
     // pcgs_z_kernel: slice ring + alpha row + int16 [KT][64] document counts per single-wave workgroup
     const int ns = std::max(kPcgsRingSlots - 1, (h->K + kSliceTopics - 1) / kSliceTopics), kt = ns * kSliceTopics;
-    h->pcgs_lds = kPcgsRingSlots * kSliceBytes + kt * 8 + kt * 128;
+    h->pcgs_sliced = h->K <= kSlicedMaxTopics;
+    if (const char *e = std::getenv("GGS_DEBUG_PCGS_STREAM")) h->pcgs_sliced = h->pcgs_sliced && std::atoi(e) == 0;
+    if (h->pcgs_sliced) {
+      const int kmax = ((h->K + 7) / 8) * 8;                       // alpha row + counts below the ring (pcgs_sliced_kernel's kHead)
+      h->pcgs_lds = (kmax * 8 + kmax * 128 + 255) / 256 * 256 + kPcgsRingSlots * kSliceBytes;
+    } else {
+      h->pcgs_lds = kPcgsRingSlots * kSliceBytes + kt * 8 + kt * 128;
+    }
     if (h->pcgs_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);
     h->pcgs_waves_per_cu = std::max(1, std::min(8, kMaxLdsBytes / ((h->pcgs_lds + 2047) / 2048 * 2048)));
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(pcgs_z_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, h->pcgs_lds) != hipSuccess)
+    if (hipFuncSetAttribute(h->pcgs_sliced ? pcgs_kernel_for(h->K) : reinterpret_cast<const void *>(pcgs_z_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            h->pcgs_lds) != hipSuccess)
       return bail(GGS_ERR_HIP);
   }
   for (auto &E : h->evs) {

@@ -492,6 +492,23 @@ def test_pcgs_matches_oracle(native, oracle, K, alpha, beta):
         compare_state(g, o, "pcgs K=%d sweep %d" % (K, it + 1), theta=False)
 
 
+def test_pcgs_two_pass_kernel_below_193_topics(native, oracle, monkeypatch):
+    """K <= 192 normally takes pcgs_sliced_kernel (scores in registers); GGS_DEBUG_PCGS_STREAM=1 keeps the two-pass
+    pcgs_z_kernel, which larger K always use."""
+    monkeypatch.setenv("GGS_DEBUG_PCGS_STREAM", "1")
+    c = random_corpus(200, 300, 130, seed=3, empty_every=10)
+    g = native.GGSHandle(40, c.num_types, 0.1, 0.01, 5, flags=native.FLAG_PARANOID | native.FLAG_PCGS)
+    monkeypatch.delenv("GGS_DEBUG_PCGS_STREAM")
+    o = oracle.OracleSampler(40, c.num_types, 0.1, 0.01, 5, threads=4)
+    o.set_scheme("pcgs")
+    for s in (g, o):
+        s.set_corpus(c.doc_ptr, c.tokens)
+        s.init_z_java_lcg(2)
+        s.init_phi()
+        s.sweep(2)
+    compare_state(g, o, "pcgs two-pass K=40", theta=False)
+
+
 def test_pcgs_on_cats(native, oracle, cats):
     """cats: 23 documents of very different lengths, so the lanes of the one group finish at different steps."""
     K = 20

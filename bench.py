@@ -187,7 +187,7 @@ def main():
         achieved = n_local * btok / (z_ms * 1e-3) / 1e9 if z_ms > 0 else 0.0
         # the z step: for K <= 192 the cold-chunk kernel and, beside it on a second stream, the hot-chunk kernel
         kmax = 8 * ((K + 7) // 8)
-        zkernels = (["pcgs_z_kernel"] if args.scheme == "pcgs" else
+        zkernels = ((["pcgs_sliced_kernel<%d>" % kmax] if K <= 192 else ["pcgs_z_kernel"]) if args.scheme == "pcgs" else
                     ["z_sliced_kernel<%d>" % kmax, "z_hot_kernel<%d>" % kmax] if K <= 192 else ["z_stream_kernel"])
         line = {
             "metric": "M tokens sampled/sec (whole node) per Gibbs sweep at K=%d" % K + ("" if args.scheme == "ggs" else " (scheme=%s)" % args.scheme),

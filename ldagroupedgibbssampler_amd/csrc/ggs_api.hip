@@ -1103,7 +1103,7 @@ int ggs_check_invariants(ggs_handle *h) {
 
 int ggs_get_launch_info(ggs_handle *h, int64_t *num_chunks, int32_t *lds_bytes_z, int32_t *docs_per_block_theta) {
   if (!h) return GGS_ERR_BAD_ARG;
-  if (num_chunks) *num_chunks = h->C;
+  if (num_chunks) *num_chunks = h->z_sliced ? h->Cs : h->C;
   if (lds_bytes_z) *lds_bytes_z = h->z_lds;
   if (docs_per_block_theta) *docs_per_block_theta = h->theta_docs_per_block;
   return GGS_OK;

@@ -201,6 +201,19 @@ def test_synthetic_k100_slice(native, oracle):
     assert t["sweeps"] == 2 and t["tokens_sampled"] == 2 * c.num_tokens and t["z_ms"] > 0
 
 
+def test_synthetic_k100_medium(native, oracle):
+    """30 000 documents of the benchmark's corpus family (6 M tokens, V = 50 000, Zipfian words), a third of the benchmark:
+    every persistent wave walks dozens of cold and hot chunks, the ring wraps across chunk boundaries, the guest kernel
+    runs beside the cold one, the normalisers see the full vocabulary."""
+    c = synthetic_lda_corpus(30000, 50000, 200, true_topics=100, seed=7)
+    g, o = make_pair(native, oracle, c, 100, 0.1, 0.01, 31, zseed=32)
+    o.set_threads(16)
+    g.sweep(2)
+    o.sweep(2)
+    compare_state(g, o, "synthetic K=100, 30000 documents")
+    assert g.launch_info()["num_chunks"] > 40 * 1024
+
+
 def test_set_z_and_sample_z_given_phi(native, oracle):
     c = random_corpus(100, 200, 60, seed=9)
     K = 10
@@ -355,9 +368,9 @@ def test_error_behaviour(native):
 
 # ---------------------------------------------------------------- full size (properties only)
 def test_full_size_properties(native):
-    """BASELINE config 2 shape (D=100k, V=50k, ~20M tokens, K=100): too big for the oracle
-    in seconds, so check what does not depend on size: count invariants after every sweep,
-    z range, theta/phi rows summing to 1, and run-to-run determinism of the whole state."""
+    """BASELINE config 2 shape (D=100k, V=50k, ~20M tokens, K=100): what does not depend on size -- count invariants
+    after every sweep, z range, theta/phi rows summing to 1, run-to-run determinism of the whole state -- and two sweeps
+    of the oracle itself at full size (the GPU box has the host cores for it): z, n_k, phi, theta bit for bit."""
     import hashlib
     c = synthetic_lda_corpus(100000, 50000, 200, true_topics=100, seed=2019)
 
@@ -383,6 +396,18 @@ def test_full_size_properties(native):
     assert (phi > 0).all()
     *_, h2 = run()
     assert h1 == h2
+    # and, since the host has cores to spare for ONE sweep of the oracle at this size: the full benchmark state, bit for bit
+    import os
+    from oracle import oracle as O
+    o = O.OracleSampler(100, c.num_types, 0.1, 0.01, 2019, threads=min(64, os.cpu_count() or 4))
+    o.set_corpus(c.doc_ptr, c.tokens)
+    o.init_z_java_lcg(2019)
+    o.init_phi()
+    o.sweep(2)
+    assert_bit_equal(z, o.get_z(), "full size z")
+    assert_bit_equal(nk, o.get_topic_totals(), "full size n_k")
+    assert_bit_equal(phi, o.get_phi(), "full size phi")
+    assert_bit_equal(th, o.get_theta()[:2000], "full size theta (first 2000 documents)")
 
 
 def test_sharded_orchestration_over_rccl_single_rank(native, oracle):

@@ -6,9 +6,15 @@
 A "step" is one full sweep of BASELINE.json's configs[1]: synthetic LDA corpus D=100k,
 V=50k, mean 200 tokens/doc (~20M tokens), K=100, alpha=0.1, beta=0.01 -- theta draw +
 z draw + count merge (+ RCCL all-reduce of the deltas when N>1) + Phi re-draw, i.e. what
-UncollapsedParallelLDA.sample does between preZ() and postPhi() (UPLDA:659-687).  The corpus
-is FIXED as N grows (documents are sharded across the ranks), so scaling is "strong".
+UncollapsedParallelLDA.sample does between preZ() and postPhi() (UPLDA:659-687).
 Inputs are resident in HBM before the timed region; rank 0 prints ONE JSON line.
+
+N>1 shards the documents across the ranks (one count all-reduce per sweep).  Default
+`--scaling weak`: every rank holds a configs[1]-sized shard (rank r generates its D documents
+with seed+r; rank 0's shard IS the N=1 corpus), i.e. the corpus grows with the node, V and K
+stay -- the per-GPU work is fixed, `value` = tokens of all ranks / time.  `--scaling strong`
+keeps the N=1 corpus and splits it (2.5 M tokens per GPU at N=8: the replicated Phi draw and
+the all-reduce then dominate).
 
 N>1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -109,6 +115,8 @@ def main():
     ap.add_argument("--cpu-sample-docs", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scheme", default="ggs", choices=["ggs", "pcgs"], help="ggs = the headline path; pcgs = the partially collapsed z loop (SURVEY 8f-1), for comparison")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = D documents PER RANK (default), strong = the N=1 corpus split across the ranks")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the doc-sharded path (process group + RCCL all-reduce) even with one rank; for testing")
     args = ap.parse_args()
@@ -139,14 +147,29 @@ def main():
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     K = args.topics
-    corpus = synthetic_lda_corpus(args.docs, args.types, args.mean_len, true_topics=100, seed=args.seed)
-    z0 = java_lcg_initial_z(corpus.num_tokens, K, args.seed)
+    weak = sharded and args.scaling == "weak"
+    corpus = synthetic_lda_corpus(args.docs, args.types, args.mean_len, true_topics=100, seed=args.seed + (rank if weak else 0))
+    if weak:
+        sizes = torch.zeros(world, 2, dtype=torch.int64, device="cuda")
+        sizes[rank, 0], sizes[rank, 1] = corpus.num_docs, corpus.num_tokens
+        dist.all_reduce(sizes)
+        sizes = [(int(d), int(t)) for d, t in sizes.cpu().tolist()]
+        total_docs, total_tokens = sum(d for d, _ in sizes), sum(t for _, t in sizes)
+        tok_base = sum(t for _, t in sizes[:rank])
+        z0 = java_lcg_initial_z(tok_base + corpus.num_tokens, K, args.seed)[tok_base:]   # one sequential stream over the global corpus
+    else:
+        total_docs, total_tokens = corpus.num_docs, corpus.num_tokens
+        z0 = java_lcg_initial_z(corpus.num_tokens, K, args.seed)
 
     h = native.GGSHandle(K, corpus.num_types, args.alpha, args.beta, args.seed, device_id=local_rank,
                          flags=native.FLAG_PCGS if args.scheme == "pcgs" else 0)
     if sharded:
-        sh = ShardedGGS(h, TorchHipExchange, corpus, rank, world)
-        sh.set_z_global(z0)
+        if weak:
+            sh = ShardedGGS.from_local_shard(h, TorchHipExchange, corpus, sizes, rank, world)
+            sh.set_z_local(z0)
+        else:
+            sh = ShardedGGS(h, TorchHipExchange, corpus, rank, world)
+            sh.set_z_global(z0)
         def run(n):
             # one count exchange per sweep, enqueued back to back; the host waits once per batch of 5
             for i in range(0, n, 5):
@@ -191,20 +214,21 @@ def main():
                     ["z_sliced_kernel<%d>" % kmax, "z_hot_kernel<%d>" % kmax] if K <= 192 else ["z_stream_kernel"])
         line = {
             "metric": "M tokens sampled/sec (whole node) per Gibbs sweep at K=%d" % K + ("" if args.scheme == "ggs" else " (scheme=%s)" % args.scheme),
-            "value": round(corpus.num_tokens * args.steps / dt / 1e6, 3),
+            "value": round(total_tokens * args.steps / dt / 1e6, 3),
             "unit": "M tokens/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": "LDAGroupedGibbsSampler sweep, synthetic LDA corpus D=%d V=%d N=%d tokens K=%d alpha=%g beta=%g seed=%d"
-                            % (corpus.num_docs, corpus.num_types, corpus.num_tokens, K, args.alpha, args.beta, args.seed),
+                            % (total_docs, corpus.num_types, total_tokens, K, args.alpha, args.beta, args.seed)
+                            + (" (%d documents per rank)" % args.docs if weak else ""),
                 "parallelism": "doc-sharded x%d, int32 count all-reduce (RCCL) per sweep" % world if sharded else "1 GPU",
             },
             "roofline": {

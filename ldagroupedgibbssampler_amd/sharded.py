@@ -59,19 +59,39 @@ class ShardedGGS:
     def __init__(self, engine, exchange_factory, corpus, rank, world_size):
         self.engine, self.rank, self.world = engine, int(rank), int(world_size)
         self.bounds = even_split(corpus.num_docs, self.world)
-        sub, self.doc_base, self.tok_base = corpus.shard(self.bounds[self.rank], self.bounds[self.rank + 1])
-        self.local = sub
-        self.global_tokens = corpus.num_tokens
-        engine.set_corpus(sub.doc_ptr, sub.tokens, self.doc_base, self.tok_base)
-        engine.set_global_token_count(self.global_tokens)
-        self.exchange = exchange_factory(engine)
+        sub, doc_base, tok_base = corpus.shard(self.bounds[self.rank], self.bounds[self.rank + 1])
+        self._attach(exchange_factory, sub, doc_base, tok_base, corpus.num_tokens)
+
+    @classmethod
+    def from_local_shard(cls, engine, exchange_factory, shard, shard_sizes, rank, world_size):
+        """The rank already holds its documents (a corpus too large to build on every rank: each rank
+        loads or generates its own part).  ``shard_sizes`` = [(num_docs, num_tokens)] of every rank in
+        rank order, e.g. from an all-gather; the global corpus is the concatenation of the shards."""
+        self = cls.__new__(cls)
+        self.engine, self.rank, self.world = engine, int(rank), int(world_size)
+        if len(shard_sizes) != self.world or tuple(shard_sizes[self.rank]) != (shard.num_docs, shard.num_tokens):
+            raise ValueError("shard_sizes must list (num_docs, num_tokens) of every rank, this rank's own included")
+        docs = np.concatenate([[0], np.cumsum([int(d) for d, _ in shard_sizes])])
+        toks = np.concatenate([[0], np.cumsum([int(t) for _, t in shard_sizes])])
+        self.bounds = [int(x) for x in docs]
+        self._attach(exchange_factory, shard, int(docs[self.rank]), int(toks[self.rank]), int(toks[-1]))
+        return self
+
+    def _attach(self, exchange_factory, sub, doc_base, tok_base, global_tokens):
+        self.local, self.doc_base, self.tok_base, self.global_tokens = sub, doc_base, tok_base, global_tokens
+        self.engine.set_corpus(sub.doc_ptr, sub.tokens, doc_base, tok_base)
+        self.engine.set_global_token_count(global_tokens)
+        self.exchange = exchange_factory(self.engine)
 
     def set_z_global(self, z_global):
         """Start-up: every rank takes its slice of the corpus-wide z (e.g. the seeded
         java.util.Random initialisation, which is one sequential stream and therefore
         computed once), builds local counts, sum-all-reduces them, draws the initial Phi."""
-        z_local = np.ascontiguousarray(z_global[self.tok_base:self.tok_base + self.local.num_tokens], np.int32)
-        self.engine.set_z(z_local, redraw_phi=False)
+        self.set_z_local(z_global[self.tok_base:self.tok_base + self.local.num_tokens])
+
+    def set_z_local(self, z_local):
+        """The same start-up from this shard's own slice of z."""
+        self.engine.set_z(np.ascontiguousarray(z_local, np.int32), redraw_phi=False)
         self.exchange.allreduce_startup()
         self.engine.init_phi()
 

@@ -121,6 +121,74 @@ def test_two_rank_sharded_sweep_equals_unsharded(oracle, tmp_path, scheme):
         assert np.array_equal(p["phi"].view(np.int64), ref.get_phi().view(np.int64))
 
 
+def _local_shards(world):
+    from ldagroupedgibbssampler_amd.corpus import random_corpus
+    return [random_corpus(40 + 23 * r, 120, 50, seed=100 + r, empty_every=7) for r in range(world)]
+
+
+def _worker_local(rank, world, port, out_dir):
+    """Every rank brings its OWN documents (bench.py --scaling weak): ShardedGGS.from_local_shard."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from ldagroupedgibbssampler_amd.sharded import ShardedGGS, java_lcg_initial_z
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = _local_shards(world)[rank]
+    sizes = torch.zeros(world, 2, dtype=torch.int64)
+    sizes[rank, 0], sizes[rank, 1] = c.num_docs, c.num_tokens
+    dist.all_reduce(sizes)
+    sizes = [tuple(r) for r in sizes.tolist()]
+    K = 9
+    eng = OracleEngine(O, K, c.num_types, 0.1, 0.01, 4242)
+    sh = ShardedGGS.from_local_shard(eng, GlooExchange, c, sizes, rank, world)
+    sh.set_z_local(java_lcg_initial_z(sh.tok_base + c.num_tokens, K, 77)[sh.tok_base:])
+    sh.sweep(2)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), z=eng.o.get_z(), nwk=eng.o.get_type_topic_counts(), phi=eng.o.get_phi(),
+             theta=eng.o.get_theta(), global_tokens=sh.global_tokens)
+    dist.destroy_process_group()
+
+
+def test_two_ranks_with_own_shards_equal_the_concatenated_corpus(oracle, tmp_path):
+    import torch.multiprocessing as mp
+    from ldagroupedgibbssampler_amd.corpus import Corpus
+    from ldagroupedgibbssampler_amd.sharded import java_lcg_initial_z
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 2
+    mp.spawn(_worker_local, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+
+    shards = _local_shards(world)
+    ptr = [np.zeros(1, np.int64)]
+    for c in shards:
+        ptr.append(c.doc_ptr[1:] + ptr[-1][-1])
+    whole = Corpus(np.concatenate(ptr), np.concatenate([c.tokens for c in shards]), 120)
+    K = 9
+    ref = oracle.OracleSampler(K, 120, 0.1, 0.01, 4242)
+    ref.set_corpus(whole.doc_ptr, whole.tokens)
+    ref.set_z(java_lcg_initial_z(whole.num_tokens, K, 77), redraw_phi=True)
+    ref.sweep(2)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    assert all(int(p["global_tokens"]) == whole.num_tokens for p in parts)
+    assert np.array_equal(np.concatenate([p["z"] for p in parts]), ref.get_z())
+    assert np.array_equal(np.concatenate([p["theta"] for p in parts]).view(np.int64), ref.get_theta().view(np.int64))
+    for p in parts:
+        assert np.array_equal(p["nwk"], ref.get_type_topic_counts())
+        assert np.array_equal(p["phi"].view(np.int64), ref.get_phi().view(np.int64))
+
+
+def test_from_local_shard_rejects_wrong_sizes(oracle):
+    from ldagroupedgibbssampler_amd.sharded import ShardedGGS
+    c = _local_shards(1)[0]
+    eng = OracleEngine(oracle, 4, c.num_types, 0.1, 0.01, 1)
+    with pytest.raises(ValueError):
+        ShardedGGS.from_local_shard(eng, lambda e: None, c, [(c.num_docs, c.num_tokens + 1)], 0, 1)
+
+
 def test_even_split_rule():
     """randomscan/document/EvenSplitBatchBuilder.java:30-44: sizes n//p + (remainder > b)."""
     from ldagroupedgibbssampler_amd.corpus import even_split

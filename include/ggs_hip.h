@@ -61,7 +61,8 @@ enum {
   GGS_PURPOSE_Z = 1,       /* elem = global token index          */
   GGS_PURPOSE_THETA = 2,   /* elem = global doc index * K + k    */
   GGS_PURPOSE_PHI = 3,     /* elem = k * V + v                   */
-  GGS_PURPOSE_INIT_PHI = 4 /* elem = k * V + v                   */
+  GGS_PURPOSE_INIT_PHI = 4,/* elem = k * V + v                   */
+  GGS_PURPOSE_HELDOUT = 5  /* elem = global test doc * numParticles + particle; one uniform per in-vocabulary token */
 };
 #define GGS_MAX_BLOCKS 4096
 
@@ -196,6 +197,19 @@ int ggs_model_log_likelihood(ggs_handle *h, double *doc_side, double *topic_side
  * -- to compute what is a sum over tokens.)  Same accuracy contract as ggs_model_log_likelihood.
  * GGS_ERR_UNSUPPORTED for scheme pcgs, whose diagnostic theta is a fresh random draw (UPLDA:712-714). */
 int ggs_log_posterior(ggs_handle *h, double *doc_side, double *topic_side);
+/* replaces: addTestInstances (UPLDA:340-343; the test set of the held-out estimator).  CSR like ggs_set_corpus; token
+ * ids are indices of the TRAINING alphabet, ids >= num_types are out of vocabulary and skipped as at MPE:341-345.
+ * doc_base = global index of the first test document (RNG element ids only; for a sharded test set).  Documents longer
+ * than 2*GGS_MAX_BLOCKS tokens: GGS_ERR_UNSUPPORTED. */
+int ggs_set_test_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr /*D+1*/, const int32_t *tokens, int64_t doc_base);
+/* replaces: new MarginalProbEstimatorPlain(numTopics, alpha, alphaSum, beta, typeTopicCounts, tokensPerTopic)
+ * .evaluateLeftToRight(testSet, numParticles, null) (MPE:51-121,123-519; call sites UPLDA:604-622,677-682,840-844 with
+ * numParticles = 100, UPLDA:615) on the handle's CURRENT counts (corpus-wide after the sweep's exchange): the
+ * left-to-right estimate of the test set's log likelihood, without the resampling pass (MPE:125).  doc_ll (D or NULL)
+ * = the per-document values (what Java prints to docProbabilityStream); *total = their sum in document order.
+ * Bit-identical to the oracle's restatement under the Philox stream GGS_PURPOSE_HELDOUT (the reference's Randoms is
+ * clock-seeded).  The estimator's IllegalStateException ("Sampled invalid topic") -> GGS_ERR_INVALID_TOPIC. */
+int ggs_heldout_log_likelihood(ggs_handle *h, int32_t num_particles, double *doc_ll, double *total);
 /* out[k] = x[0][k] + x[1][k] + ... in index order (exactly one of x / counts given; with counts the addends are
  * beta + counts[v][k]): the Phi normalisers' exact parallel column sum on its own, for adversarial inputs */
 int ggs_debug_column_sum(int32_t device_id, int32_t V, int32_t K, const double *x /*V*K or NULL*/, const int32_t *counts /*V*K or NULL*/,

@@ -91,6 +91,8 @@ SIGNATURES = {
                                  _dp, _dp, _ip]),
     "ggs_model_log_likelihood": (C.c_int, [_vp, _dp, _dp]),
     "ggs_log_posterior": (C.c_int, [_vp, _dp, _dp]),
+    "ggs_set_test_corpus": (C.c_int, [_vp, C.c_int64, _lp, _ip, C.c_int64]),
+    "ggs_heldout_log_likelihood": (C.c_int, [_vp, C.c_int32, _dp, _dp]),
     "ggs_debug_column_sum": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _ip, C.c_double, _dp]),
 }
 

@@ -18,6 +18,7 @@
 #include "ggs_exact_sum.hpp"
 #include "ggs_z_pcgs.hpp"
 #include "ggs_loglik.hpp"
+#include "ggs_heldout.hpp"
 
 using namespace ggs;
 
@@ -83,6 +84,13 @@ struct ggs_handle {
   int32_t sum_nseg = 0;
   bool exact_sum = true;                               // GGS_DEBUG_CHAIN=1: the element-by-element column_chain_kernel instead
   uint32_t *d_status = nullptr;
+  // test set of the held-out estimator (ggs_heldout.hpp)
+  int64_t *d_test_ptr = nullptr;
+  int32_t *d_test_tok = nullptr;
+  double *d_test_ll = nullptr;
+  std::vector<int64_t> test_ptr;
+  int64_t test_doc_base = 0;
+  bool have_test = false;
   void *d_scratch = nullptr;
   size_t scratch_bytes = 0;
 
@@ -642,7 +650,8 @@ void ggs_destroy(ggs_handle *h) {
   (void)hipDeviceSynchronize();
   void *bufs[] = {h->d_doc_ptr, h->d_chunk_start, h->d_tok, h->d_z, h->d_chunk_doc, h->d_chunk_len, h->d_alpha, h->d_theta, h->d_theta_next,
                   h->d_phiT, h->d_mag, h->d_tot, h->d_phi_mean, h->d_n_wk, h->d_n_k, h->d_perm, h->d_inv_perm, h->d_zw, h->d_seg_word, h->d_seg_begin,
-                  h->d_status, h->d_scratch, h->d_sum_pref, h->d_sum_fn, h->d_ct_tok, h->d_ct_idx, h->d_ct_ip, h->d_c_docs, h->d_hot_words, h->d_order};
+                  h->d_status, h->d_scratch, h->d_sum_pref, h->d_sum_fn, h->d_ct_tok, h->d_ct_idx, h->d_ct_ip, h->d_c_docs, h->d_hot_words, h->d_order,
+                  h->d_test_ptr, h->d_test_tok, h->d_test_ll};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (auto &E : h->evs) {
@@ -1070,6 +1079,86 @@ int ggs_log_posterior(ggs_handle *h, double *doc_side, double *topic_side) {
   *doc_side = out[0]; *topic_side = out[1];
   return GGS_OK;
 }
+int ggs_set_test_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32_t *tokens, int64_t doc_base) {
+  if (!h || D < 0 || !doc_ptr || doc_base < 0) return set_err(h, GGS_ERR_BAD_ARG, "bad test corpus arguments");
+  if (doc_ptr[0] != 0) return set_err(h, GGS_ERR_BAD_ARG, "doc_ptr[0] must be 0");
+  for (int64_t d = 0; d < D; ++d) {
+    if (doc_ptr[d + 1] < doc_ptr[d]) return set_err(h, GGS_ERR_BAD_ARG, "doc_ptr must be non-decreasing");
+    if (doc_ptr[d + 1] - doc_ptr[d] > 2 * (int64_t)GGS_MAX_BLOCKS)
+      return set_err(h, GGS_ERR_UNSUPPORTED, "a test document has more than 2*GGS_MAX_BLOCKS tokens (one Philox stream per particle)");
+  }
+  const int64_t N = doc_ptr[D];
+  if (N > 0 && !tokens) return set_err(h, GGS_ERR_BAD_ARG, "tokens is null");
+  for (int64_t i = 0; i < N; ++i)
+    if (tokens[i] < 0) return set_err(h, GGS_ERR_BAD_ARG, "negative token id");    // ids >= num_types are out of vocabulary (MPE:341-345)
+  int rc = bind_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if ((rc = dev_alloc(h, &h->d_test_ptr, (size_t)D + 1)) || (rc = dev_alloc(h, &h->d_test_tok, (size_t)N)) || (rc = dev_alloc(h, &h->d_test_ll, (size_t)D))) return rc;
+  HIP_TRY(h, hipMemcpy(h->d_test_ptr, doc_ptr, sizeof(int64_t) * (size_t)(D + 1), hipMemcpyHostToDevice));
+  if (N) HIP_TRY(h, hipMemcpy(h->d_test_tok, tokens, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice));
+  h->test_ptr.assign(doc_ptr, doc_ptr + D + 1);
+  h->test_doc_base = doc_base;
+  h->have_test = true;
+  return GGS_OK;
+}
+
+int ggs_heldout_log_likelihood(ggs_handle *h, int32_t num_particles, double *doc_ll, double *total) {
+  int rc = require_ready(h, false);
+  if (rc) return rc;
+  if (!h->have_test) return set_err(h, GGS_ERR_STATE, "no test set: call ggs_set_test_corpus first");
+  if (num_particles < 1 || !total) return set_err(h, GGS_ERR_BAD_ARG, "num_particles < 1 or null output");
+  const int K = h->K;
+  const int64_t D = (int64_t)h->test_ptr.size() - 1;
+  // LDS: alpha and the denominators once per block, 2 bytes per (particle, topic) per wave
+  int waves = kHeldoutMaxWaves;
+  auto lds_of = [&](int w) { return (size_t)16 * K + (size_t)w * K * 128; };
+  while (waves > 1 && lds_of(waves) > (size_t)64 * 1024) waves >>= 1;      // <= 64 KiB per block keeps several blocks on a CU
+  if (lds_of(waves) > (size_t)160 * 1024) return set_err(h, GGS_ERR_UNSUPPORTED, "num_topics too large for the held-out estimator's per-particle counts in LDS");
+  if (lds_of(waves) > (size_t)48 * 1024)
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(waves)));
+  // wordProbabilities of a batch of documents: tokens x particles doubles, at most ~1 GiB at a time
+  const int64_t cap_cells = std::max<int64_t>((int64_t)1 << 27, 2 * (int64_t)GGS_MAX_BLOCKS * num_particles);
+  int64_t max_cells = 0;
+  std::vector<int64_t> cuts{0};
+  for (int64_t d = 0; d < D;) {
+    int64_t e = d;
+    while (e < D && (h->test_ptr[e + 1] - h->test_ptr[d]) * num_particles <= cap_cells) ++e;
+    max_cells = std::max(max_cells, (h->test_ptr[e] - h->test_ptr[d]) * num_particles);
+    cuts.push_back(e);
+    d = e;
+  }
+  const size_t tab_bytes = sizeof(double) * (size_t)(2 * K + 2);
+  if ((rc = ensure_scratch(h, tab_bytes + sizeof(double) * (size_t)std::max<int64_t>(max_cells, 1)))) return rc;
+  HeldoutParams hp{};
+  hp.doc_ptr = h->d_test_ptr; hp.tok = h->d_test_tok; hp.n_wk = h->d_n_wk;
+  auto *tab = static_cast<double *>(h->d_scratch);
+  hp.tab = tab; hp.probs = tab + 2 * K + 2; hp.doc_ll = h->d_test_ll; hp.status = h->d_status;
+  hp.beta = h->beta;
+  double alpha_sum = 0;
+  for (int k = 0; k < K; ++k) alpha_sum += h->alpha[k];
+  hp.alpha_sum = alpha_sum;
+  hp.seed = h->seed; hp.iteration = (uint32_t)h->iteration; hp.doc_base = h->test_doc_base;
+  hp.K = K; hp.V = h->V; hp.P = num_particles; hp.blocks_per_doc = (num_particles + 63) / 64; hp.waves = waves;
+  hipLaunchKernelGGL(heldout_setup_kernel, dim3(1), dim3(64), 0, h->stream, h->d_alpha, h->d_n_k, h->beta, h->beta * h->V, K, tab);
+  for (size_t b = 0; b + 1 < cuts.size(); ++b) {
+    hp.d0 = cuts[b]; hp.d1 = cuts[b + 1];
+    const int64_t units = (hp.d1 - hp.d0) * hp.blocks_per_doc;
+    if (units == 0) continue;
+    hipLaunchKernelGGL(heldout_particles_kernel, dim3((unsigned)((units + waves - 1) / waves)), dim3(waves * 64), lds_of(waves), h->stream, hp);
+    hipLaunchKernelGGL(heldout_reduce_kernel, dim3((unsigned)((hp.d1 - hp.d0 + 3) / 4)), dim3(256), 0, h->stream, hp);
+  }
+  HIP_TRY(h, hipGetLastError());
+  std::vector<double> ll((size_t)D);
+  if (D) HIP_TRY(h, hipMemcpyAsync(ll.data(), h->d_test_ll, sizeof(double) * (size_t)D, hipMemcpyDeviceToHost, h->stream));
+  if ((rc = check_status(h))) return rc;                    // synchronises; MPE:416,447,455,464-469 surface here
+  double t = 0;
+  for (int64_t d = 0; d < D; ++d) t += ll[(size_t)d];       // MPE:116: in document order
+  *total = t;
+  if (doc_ll && D) std::memcpy(doc_ll, ll.data(), sizeof(double) * (size_t)D);
+  return GGS_OK;
+}
+
 int ggs_get_timings(ggs_handle *h, ggs_timings *out) { if (!h || !out) return GGS_ERR_BAD_ARG; *out = h->tm; return GGS_OK; }
 int ggs_reset_timings(ggs_handle *h) { if (!h) return GGS_ERR_BAD_ARG; h->tm = ggs_timings{}; return GGS_OK; }
 

@@ -1,0 +1,186 @@
+// ggs_heldout.hpp -- MarginalProbEstimatorPlain.evaluateLeftToRight (topics/MarginalProbEstimatorPlain.java:85-121,
+// 123-519; usingResampling = false, :125) on the device: the left-to-right held-out log likelihood the sampling
+// loop computes on the test set every diagnostic iteration (UPLDA:604-611,677-682,840-844; 100 particles, :615).
+// In Java it is numParticles x test tokens x K serial work per evaluation.  SURVEY 8(f)-2.
+//
+// One particle's pass over one document is sequential (its topic counts run along the positions); particles and
+// documents are independent.  A wave = 64 particles of one document, walking the positions together, so the word's
+// typeTopicCounts row is wave-uniform: it is read once, its non-zero cells found with a ballot, and only those enter
+// the score loop -- a zero count contributes +0.0 to topicTermMass and nothing to the walk (MPE:352-365,409-415), so
+// skipping it is exact.  cachedCoefficients[k] is a function of (k, this particle's count of k) alone (MPE:78,502-504,
+// 514-519): (alpha_k + n) / (tokensPerTopic_k + betaSum), recomputed by one IEEE division where it is used, which
+// leaves 2 bytes per (particle, topic) of state in LDS instead of 10.
+//
+// The reference draws from a clock-seeded Randoms (MPE:64,87): the stream is ours -- purpose GGS_PURPOSE_HELDOUT,
+// element = global test document * numParticles + particle, one uniform per in-vocabulary token, in sequence.
+// Bit-identical to oracle/ggs_oracle.c:orc_heldout_log_likelihood, per document and in total (the total is added in
+// document order on the host from the per-document values).
+#pragma once
+#include "ggs_kernels.hpp"
+
+namespace ggs {
+
+struct HeldoutParams {
+  const int64_t *doc_ptr;   // test documents [D+1]
+  const int32_t *tok;       // test tokens; ids >= V are out of vocabulary and skipped (MPE:341-345)
+  const int32_t *n_wk;      // typeTopicCounts [V][K]
+  const double *tab;        // [0] smoothingOnlyMass, then alpha[K], then denom[K] = tokensPerTopic + betaSum
+  double *probs;            // wordProbabilities of the batch: (doc_ptr[d] - doc_ptr[d0]) * P + particle * len_d + position
+  double *doc_ll;           // [D]
+  uint32_t *status;
+  double beta, alpha_sum;
+  uint64_t seed;
+  uint32_t iteration;
+  int64_t d0, d1, doc_base; // this launch covers test documents [d0, d1)
+  int32_t K, V, P, blocks_per_doc, waves;
+};
+
+constexpr int kHeldoutMaxWaves = 4;
+
+// alpha, denominators and smoothingOnlyMass (MPE:63,75-78), one thread: the mass is one running double
+__global__ void heldout_setup_kernel(const double *alpha, const int32_t *n_k, double beta, double beta_sum, int32_t K, double *tab) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double smoothing = 0;
+  for (int k = 0; k < K; ++k) {
+    const double denom = (double)n_k[k] + beta_sum;
+    smoothing += alpha[k] * beta / denom;
+    tab[1 + k] = alpha[k];
+    tab[1 + K + k] = denom;
+  }
+  tab[0] = smoothing;
+}
+
+__global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kernel(HeldoutParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int K = p.K;
+  double *alpha_s = reinterpret_cast<double *>(smem);
+  double *denom_s = alpha_s + K;
+  for (int k = threadIdx.x; k < 2 * K; k += blockDim.x) alpha_s[k] = p.tab[1 + k];
+  __syncthreads();
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int16_t *cnt_s = reinterpret_cast<int16_t *>(denom_s + K) + (size_t)wave * K * 64;
+  const int64_t unit = (int64_t)blockIdx.x * p.waves + wave;
+  const int64_t d = p.d0 + unit / p.blocks_per_doc;
+  if (d >= p.d1) return;                                                // no block-wide barrier below
+  const int particle = (int)(unit % p.blocks_per_doc) * 64 + lane;
+  const bool live = particle < p.P;                                     // dead lanes compute along, store nothing
+  const int64_t beg = p.doc_ptr[d], len = p.doc_ptr[d + 1] - beg;
+  double *out = p.probs + (beg - p.doc_ptr[p.d0]) * p.P + (int64_t)particle * len;
+  for (int k = 0; k < K; ++k) cnt_s[k * 64 + lane] = 0;
+  const double smoothing = p.tab[0], beta = p.beta;
+  const uint64_t elem = (uint64_t)(p.doc_base + d) * (uint64_t)p.P + (uint64_t)particle;
+  double beta_mass = 0.0, u_odd = 0.0;
+  int so_far = 0;                                                       // tokensSoFar: wave-uniform
+  bool bad = false;
+  for (int64_t limit = 0; limit < len; ++limit) {
+    const int32_t type = __builtin_amdgcn_readfirstlane(p.tok[beg + limit]);
+    if (type >= p.V) { if (live) out[limit] = 0.0; continue; }
+    const int32_t *row = p.n_wk + (size_t)type * K;
+    // MPE:352-365: topicTermMass in topic order, zero cells skipped
+    double mass = 0.0;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+      const int32_t v = k0 + lane < K ? row[k0 + lane] : 0;
+      uint64_t m = __ballot(v != 0);
+      while (m) {
+        const int b = __builtin_ctzll(m);
+        m &= m - 1;
+        const int k = k0 + b;
+        const int32_t c = __builtin_amdgcn_readlane(v, b);
+        const double coef = (alpha_s[k] + (double)cnt_s[k * 64 + lane]) / denom_s[k];
+        mass += coef * (double)c;
+      }
+    }
+    const double total = smoothing + beta_mass + mass;
+    double u;
+    if ((so_far & 1) == 0) {
+      const U4 o = philox4x32_10((uint32_t)elem, (uint32_t)(elem >> 32), ((uint32_t)GGS_PURPOSE_HELDOUT << 24) | (uint32_t)(so_far >> 1),
+                                 p.iteration, (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
+      u = u53(o.x, o.y);
+      u_odd = u53(o.z, o.w);
+    } else {
+      u = u_odd;
+    }
+    double sample = u * total;                                          // MPE:393
+    if (live) out[limit] = total / (p.alpha_sum + (double)so_far);      // MPE:399-401
+    ++so_far;
+    int newTopic = -1;
+    const bool in_term = sample < mass;
+    if (__ballot(in_term)) {                                            // MPE:409-419, the same products again
+      bool walking = in_term && sample > 0;
+      for (int k0 = 0; k0 < K; k0 += 64) {
+        const int32_t v = k0 + lane < K ? row[k0 + lane] : 0;
+        uint64_t m = __ballot(v != 0);
+        while (m) {
+          const int b = __builtin_ctzll(m);
+          m &= m - 1;
+          const int k = k0 + b;
+          const int32_t c = __builtin_amdgcn_readlane(v, b);
+          const double coef = (alpha_s[k] + (double)cnt_s[k * 64 + lane]) / denom_s[k];
+          const double score = coef * (double)c;
+          if (walking) {
+            sample -= score;
+            if (!(sample > 0)) { newTopic = k; walking = false; }
+          }
+        }
+        if (!__ballot(walking)) break;
+      }
+    }
+    if (!in_term) {
+      sample -= mass;
+      const bool in_beta = sample < beta_mass;
+      if (in_beta) sample /= beta; else { sample -= beta_mass; sample /= beta; }
+      if (__ballot(in_beta)) {                                          // MPE:423-440: this particle's topics, ascending
+        bool walking = in_beta;
+        for (int k = 0; k < K; ++k) {
+          const int n = cnt_s[k * 64 + lane];
+          if (walking && n > 0) {
+            sample -= (double)n / denom_s[k];
+            if (sample <= 0.0) { newTopic = k; walking = false; }
+          }
+          if (!__ballot(walking)) break;
+        }
+      }
+      if (__ballot(!in_beta)) {                                         // MPE:442-460: the smoothing-only bucket
+        bool walking = !in_beta;
+        if (walking) { newTopic = 0; sample -= alpha_s[0] / denom_s[0]; }
+        for (int k = 1; __ballot(walking && sample > 0.0); ++k) {
+          if (k >= K) break;
+          if (walking && sample > 0.0) { newTopic = k; sample -= alpha_s[k] / denom_s[k]; }
+        }
+        if (walking && sample > 0.0) newTopic = -1;                     // ran past the last topic (MPE:455)
+      }
+    }
+    if (newTopic < 0) { bad = true; newTopic = 0; }                     // MPE:416,447,455,464-469 throw
+    const int n_old = cnt_s[newTopic * 64 + lane];
+    beta_mass -= beta * (double)n_old / denom_s[newTopic];              // MPE:474-475
+    cnt_s[newTopic * 64 + lane] = (int16_t)(n_old + 1);
+    beta_mass += beta * (double)(n_old + 1) / denom_s[newTopic];        // MPE:506-507
+  }
+  if (bad && live) atomicOr(p.status, ST_INVALID_TOPIC);
+}
+
+// MPE:102-116: per position the sum over the particles in particle order, log, minus log(numParticles); per document
+// the sum over the positions in order.  One wave per document.
+__global__ __launch_bounds__(256) void heldout_reduce_kernel(HeldoutParams p) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int64_t d = p.d0 + (int64_t)blockIdx.x * 4 + wave;
+  if (d >= p.d1) return;
+  const int64_t beg = p.doc_ptr[d], len = p.doc_ptr[d + 1] - beg;
+  const double *in = p.probs + (beg - p.doc_ptr[p.d0]) * p.P;
+  const double log_particles = strict_log((double)p.P);
+  double doc_ll = 0.0;
+  for (int64_t pos0 = 0; pos0 < len; pos0 += 64) {
+    const int64_t pos = pos0 + lane;
+    double term = 0.0;
+    if (pos < len) {
+      double sum = 0.0;
+      for (int q = 0; q < p.P; ++q) sum += in[(int64_t)q * len + pos];
+      if (sum > 0.0) term = strict_log(sum) - log_particles;            // else: skipped, and x + 0.0 == x
+    }
+    const int n = (int)(len - pos0 < 64 ? len - pos0 : 64);
+    for (int j = 0; j < n; ++j) doc_ll += __shfl(term, j);               // every lane runs the same chain
+  }
+  if (lane == 0) p.doc_ll[d] = doc_ll;
+}
+
+}  // namespace ggs

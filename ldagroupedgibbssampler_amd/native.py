@@ -202,6 +202,22 @@ class GGSHandle:
         self._chk(self._L.ggs_log_posterior(self._h, C.byref(a), C.byref(b)))
         return a.value, b.value
 
+    def set_test_corpus(self, doc_ptr, tokens, doc_base=0):
+        """addTestInstances (MSLDA:918-923): the held-out estimator's test set; ids >= num_types are out of vocabulary."""
+        doc_ptr = np.ascontiguousarray(doc_ptr, np.int64)
+        tokens = np.ascontiguousarray(tokens, np.int32)
+        self._test_docs = doc_ptr.size - 1
+        self._chk(self._L.ggs_set_test_corpus(self._h, self._test_docs, doc_ptr.ctypes.data_as(C.POINTER(C.c_int64)),
+                                              tokens.ctypes.data_as(C.POINTER(C.c_int32)), int(doc_base)))
+
+    def heldout_log_likelihood(self, num_particles=100):
+        """MarginalProbEstimatorPlain.evaluateLeftToRight (MPE:85-121) on the current counts, on the device:
+        (total, per-document values)."""
+        doc_ll = np.zeros(getattr(self, "_test_docs", 0), np.float64)
+        tot = C.c_double()
+        self._chk(self._L.ggs_heldout_log_likelihood(self._h, int(num_particles), doc_ll.ctypes.data_as(C.POINTER(C.c_double)), C.byref(tot)))
+        return tot.value, doc_ll
+
     def launch_info(self):
         c, l, b = C.c_int64(), C.c_int32(), C.c_int32()
         self._chk(self._L.ggs_get_launch_info(self._h, C.byref(c), C.byref(l), C.byref(b)))

@@ -146,7 +146,23 @@ class LDAGroupedGibbsSampler:
         self.currentIteration = 0
 
     def addTestInstances(self, test_set):
-        raise NotImplementedError("held-out evaluation (MarginalProbEstimatorPlain) stays on the Java side; SURVEY 8f-2")
+        """MSLDA:918-923: the test set of the held-out estimator; it must share the training alphabet
+        ("Alphabets on training and test sets do not match!")."""
+        self._need_data()
+        if not isinstance(test_set, Corpus):
+            raise TypeError("addTestInstances expects a ldagroupedgibbssampler_amd.corpus.Corpus")
+        if test_set.num_types != self._corpus.num_types:
+            raise ValueError("Alphabets on training and test sets do not match!")
+        self._h.set_test_corpus(test_set.doc_ptr, test_set.tokens)
+        self._test_set = test_set
+
+    def heldOutLogLikelihood(self, num_particles=100):
+        """What the sampling loop logs when a test set is present (UPLDA:604-622,840-844):
+        MarginalProbEstimatorPlain(...).evaluateLeftToRight(testSet, 100, null), on the device."""
+        self._need_data()
+        if getattr(self, "_test_set", None) is None:
+            raise ValueError("no test set: call addTestInstances first")
+        return self._h.heldout_log_likelihood(num_particles)[0]
 
     def sample(self, iterations):
         """UPLDA:552-943 without the host-side diagnostics: one native sweep per iteration so the

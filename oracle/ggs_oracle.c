@@ -962,6 +962,151 @@ void orc_log_posterior(const orc_state *s, double *doc_side, double *topic_side)
   free(n_dj); free(cell);
 }
 
+/* ------------------------------------------------------------------------ */
+/* topics/MarginalProbEstimatorPlain.java: the left-to-right held-out estimator the sampling loop calls on the
+ * test set every diagnostic iteration (UPLDA:604-611,677-682,840-844; 100 particles, UPLDA:615).  Restated in the
+ * Java operation order with usingResampling = false (MPE:125, "The resampling implementation is broken").
+ *   ctor            MPE:51-79     betaSum = beta * V; smoothingOnlyMass; cachedCoefficients
+ *   leftToRight     MPE:123-519   one particle's pass over one document
+ *   evaluateLeftToRight MPE:85-121 per position: sum over particles, log, minus log(numParticles)
+ * The reference draws from a clock-seeded `new Randoms()` (MPE:64,87): not reproducible, so the stream is ours --
+ * purpose ORC_PURPOSE_HELDOUT, element = (doc_base + doc) * numParticles + particle, the uniforms of one particle
+ * taken in sequence (one per in-vocabulary token); Randoms.nextUniform is taken to be nextDouble (as for the
+ * collapsed path).  Math.log is the fdlibm log used everywhere else here.  Parity unpinned against a JVM run. */
+static int left_to_right(orc_state *s, const int32_t *tok, int64_t docLength, uint64_t elem, double betaSum, double smoothingOnlyMass,
+                         double alphaSum, double *cachedCoefficients, int32_t *localTopicCounts, int32_t *localTopicIndex,
+                         double *topicTermScores, double *wordProbabilities) {
+  const int32_t numTopics = s->K;
+  const double beta = s->beta;
+  const int32_t *tokensPerTopic = s->n_k;
+  int rc = ORC_OK;
+  int tokensSoFar = 0, nonZeroTopics = 0, denseIndex;
+  double topicBetaMass = 0.0, topicTermMass;
+  draw_rng r; draw_init(&r, s->seed, (uint32_t)s->iteration, ORC_PURPOSE_HELDOUT, elem);
+  memset(localTopicCounts, 0, sizeof(int32_t) * (size_t)numTopics);
+  for (int64_t limit = 0; limit < docLength; limit++) wordProbabilities[limit] = 0.0;
+  for (int64_t limit = 0; limit < docLength; limit++) {
+    const int32_t type = tok[limit];
+    if (type >= s->V) continue;                                           /* MPE:341-345 out-of-vocabulary */
+    const int32_t *currentTypeTopicCounts = s->n_wk + (size_t)type * numTopics;
+    topicTermMass = 0.0;
+    for (int32_t index = 0; index < numTopics; index++) {                 /* MPE:352-365 */
+      double score = cachedCoefficients[index] * currentTypeTopicCounts[index];
+      topicTermMass += score;
+      topicTermScores[index] = score;
+    }
+    double sample = draw_next_double(&r) * (smoothingOnlyMass + topicBetaMass + topicTermMass);   /* MPE:393 */
+    wordProbabilities[limit] += (smoothingOnlyMass + topicBetaMass + topicTermMass) / (alphaSum + tokensSoFar);   /* MPE:399-401 */
+    tokensSoFar++;
+    int32_t newTopic = -1;
+    if (sample < topicTermMass) {                                         /* MPE:409-419 */
+      int32_t i = -1;
+      while (sample > 0) {
+        i++;
+        if (i >= numTopics) break;                                        /* Java: ArrayIndexOutOfBoundsException */
+        sample -= topicTermScores[i];
+      }
+      newTopic = i;
+    } else {
+      sample -= topicTermMass;
+      if (sample < topicBetaMass) {                                       /* MPE:423-440 */
+        sample /= beta;
+        for (denseIndex = 0; denseIndex < nonZeroTopics; denseIndex++) {
+          int32_t topic = localTopicIndex[denseIndex];
+          sample -= localTopicCounts[topic] / (tokensPerTopic[topic] + betaSum);
+          if (sample <= 0.0) { newTopic = topic; break; }
+        }
+      } else {                                                            /* MPE:442-460 */
+        sample -= topicBetaMass;
+        sample /= beta;
+        newTopic = 0;
+        sample -= s->alpha[newTopic] / (tokensPerTopic[newTopic] + betaSum);
+        while (sample > 0.0) {
+          newTopic++;
+          if (newTopic >= numTopics) break;
+          sample -= s->alpha[newTopic] / (tokensPerTopic[newTopic] + betaSum);
+        }
+      }
+    }
+    if (r.exhausted) { rc = fail(s, ORC_ERR_RNG_EXHAUSTED, "held-out stream: document longer than 2*ORC_MAX_BLOCKS tokens"); break; }
+    if (newTopic < 0 || newTopic >= numTopics) {                          /* MPE:416,447,455,464-469: IllegalStateException */
+      rc = fail(s, ORC_ERR_INVALID_TOPIC, "Sampled invalid topic");
+      break;
+    }
+    topicBetaMass -= beta * localTopicCounts[newTopic] / (tokensPerTopic[newTopic] + betaSum);          /* MPE:474-475 */
+    localTopicCounts[newTopic]++;
+    if (localTopicCounts[newTopic] == 1) {                                /* MPE:481-499 sorted insert */
+      denseIndex = nonZeroTopics;
+      while (denseIndex > 0 && localTopicIndex[denseIndex - 1] > newTopic) {
+        localTopicIndex[denseIndex] = localTopicIndex[denseIndex - 1];
+        denseIndex--;
+      }
+      localTopicIndex[denseIndex] = newTopic;
+      nonZeroTopics++;
+    }
+    cachedCoefficients[newTopic] = (s->alpha[newTopic] + localTopicCounts[newTopic]) / (tokensPerTopic[newTopic] + betaSum);   /* MPE:502-504 */
+    topicBetaMass += beta * localTopicCounts[newTopic] / (tokensPerTopic[newTopic] + betaSum);          /* MPE:506-507 */
+  }
+  for (denseIndex = 0; denseIndex < nonZeroTopics; denseIndex++) {        /* MPE:514-519 */
+    int32_t topic = localTopicIndex[denseIndex];
+    cachedCoefficients[topic] = s->alpha[topic] / (tokensPerTopic[topic] + betaSum);
+  }
+  return rc;
+}
+
+int orc_heldout_log_likelihood(orc_state *s, int64_t D, const int64_t *doc_ptr, const int32_t *tokens, int64_t doc_base,
+                               int32_t numParticles, double *doc_ll, double *total) {
+  if (D < 0 || numParticles < 1 || !doc_ptr || !total) return fail(s, ORC_ERR_BAD_ARG, "bad held-out arguments");
+  const int32_t numTopics = s->K;
+  double alphaSum = 0;
+  for (int32_t k = 0; k < numTopics; k++) alphaSum += s->alpha[k];
+  const double betaSum = s->beta * s->V;                                  /* MPE:63 */
+  double smoothingOnlyMass = 0;
+  double *base = malloc(sizeof(double) * (size_t)numTopics);
+  for (int32_t topic = 0; topic < numTopics; topic++) {                   /* MPE:75-78 */
+    smoothingOnlyMass += s->alpha[topic] * s->beta / (s->n_k[topic] + betaSum);
+    base[topic] = s->alpha[topic] / (s->n_k[topic] + betaSum);
+  }
+  const double logNumParticles = orc_log(numParticles);
+  int rc_all = ORC_OK;
+#pragma omp parallel num_threads(s->threads)
+  {
+    double *cachedCoefficients = malloc(sizeof(double) * (size_t)numTopics);
+    memcpy(cachedCoefficients, base, sizeof(double) * (size_t)numTopics);
+    int32_t *localTopicCounts = malloc(sizeof(int32_t) * (size_t)numTopics);
+    int32_t *localTopicIndex = malloc(sizeof(int32_t) * (size_t)numTopics);
+    double *topicTermScores = malloc(sizeof(double) * (size_t)numTopics);
+    double *probs = NULL; int64_t cap = 0;
+#pragma omp for schedule(dynamic, 4)
+    for (int64_t d = 0; d < D; d++) {
+      const int64_t docLength = doc_ptr[d + 1] - doc_ptr[d];
+      if (docLength * numParticles > cap) { cap = docLength * numParticles; free(probs); probs = malloc(sizeof(double) * (size_t)(cap ? cap : 1)); }
+      for (int32_t particle = 0; particle < numParticles; particle++) {   /* MPE:97-100 */
+        int rc = left_to_right(s, tokens + doc_ptr[d], docLength, (uint64_t)(doc_base + d) * (uint64_t)numParticles + (uint64_t)particle, betaSum,
+                               smoothingOnlyMass, alphaSum, cachedCoefficients, localTopicCounts, localTopicIndex, topicTermScores,
+                               probs + (size_t)particle * docLength);
+        if (rc) {
+#pragma omp critical(orc_heldout_rc)
+          rc_all = rc;
+        }
+      }
+      double docLogLikelihood = 0;
+      for (int64_t position = 0; position < docLength; position++) {     /* MPE:102-111 */
+        double sum = 0;
+        for (int32_t particle = 0; particle < numParticles; particle++) sum += probs[(size_t)particle * docLength + position];
+        if (sum > 0.0) docLogLikelihood += orc_log(sum) - logNumParticles;
+      }
+      doc_ll[d] = docLogLikelihood;
+    }
+    free(cachedCoefficients); free(localTopicCounts); free(localTopicIndex); free(topicTermScores); free(probs);
+  }
+  double totalLogLikelihood = 0;                                          /* MPE:116: in document order */
+  for (int64_t d = 0; d < D; d++) totalLogLikelihood += doc_ll[d];
+  *total = totalLogLikelihood;
+  free(base);
+  return rc_all;
+}
+
 void orc_get_z(const orc_state *s, int32_t *z) { memcpy(z, s->z, sizeof(int32_t) * s->N); }
 void orc_get_type_topic_counts(const orc_state *s, int32_t *o) { memcpy(o, s->n_wk, sizeof(int32_t) * (size_t)s->K * s->V); }
 void orc_get_topic_type_counts(const orc_state *s, int32_t *o) { memcpy(o, s->n_kw, sizeof(int32_t) * (size_t)s->K * s->V); }

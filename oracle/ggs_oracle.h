@@ -18,6 +18,7 @@
  *   topics/UncollapsedParallelLDA.java:1107-1221 delta merge
  *   topics/ModifiedSimpleLDA.java:158-226       count-form (collapsed) step
  *   topics/UncollapsedParallelLDA.java:1466-1544 the z loop of scheme=pcgs (partially collapsed)
+ *   topics/MarginalProbEstimatorPlain.java:51-121,123-519 left-to-right held-out log likelihood
  *
  * PARITY STATUS: the reference's GGS path draws from
  * ThreadLocalRandom / a nanoTime-seeded xorshift and therefore has no
@@ -47,7 +48,8 @@ enum {
   ORC_PURPOSE_Z = 1,        /* elem = global token index                     */
   ORC_PURPOSE_THETA = 2,    /* elem = global_doc * K + k                     */
   ORC_PURPOSE_PHI = 3,      /* elem = k * V + v                              */
-  ORC_PURPOSE_INIT_PHI = 4  /* elem = k * V + v                              */
+  ORC_PURPOSE_INIT_PHI = 4, /* elem = k * V + v                              */
+  ORC_PURPOSE_HELDOUT = 5   /* elem = global_test_doc * numParticles + particle; uniforms in sequence */
 };
 
 #define ORC_MAX_BLOCKS 4096 /* per-draw cap on consumed Philox blocks        */
@@ -96,6 +98,9 @@ void orc_set_phi_mean_gating(orc_state *s, int save, int burn_in, int thin);
 void orc_log_posterior(const orc_state *s, double *doc_side, double *topic_side);
 /* UPLDA:1644-1758 modelLogLikelihood in the Java loop order; the model's value is doc_side + topic_side */
 void orc_model_log_likelihood(const orc_state *s, double *doc_side, double *topic_side);
+/* MarginalProbEstimatorPlain.evaluateLeftToRight (MPE:85-121) on the state's current counts; doc_ll[D] is required */
+int orc_heldout_log_likelihood(orc_state *s, int64_t D, const int64_t *doc_ptr, const int32_t *tokens, int64_t doc_base,
+                               int32_t numParticles, double *doc_ll, double *total);
 /* 0 = ggs (default), 1 = pcgs: UPLDA:1466-1544 z loop (theta integrated out), same Phi draw */
 void orc_set_scheme(orc_state *s, int scheme);
 void orc_set_threads(orc_state *s, int threads);

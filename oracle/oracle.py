@@ -64,6 +64,7 @@ def lib():
         "orc_set_scheme": (None, [vp, C.c_int]),
         "orc_model_log_likelihood": (None, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "orc_log_posterior": (None, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "orc_heldout_log_likelihood": (C.c_int, [vp, C.c_int64, lp, ip, C.c_int64, C.c_int32, dp, C.POINTER(C.c_double)]),
         "orc_set_iteration": (None, [vp, C.c_int32]),
         "orc_get_iteration": (C.c_int32, [vp]),
         "orc_sweep": (C.c_int, [vp, C.c_int32]),
@@ -245,6 +246,16 @@ class OracleSampler:
         a, b = C.c_double(), C.c_double()
         lib().orc_log_posterior(self._h, C.byref(a), C.byref(b))
         return a.value, b.value
+
+    def heldout_log_likelihood(self, doc_ptr, tokens, num_particles=100, doc_base=0):
+        """MarginalProbEstimatorPlain.evaluateLeftToRight (MPE:85-121) on the current counts: (total, per-document)."""
+        doc_ptr = np.ascontiguousarray(doc_ptr, np.int64)
+        tokens = np.ascontiguousarray(tokens, np.int32)
+        doc_ll = np.zeros(doc_ptr.size - 1, np.float64)
+        tot = C.c_double()
+        self._chk(lib().orc_heldout_log_likelihood(self._h, doc_ptr.size - 1, _lp(doc_ptr), _ip(tokens), doc_base, num_particles,
+                                                   _dp(doc_ll), C.byref(tot)))
+        return tot.value, doc_ll
 
     def set_scheme(self, scheme):
         """'ggs' (default) or 'pcgs' (UPLDA:1466-1544 z loop, same Phi draw)."""

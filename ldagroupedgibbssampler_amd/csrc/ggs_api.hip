@@ -1111,10 +1111,14 @@ int ggs_heldout_log_likelihood(ggs_handle *h, int32_t num_particles, double *doc
   const int K = h->K;
   const int64_t D = (int64_t)h->test_ptr.size() - 1;
   // LDS: alpha and the denominators once per block, 2 bytes per (particle, topic) per wave
-  int waves = kHeldoutMaxWaves;
-  auto lds_of = [&](int w) { return (size_t)16 * K + (size_t)w * K * 128; };
-  while (waves > 1 && lds_of(waves) > (size_t)64 * 1024) waves >>= 1;      // <= 64 KiB per block keeps several blocks on a CU
-  if (lds_of(waves) > (size_t)160 * 1024) return set_err(h, GGS_ERR_UNSUPPORTED, "num_topics too large for the held-out estimator's per-particle counts in LDS");
+  auto lds_of = [&](int w) { return (size_t)(16 + 8 * kHeldoutCoefCap) * K + (size_t)w * K * 128 + (size_t)w * ((K + 63) / 64 * 64) * 8; };
+  int waves = 0, best = 0;
+  for (int w = kHeldoutMaxWaves; w >= 1; w >>= 1) {                        // the block shape that puts most waves on a CU
+    const size_t alloc = (lds_of(w) + 2047) / 2048 * 2048;                 // LDS is handed out in 2 KiB granules
+    const int per_cu = alloc <= (size_t)160 * 1024 ? (int)((size_t)160 * 1024 / alloc) * w : 0;
+    if (per_cu > best) { best = per_cu; waves = w; }
+  }
+  if (!waves) return set_err(h, GGS_ERR_UNSUPPORTED, "num_topics too large for the held-out estimator's per-particle counts in LDS");
   if (lds_of(waves) > (size_t)48 * 1024)
     HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(waves)));
   // wordProbabilities of a batch of documents: tokens x particles doubles, at most ~1 GiB at a time

@@ -8,8 +8,8 @@
 // typeTopicCounts row is wave-uniform: it is read once, its non-zero cells found with a ballot, and only those enter
 // the score loop -- a zero count contributes +0.0 to topicTermMass and nothing to the walk (MPE:352-365,409-415), so
 // skipping it is exact.  cachedCoefficients[k] is a function of (k, this particle's count of k) alone (MPE:78,502-504,
-// 514-519): (alpha_k + n) / (tokensPerTopic_k + betaSum), recomputed by one IEEE division where it is used, which
-// leaves 2 bytes per (particle, topic) of state in LDS instead of 10.
+// 514-519): (alpha_k + n) / (tokensPerTopic_k + betaSum) -- a block-wide LDS table for n < 16 and the same IEEE division
+// beyond, which leaves 2 bytes per (particle, topic) of state in LDS instead of 10.
 //
 // The reference draws from a clock-seeded Randoms (MPE:64,87): the stream is ours -- purpose GGS_PURPOSE_HELDOUT,
 // element = global test document * numParticles + particle, one uniform per in-vocabulary token, in sequence.
@@ -25,7 +25,7 @@ struct HeldoutParams {
   const int32_t *tok;       // test tokens; ids >= V are out of vocabulary and skipped (MPE:341-345)
   const int32_t *n_wk;      // typeTopicCounts [V][K]
   const double *tab;        // [0] smoothingOnlyMass, then alpha[K], then denom[K] = tokensPerTopic + betaSum
-  double *probs;            // wordProbabilities of the batch: (doc_ptr[d] - doc_ptr[d0]) * P + particle * len_d + position
+  double *probs;            // wordProbabilities of the batch: ((doc_ptr[d] - doc_ptr[d0]) + position) * P + particle
   double *doc_ll;           // [D]
   uint32_t *status;
   double beta, alpha_sum;
@@ -36,6 +36,8 @@ struct HeldoutParams {
 };
 
 constexpr int kHeldoutMaxWaves = 4;
+constexpr int kHeldoutCoefCap = 16;
+constexpr int kHeldoutBatch = 8;
 
 // alpha, denominators and smoothingOnlyMass (MPE:63,75-78), one thread: the mass is one running double
 __global__ void heldout_setup_kernel(const double *alpha, const int32_t *n_k, double beta, double beta_sum, int32_t K, double *tab) {
@@ -55,17 +57,55 @@ __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kerne
   const int K = p.K;
   double *alpha_s = reinterpret_cast<double *>(smem);
   double *denom_s = alpha_s + K;
+  double *coef_s = denom_s + K;                                         // [K][kHeldoutCoefCap]: (alpha_k + n) / denom_k for small n
   for (int k = threadIdx.x; k < 2 * K; k += blockDim.x) alpha_s[k] = p.tab[1 + k];
   __syncthreads();
+  for (int i = threadIdx.x; i < K * kHeldoutCoefCap; i += blockDim.x) {
+    const int k = i / kHeldoutCoefCap, n = i - k * kHeldoutCoefCap;
+    coef_s[i] = (alpha_s[k] + (double)n) / denom_s[k];
+  }
+  __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int16_t *cnt_s = reinterpret_cast<int16_t *>(denom_s + K) + (size_t)wave * K * 64;
+  const int Kpad = (K + 63) & ~63;
+  uint16_t *cnt_s = reinterpret_cast<uint16_t *>(coef_s + (size_t)K * kHeldoutCoefCap) + (size_t)wave * K * 64;
+  // the current word's non-zero (topic, count) cells, compacted in topic order: what both passes iterate
+  int2 *list_s = reinterpret_cast<int2 *>(reinterpret_cast<int16_t *>(coef_s + (size_t)K * kHeldoutCoefCap) + (size_t)p.waves * K * 64) + (size_t)wave * Kpad;
+  // The loops below are chains of dependent LDS reads (count -> coefficient) with a data-dependent trip count: what they
+  // cost is latency, not arithmetic (8 waves fit a CU).  They therefore take the non-zero cells kHeldoutBatch at a time
+  // -- all counts first, then all coefficients, then the ordered adds -- padding the last batch with cells of count 0,
+  // which add +0.0 to the mass and subtract 0.0 in the walk.  And what they cost beyond latency is instruction issue
+  // (a wave issues one instruction per ~8 cycles): the cells are compacted once per word so that the loops index them
+  // by a counter instead of peeling bits off a ballot mask.
+  int kk[kHeldoutBatch];
+  int32_t cc[kHeldoutBatch];
+  double cf[kHeldoutBatch];
+  auto next_cells = [&](const int2 cell, int j0) {                      // cells j0 .. j0 + kHeldoutBatch - 1 of `cell` (lane j = j-th cell)
+#pragma unroll
+    for (int j = 0; j < kHeldoutBatch; ++j) {
+      kk[j] = __builtin_amdgcn_readlane(cell.x, j0 + j);
+      cc[j] = __builtin_amdgcn_readlane(cell.y, j0 + j);
+    }
+    // cachedCoefficients of this lane's particle: from the table while the count is small; where some lane's count of
+    // a cell is beyond the table, the same division for that cell (the same value for the lanes the table covers)
+    int n[kHeldoutBatch];
+    bool big = false;
+#pragma unroll
+    for (int j = 0; j < kHeldoutBatch; ++j) { n[j] = cnt_s[kk[j] * 64 + lane]; big |= n[j] >= kHeldoutCoefCap; }
+#pragma unroll
+    for (int j = 0; j < kHeldoutBatch; ++j) cf[j] = coef_s[kk[j] * kHeldoutCoefCap + (n[j] < kHeldoutCoefCap ? n[j] : kHeldoutCoefCap - 1)];
+    if (__ballot(big)) {
+#pragma unroll
+      for (int j = 0; j < kHeldoutBatch; ++j)
+        if (__ballot(n[j] >= kHeldoutCoefCap)) cf[j] = (alpha_s[kk[j]] + (double)n[j]) / denom_s[kk[j]];
+    }
+  };
   const int64_t unit = (int64_t)blockIdx.x * p.waves + wave;
   const int64_t d = p.d0 + unit / p.blocks_per_doc;
   if (d >= p.d1) return;                                                // no block-wide barrier below
   const int particle = (int)(unit % p.blocks_per_doc) * 64 + lane;
   const bool live = particle < p.P;                                     // dead lanes compute along, store nothing
   const int64_t beg = p.doc_ptr[d], len = p.doc_ptr[d + 1] - beg;
-  double *out = p.probs + (beg - p.doc_ptr[p.d0]) * p.P + (int64_t)particle * len;
+  double *out = p.probs + (beg - p.doc_ptr[p.d0]) * p.P + particle;     // [position][particle]: one wave's store is contiguous
   for (int k = 0; k < K; ++k) cnt_s[k * 64 + lane] = 0;
   const double smoothing = p.tab[0], beta = p.beta;
   const uint64_t elem = (uint64_t)(p.doc_base + d) * (uint64_t)p.P + (uint64_t)particle;
@@ -74,20 +114,27 @@ __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kerne
   bool bad = false;
   for (int64_t limit = 0; limit < len; ++limit) {
     const int32_t type = __builtin_amdgcn_readfirstlane(p.tok[beg + limit]);
-    if (type >= p.V) { if (live) out[limit] = 0.0; continue; }
+    if (type >= p.V) { if (live) out[limit * p.P] = 0.0; continue; }
     const int32_t *row = p.n_wk + (size_t)type * K;
-    // MPE:352-365: topicTermMass in topic order, zero cells skipped
-    double mass = 0.0;
+    // the row's non-zero cells in topic order (zero cells add +0.0 to the mass and nothing to the walk: skipped)
+    int cells = 0;
     for (int k0 = 0; k0 < K; k0 += 64) {
       const int32_t v = k0 + lane < K ? row[k0 + lane] : 0;
-      uint64_t m = __ballot(v != 0);
-      while (m) {
-        const int b = __builtin_ctzll(m);
-        m &= m - 1;
-        const int k = k0 + b;
-        const int32_t c = __builtin_amdgcn_readlane(v, b);
-        const double coef = (alpha_s[k] + (double)cnt_s[k * 64 + lane]) / denom_s[k];
-        mass += coef * (double)c;
+      const uint64_t m = __ballot(v != 0);
+      const int rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      if (v != 0) list_s[cells + rank] = make_int2(k0 + lane, v);
+      cells += __popcll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+    // MPE:352-365: topicTermMass in topic order; lanes past the last cell hold (topic 0, count 0): +0.0
+    double mass = 0.0;
+    for (int c0 = 0; c0 < cells; c0 += 64) {
+      const int2 cell = c0 + lane < cells ? list_s[c0 + lane] : make_int2(0, 0);
+      const int lim = cells - c0 < 64 ? cells - c0 : 64;
+      for (int j0 = 0; j0 < lim; j0 += kHeldoutBatch) {
+        next_cells(cell, j0);
+#pragma unroll
+        for (int j = 0; j < kHeldoutBatch; ++j) mass += cf[j] * (double)cc[j];
       }
     }
     const double total = smoothing + beta_mass + mass;
@@ -101,28 +148,26 @@ __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kerne
       u = u_odd;
     }
     double sample = u * total;                                          // MPE:393
-    if (live) out[limit] = total / (p.alpha_sum + (double)so_far);      // MPE:399-401
+    if (live) out[limit * p.P] = total / (p.alpha_sum + (double)so_far);   // MPE:399-401
     ++so_far;
     int newTopic = -1;
     const bool in_term = sample < mass;
     if (__ballot(in_term)) {                                            // MPE:409-419, the same products again
       bool walking = in_term && sample > 0;
-      for (int k0 = 0; k0 < K; k0 += 64) {
-        const int32_t v = k0 + lane < K ? row[k0 + lane] : 0;
-        uint64_t m = __ballot(v != 0);
-        while (m) {
-          const int b = __builtin_ctzll(m);
-          m &= m - 1;
-          const int k = k0 + b;
-          const int32_t c = __builtin_amdgcn_readlane(v, b);
-          const double coef = (alpha_s[k] + (double)cnt_s[k * 64 + lane]) / denom_s[k];
-          const double score = coef * (double)c;
-          if (walking) {
-            sample -= score;
-            if (!(sample > 0)) { newTopic = k; walking = false; }
+      for (int c0 = 0; c0 < cells && __ballot(walking); c0 += 64) {
+        const int2 cell = c0 + lane < cells ? list_s[c0 + lane] : make_int2(0, 0);
+        const int lim = cells - c0 < 64 ? cells - c0 : 64;
+        for (int j0 = 0; j0 < lim && __ballot(walking); j0 += kHeldoutBatch) {
+          next_cells(cell, j0);
+#pragma unroll
+          for (int j = 0; j < kHeldoutBatch; ++j) {
+            const double score = cf[j] * (double)cc[j];
+            if (walking) {
+              sample -= score;
+              if (!(sample > 0)) { newTopic = kk[j]; walking = false; }
+            }
           }
         }
-        if (!__ballot(walking)) break;
       }
     }
     if (!in_term) {
@@ -131,13 +176,16 @@ __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kerne
       if (in_beta) sample /= beta; else { sample -= beta_mass; sample /= beta; }
       if (__ballot(in_beta)) {                                          // MPE:423-440: this particle's topics, ascending
         bool walking = in_beta;
-        for (int k = 0; k < K; ++k) {
-          const int n = cnt_s[k * 64 + lane];
-          if (walking && n > 0) {
-            sample -= (double)n / denom_s[k];
-            if (sample <= 0.0) { newTopic = k; walking = false; }
-          }
-          if (!__ballot(walking)) break;
+        for (int k0 = 0; k0 < K && __ballot(walking); k0 += 8) {
+          int n[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) n[j] = k0 + j < K ? cnt_s[(k0 + j) * 64 + lane] : 0;
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            if (walking && n[j] > 0) {
+              sample -= (double)n[j] / denom_s[k0 + j];
+              if (sample <= 0.0) { newTopic = k0 + j; walking = false; }
+            }
         }
       }
       if (__ballot(!in_beta)) {                                         // MPE:442-460: the smoothing-only bucket
@@ -153,7 +201,7 @@ __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kerne
     if (newTopic < 0) { bad = true; newTopic = 0; }                     // MPE:416,447,455,464-469 throw
     const int n_old = cnt_s[newTopic * 64 + lane];
     beta_mass -= beta * (double)n_old / denom_s[newTopic];              // MPE:474-475
-    cnt_s[newTopic * 64 + lane] = (int16_t)(n_old + 1);
+    cnt_s[newTopic * 64 + lane] = (uint16_t)(n_old + 1);
     beta_mass += beta * (double)(n_old + 1) / denom_s[newTopic];        // MPE:506-507
   }
   if (bad && live) atomicOr(p.status, ST_INVALID_TOPIC);
@@ -174,7 +222,7 @@ __global__ __launch_bounds__(256) void heldout_reduce_kernel(HeldoutParams p) {
     double term = 0.0;
     if (pos < len) {
       double sum = 0.0;
-      for (int q = 0; q < p.P; ++q) sum += in[(int64_t)q * len + pos];
+      for (int q = 0; q < p.P; ++q) sum += in[pos * p.P + q];
       if (sum > 0.0) term = strict_log(sum) - log_particles;            // else: skipped, and x + 0.0 == x
     }
     const int n = (int)(len - pos0 < 64 ? len - pos0 : 64);

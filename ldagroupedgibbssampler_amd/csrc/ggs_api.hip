@@ -86,7 +86,8 @@ struct ggs_handle {
   uint32_t *d_status = nullptr;
   // test set of the held-out estimator (ggs_heldout.hpp)
   int64_t *d_test_ptr = nullptr;
-  int32_t *d_test_tok = nullptr;
+  int32_t *d_test_tok = nullptr, *d_test_docs = nullptr;       // d_test_docs: ids of the documents of <= 255 tokens, then of the longer ones
+  std::vector<int32_t> test_short, test_long;
   double *d_test_ll = nullptr;
   std::vector<int64_t> test_ptr;
   int64_t test_doc_base = 0;
@@ -651,7 +652,7 @@ void ggs_destroy(ggs_handle *h) {
   void *bufs[] = {h->d_doc_ptr, h->d_chunk_start, h->d_tok, h->d_z, h->d_chunk_doc, h->d_chunk_len, h->d_alpha, h->d_theta, h->d_theta_next,
                   h->d_phiT, h->d_mag, h->d_tot, h->d_phi_mean, h->d_n_wk, h->d_n_k, h->d_perm, h->d_inv_perm, h->d_zw, h->d_seg_word, h->d_seg_begin,
                   h->d_status, h->d_scratch, h->d_sum_pref, h->d_sum_fn, h->d_ct_tok, h->d_ct_idx, h->d_ct_ip, h->d_c_docs, h->d_hot_words, h->d_order,
-                  h->d_test_ptr, h->d_test_tok, h->d_test_ll};
+                  h->d_test_ptr, h->d_test_tok, h->d_test_ll, h->d_test_docs};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   for (auto &E : h->evs) {
@@ -1098,6 +1099,12 @@ int ggs_set_test_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const 
   HIP_TRY(h, hipMemcpy(h->d_test_ptr, doc_ptr, sizeof(int64_t) * (size_t)(D + 1), hipMemcpyHostToDevice));
   if (N) HIP_TRY(h, hipMemcpy(h->d_test_tok, tokens, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice));
   h->test_ptr.assign(doc_ptr, doc_ptr + D + 1);
+  h->test_short.clear(); h->test_long.clear();
+  for (int64_t d = 0; d < D; ++d) (doc_ptr[d + 1] - doc_ptr[d] <= 255 ? h->test_short : h->test_long).push_back((int32_t)d);
+  if ((rc = dev_alloc(h, &h->d_test_docs, (size_t)D))) return rc;
+  if (!h->test_short.empty()) HIP_TRY(h, hipMemcpy(h->d_test_docs, h->test_short.data(), sizeof(int32_t) * h->test_short.size(), hipMemcpyHostToDevice));
+  if (!h->test_long.empty())
+    HIP_TRY(h, hipMemcpy(h->d_test_docs + h->test_short.size(), h->test_long.data(), sizeof(int32_t) * h->test_long.size(), hipMemcpyHostToDevice));
   h->test_doc_base = doc_base;
   h->have_test = true;
   return GGS_OK;
@@ -1110,17 +1117,23 @@ int ggs_heldout_log_likelihood(ggs_handle *h, int32_t num_particles, double *doc
   if (num_particles < 1 || !total) return set_err(h, GGS_ERR_BAD_ARG, "num_particles < 1 or null output");
   const int K = h->K;
   const int64_t D = (int64_t)h->test_ptr.size() - 1;
-  // LDS: alpha and the denominators once per block, 2 bytes per (particle, topic) per wave
-  auto lds_of = [&](int w) { return (size_t)(16 + 8 * kHeldoutCoefCap) * K + (size_t)w * K * 128 + (size_t)w * ((K + 63) / 64 * 64) * 8; };
-  int waves = 0, best = 0;
-  for (int w = kHeldoutMaxWaves; w >= 1; w >>= 1) {                        // the block shape that puts most waves on a CU
-    const size_t alloc = (lds_of(w) + 2047) / 2048 * 2048;                 // LDS is handed out in 2 KiB granules
-    const int per_cu = alloc <= (size_t)160 * 1024 ? (int)((size_t)160 * 1024 / alloc) * w : 0;
-    if (per_cu > best) { best = per_cu; waves = w; }
-  }
-  if (!waves) return set_err(h, GGS_ERR_UNSUPPORTED, "num_topics too large for the held-out estimator's per-particle counts in LDS");
-  if (lds_of(waves) > (size_t)48 * 1024)
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(waves)));
+  // LDS: alpha, the denominators and the coefficient table once per block; per wave the word's cell list and 1 or 2 bytes
+  // per (particle, topic).  The block shape that puts most waves on a CU wins (the kernel is issue-bound).
+  const size_t Kpad = (size_t)(K + 63) / 64 * 64;
+  auto lds_of = [&](int w, int cnt_bytes) { return (size_t)(16 + 8 * kHeldoutCoefCap) * K + (size_t)w * (Kpad * 8 + (size_t)K * 64 * cnt_bytes); };
+  auto shape_for = [&](int cnt_bytes) {
+    int waves = 0, best = 0;
+    for (int w = kHeldoutMaxWaves; w >= 1; w >>= 1) {
+      const size_t alloc = (lds_of(w, cnt_bytes) + 2047) / 2048 * 2048;    // LDS is handed out in 2 KiB granules
+      const int per_cu = alloc <= (size_t)160 * 1024 ? std::min((int)((size_t)160 * 1024 / alloc) * w, 32) : 0;
+      if (per_cu && per_cu >= best) { best = per_cu; waves = w; }            // ties: the smaller block (documents differ in length)
+    }
+    return waves;
+  };
+  const int waves8 = shape_for(1), waves16 = shape_for(2);
+  if (!waves16 || !waves8) return set_err(h, GGS_ERR_UNSUPPORTED, "num_topics too large for the held-out estimator's per-particle counts in LDS");
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(waves8, 1)));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(waves16, 2)));
   // wordProbabilities of a batch of documents: tokens x particles doubles, at most ~1 GiB at a time
   const int64_t cap_cells = std::max<int64_t>((int64_t)1 << 27, 2 * (int64_t)GGS_MAX_BLOCKS * num_particles);
   int64_t max_cells = 0;
@@ -1143,13 +1156,29 @@ int ggs_heldout_log_likelihood(ggs_handle *h, int32_t num_particles, double *doc
   for (int k = 0; k < K; ++k) alpha_sum += h->alpha[k];
   hp.alpha_sum = alpha_sum;
   hp.seed = h->seed; hp.iteration = (uint32_t)h->iteration; hp.doc_base = h->test_doc_base;
-  hp.K = K; hp.V = h->V; hp.P = num_particles; hp.blocks_per_doc = (num_particles + 63) / 64; hp.waves = waves;
+  hp.K = K; hp.V = h->V; hp.P = num_particles; hp.blocks_per_doc = (num_particles + 63) / 64;
   hipLaunchKernelGGL(heldout_setup_kernel, dim3(1), dim3(64), 0, h->stream, h->d_alpha, h->d_n_k, h->beta, h->beta * h->V, K, tab);
   for (size_t b = 0; b + 1 < cuts.size(); ++b) {
     hp.d0 = cuts[b]; hp.d1 = cuts[b + 1];
-    const int64_t units = (hp.d1 - hp.d0) * hp.blocks_per_doc;
-    if (units == 0) continue;
-    hipLaunchKernelGGL(heldout_particles_kernel, dim3((unsigned)((units + waves - 1) / waves)), dim3(waves * 64), lds_of(waves), h->stream, hp);
+    if (hp.d1 == hp.d0) continue;
+    // the batch's short and long documents: sub-ranges of the two ascending id lists
+    auto range = [&](const std::vector<int32_t> &ids, size_t &lo, size_t &hi) {
+      lo = std::lower_bound(ids.begin(), ids.end(), (int32_t)hp.d0) - ids.begin();
+      hi = std::lower_bound(ids.begin(), ids.end(), (int32_t)hp.d1) - ids.begin();
+    };
+    size_t lo, hi;
+    range(h->test_short, lo, hi);
+    if (hi > lo) {
+      hp.docs = h->d_test_docs + lo; hp.n_docs = (int64_t)(hi - lo); hp.waves = waves8;
+      const int64_t units = hp.n_docs * hp.blocks_per_doc;
+      hipLaunchKernelGGL(heldout_particles_kernel<uint8_t>, dim3((unsigned)((units + waves8 - 1) / waves8)), dim3(waves8 * 64), lds_of(waves8, 1), h->stream, hp);
+    }
+    range(h->test_long, lo, hi);
+    if (hi > lo) {
+      hp.docs = h->d_test_docs + h->test_short.size() + lo; hp.n_docs = (int64_t)(hi - lo); hp.waves = waves16;
+      const int64_t units = hp.n_docs * hp.blocks_per_doc;
+      hipLaunchKernelGGL(heldout_particles_kernel<uint16_t>, dim3((unsigned)((units + waves16 - 1) / waves16)), dim3(waves16 * 64), lds_of(waves16, 2), h->stream, hp);
+    }
     hipLaunchKernelGGL(heldout_reduce_kernel, dim3((unsigned)((hp.d1 - hp.d0 + 3) / 4)), dim3(256), 0, h->stream, hp);
   }
   HIP_TRY(h, hipGetLastError());

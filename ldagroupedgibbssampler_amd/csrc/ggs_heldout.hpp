@@ -31,11 +31,13 @@ struct HeldoutParams {
   double beta, alpha_sum;
   uint64_t seed;
   uint32_t iteration;
-  int64_t d0, d1, doc_base; // this launch covers test documents [d0, d1)
+  const int32_t *docs;      // the particle kernel's documents (ids within [d0, d1)), n_docs of them
+  int64_t n_docs;
+  int64_t d0, d1, doc_base; // this batch covers test documents [d0, d1); the reduce kernel takes all of them
   int32_t K, V, P, blocks_per_doc, waves;
 };
 
-constexpr int kHeldoutMaxWaves = 4;
+constexpr int kHeldoutMaxWaves = 16;
 constexpr int kHeldoutCoefCap = 16;
 constexpr int kHeldoutBatch = 8;
 
@@ -52,6 +54,10 @@ __global__ void heldout_setup_kernel(const double *alpha, const int32_t *n_k, do
   tab[0] = smoothing;
 }
 
+// CntT: the particle's per-topic counts -- one byte each for documents of at most 255 tokens, two beyond.  The kernel
+// is bound by instruction issue (one instruction per ~8 cycles and wave), so what matters is how many waves share a
+// SIMD, and that is set by these counts' LDS footprint.
+template <typename CntT>
 __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kernel(HeldoutParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int K = p.K;
@@ -67,9 +73,9 @@ __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kerne
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int Kpad = (K + 63) & ~63;
-  uint16_t *cnt_s = reinterpret_cast<uint16_t *>(coef_s + (size_t)K * kHeldoutCoefCap) + (size_t)wave * K * 64;
   // the current word's non-zero (topic, count) cells, compacted in topic order: what both passes iterate
-  int2 *list_s = reinterpret_cast<int2 *>(reinterpret_cast<int16_t *>(coef_s + (size_t)K * kHeldoutCoefCap) + (size_t)p.waves * K * 64) + (size_t)wave * Kpad;
+  int2 *list_s = reinterpret_cast<int2 *>(coef_s + (size_t)K * kHeldoutCoefCap) + (size_t)wave * Kpad;
+  CntT *cnt_s = reinterpret_cast<CntT *>(reinterpret_cast<int2 *>(coef_s + (size_t)K * kHeldoutCoefCap) + (size_t)p.waves * Kpad) + (size_t)wave * K * 64;
   // The loops below are chains of dependent LDS reads (count -> coefficient) with a data-dependent trip count: what they
   // cost is latency, not arithmetic (8 waves fit a CU).  They therefore take the non-zero cells kHeldoutBatch at a time
   // -- all counts first, then all coefficients, then the ordered adds -- padding the last batch with cells of count 0,
@@ -100,8 +106,8 @@ __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kerne
     }
   };
   const int64_t unit = (int64_t)blockIdx.x * p.waves + wave;
-  const int64_t d = p.d0 + unit / p.blocks_per_doc;
-  if (d >= p.d1) return;                                                // no block-wide barrier below
+  if (unit / p.blocks_per_doc >= p.n_docs) return;                      // no block-wide barrier below
+  const int64_t d = p.docs[unit / p.blocks_per_doc];
   const int particle = (int)(unit % p.blocks_per_doc) * 64 + lane;
   const bool live = particle < p.P;                                     // dead lanes compute along, store nothing
   const int64_t beg = p.doc_ptr[d], len = p.doc_ptr[d + 1] - beg;
@@ -201,7 +207,7 @@ __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kerne
     if (newTopic < 0) { bad = true; newTopic = 0; }                     // MPE:416,447,455,464-469 throw
     const int n_old = cnt_s[newTopic * 64 + lane];
     beta_mass -= beta * (double)n_old / denom_s[newTopic];              // MPE:474-475
-    cnt_s[newTopic * 64 + lane] = (uint16_t)(n_old + 1);
+    cnt_s[newTopic * 64 + lane] = (CntT)(n_old + 1);
     beta_mass += beta * (double)(n_old + 1) / denom_s[newTopic];        // MPE:506-507
   }
   if (bad && live) atomicOr(p.status, ST_INVALID_TOPIC);

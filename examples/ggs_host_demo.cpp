@@ -45,6 +45,9 @@ int main(int argc, char **argv) {
     const auto est = model.getThetaEstimate();
     double s = 0; for (int k = 0; k < cfg.topics; ++k) s += est[(size_t)k];
     std::printf("theta_estimate_doc0_sum %.17g\n", s);
+    model.addTestInstances(inst);                       // the diagnostics of the sampling loop, on the device
+    std::printf("heldout %.17g\nloglik %.17g\nlogposterior %.17g\n", model.heldOutLogLikelihood(100), model.modelLogLikelihood(),
+                model.computeLogPosterior());
   } catch (const ggs::SamplerError &e) {
     std::fprintf(stderr, "SamplerError %d: %s\n", e.code, e.what());
     return 1;

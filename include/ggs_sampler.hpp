@@ -208,6 +208,32 @@ class LDAGroupedGibbsSampler {
     return t;
   }
 
+  double modelLogLikelihood() {                                             // UPLDA:1644-1758, on the device
+    need();
+    double a = 0, b = 0;
+    chk(ggs_model_log_likelihood(h_, &a, &b));
+    return a + b;
+  }
+  double computeLogPosterior() {                                            // UPLDA:1573-1634, on the device
+    need();
+    double a = 0, b = 0;
+    chk(ggs_log_posterior(h_, &a, &b));
+    return a + b;
+  }
+  void addTestInstances(const InstanceList &testSet) {                      // MSLDA:918-923; ids of the training alphabet
+    need();
+    chk(ggs_set_test_corpus(h_, testSet.size(), testSet.doc_ptr.data(), testSet.tokens.data(), 0));
+    haveTestSet_ = true;
+  }
+  // what sample() logs at UPLDA:622,841: MarginalProbEstimatorPlain(...).evaluateLeftToRight(testSet, numParticles, null)
+  double heldOutLogLikelihood(int numParticles = 100) {
+    need();
+    if (!haveTestSet_) throw SamplerError(GGS_ERR_STATE, "addTestInstances has not been called");
+    double total = 0;
+    chk(ggs_heldout_log_likelihood(h_, numParticles, nullptr, &total));
+    return total;
+  }
+
   void abort() { abort_.store(true); }                                      // MSLDA:601-603; may come from another thread
   bool getAbort() const { return abort_.load(); }
 
@@ -235,6 +261,7 @@ class LDAGroupedGibbsSampler {
   int32_t V_ = 0;
   std::vector<int64_t> doc_ptr_;
   std::atomic<bool> abort_{false};
+  bool haveTestSet_ = false;
 };
 
 }  // namespace ggs

@@ -49,6 +49,10 @@ public class LDAGroupedGibbsSamplerHIP extends LDAGroupedGibbsSampler {
 	private static native int  nGetPhiMean(long h, double[] phiMean);     // returns noSampledPhi
 	private static native void nGetTheta(long h, long docBegin, long docEnd, double[] theta);
 	private static native double[] nGetTimings(long h);                    // theta, z, merge, phi (ms, cumulative)
+	private static native double nModelLogLikelihood(long h);              // UPLDA:1644-1758 on the device
+	private static native double nLogPosterior(long h);                    // UPLDA:1573-1634 on the device
+	private static native void nSetTestCorpus(long h, long[] docPtr, int[] tokens);
+	private static native double nHeldOutLogLikelihood(long h, int numParticles);   // MarginalProbEstimatorPlain:85-121
 
 	public LDAGroupedGibbsSamplerHIP(LDAConfiguration config) { super(config); }
 
@@ -76,6 +80,29 @@ public class LDAGroupedGibbsSamplerHIP extends LDAGroupedGibbsSampler {
 		nSetZ(handle, flatZ, true);                   // counts + initial Phi on the device (UPLDA:1287-1294)
 		javaStateStale = true;                        // Java's own initial phi is superseded by the device's
 	}
+
+	@Override
+	public void addTestInstances(InstanceList testSet) {   // MSLDA:918-923; ids are indices of the shared alphabet
+		super.addTestInstances(testSet);
+		long[] docPtr = new long[testSet.size() + 1];
+		for (int d = 0; d < testSet.size(); d++)
+			docPtr[d + 1] = docPtr[d] + ((FeatureSequence) testSet.get(d).getData()).getLength();
+		int[] tokens = new int[(int) docPtr[testSet.size()]];
+		for (int d = 0; d < testSet.size(); d++)
+			System.arraycopy(((FeatureSequence) testSet.get(d).getData()).getFeatures(), 0, tokens, (int) docPtr[d],
+					(int) (docPtr[d + 1] - docPtr[d]));
+		nSetTestCorpus(handle, docPtr, tokens);
+	}
+
+	/** What sample() logs at UPLDA:622,841 -- call this instead of building a MarginalProbEstimatorPlain over the
+	 *  (stale) Java count arrays: evaluateLeftToRight(testSet, numParticles, null) on the device-resident counts. */
+	public double heldOutLogLikelihood(int numParticles) { return nHeldOutLogLikelihood(handle, numParticles); }
+
+	@Override
+	public double modelLogLikelihood() { return nModelLogLikelihood(handle); }   // UPLDA:1644-1758, no copy-back
+
+	/** Replaces the body of the private computeLogPosterior (UPLDA:1573-1634) at its call site UPLDA:820-821. */
+	public double logPosterior() { return nLogPosterior(handle); }
 
 	@Override
 	protected void loopOverBatches() {                  // UPLDA:1434-1437

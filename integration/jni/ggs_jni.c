@@ -87,3 +87,22 @@ JNIEXPORT jdoubleArray JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_n
   (*env)->SetDoubleArrayRegion(env, out, 0, 4, v);
   return out;
 }
+
+/* diagnostics computed on the device-resident state: two doubles (or one) cross JNI, no matrices */
+JNIEXPORT jdouble JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nModelLogLikelihood(JNIEnv *env, jclass c, jlong h) {
+  double a = 0, b = 0; CHECK(H(h), ggs_model_log_likelihood(H(h), &a, &b)); return a + b;       /* UPLDA:1644-1758 */
+}
+JNIEXPORT jdouble JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nLogPosterior(JNIEnv *env, jclass c, jlong h) {
+  double a = 0, b = 0; CHECK(H(h), ggs_log_posterior(H(h), &a, &b)); return a + b;              /* UPLDA:1573-1634 */
+}
+JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSetTestCorpus(JNIEnv *env, jclass c, jlong h,
+                                                                                      jlongArray docPtr, jintArray tokens) {
+  jsize D = (*env)->GetArrayLength(env, docPtr) - 1;
+  jlong *dp = (*env)->GetLongArrayElements(env, docPtr, 0); jint *tk = (*env)->GetIntArrayElements(env, tokens, 0);
+  int rc = ggs_set_test_corpus(H(h), D, (const int64_t *)dp, (const int32_t *)tk, 0);           /* MSLDA:918-923 */
+  (*env)->ReleaseLongArrayElements(env, docPtr, dp, JNI_ABORT); (*env)->ReleaseIntArrayElements(env, tokens, tk, JNI_ABORT);
+  if (rc) throw_for(env, H(h), rc);
+}
+JNIEXPORT jdouble JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nHeldOutLogLikelihood(JNIEnv *env, jclass c, jlong h, jint particles) {
+  double total = 0; CHECK(H(h), ggs_heldout_log_likelihood(H(h), particles, 0, &total)); return total;   /* MPE:85-121 */
+}

@@ -146,6 +146,10 @@ def test_cpp_mirror_matches_python_path(native, tmp_path):
     assert np.array_equal(np.array(lines["z"].split(), np.int32), g.get_z())
     assert np.array_equal(np.array(lines["nk"].split(), np.int32), g.get_topic_totals())
     assert abs(float(lines["theta_estimate_doc0_sum"]) - 1.0) < 1e-12
+    g.set_test_corpus(c.doc_ptr, c.tokens)
+    assert float(lines["heldout"]) == g.heldout_log_likelihood(100)[0]
+    assert float(lines["loglik"]) == sum(g.model_log_likelihood())
+    assert float(lines["logposterior"]) == sum(g.log_posterior())
 
 
 def test_model_log_likelihood_formula():

@@ -95,6 +95,32 @@ class ShardedGGS:
         self.exchange.allreduce_startup()
         self.engine.init_phi()
 
+    def set_test_corpus(self, test_corpus):
+        """addTestInstances for a sharded run: the test documents are split by the same even rule, every rank keeps its
+        part (the counts the estimator reads are corpus-wide on every rank after the sweep's exchange)."""
+        self.test_bounds = even_split(test_corpus.num_docs, self.world)
+        sub, doc_base, _ = test_corpus.shard(self.test_bounds[self.rank], self.test_bounds[self.rank + 1])
+        self.engine.set_test_corpus(sub.doc_ptr, sub.tokens, doc_base)
+
+    def heldout_log_likelihood(self, num_particles=100, gather=None):
+        """MarginalProbEstimatorPlain.evaluateLeftToRight over the sharded test set: (total, per-document values of the
+        whole test set) on every rank, bit-identical to the one-handle run -- the streams are keyed by the global
+        document index and the total is added in document order (MPE:116).  ``gather(local_array) -> list of every
+        rank's array`` defaults to torch.distributed.all_gather_object."""
+        _, local = self.engine.heldout_log_likelihood(num_particles)
+        if gather is None:
+            import torch.distributed as dist
+
+            def gather(a):
+                out = [None] * self.world
+                dist.all_gather_object(out, a)
+                return out
+        doc_ll = np.concatenate([np.asarray(a, np.float64) for a in gather(np.asarray(local, np.float64))])
+        total = 0.0
+        for v in doc_ll.tolist():
+            total += v
+        return total, doc_ll
+
     def sweep(self, n=1):
         """n sweeps, one count exchange each; only the last one is waited for (device-side error flags are sticky)."""
         end_async = getattr(self.engine, "sweep_end_async", self.engine.sweep_end)

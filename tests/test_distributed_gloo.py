@@ -58,6 +58,12 @@ class OracleEngine:
         self.o.update_counts()
         self.o.sample_phi()
 
+    def set_test_corpus(self, doc_ptr, tokens, doc_base=0):
+        self._test = (doc_ptr, tokens, doc_base)
+
+    def heldout_log_likelihood(self, num_particles=100):
+        return self.o.heldout_log_likelihood(self._test[0], self._test[1], num_particles, self._test[2])
+
 
 class GlooExchange:
     def __init__(self, engine):
@@ -86,8 +92,10 @@ def _worker(rank, world, port, out_dir, scheme):
     sh = ShardedGGS(eng, GlooExchange, c, rank, world)
     sh.set_z_global(java_lcg_initial_z(c.num_tokens, K, 77))
     sh.sweep(3)
+    sh.set_test_corpus(random_corpus(23, 120, 40, seed=5, empty_every=6))
+    ho_total, ho_docs = sh.heldout_log_likelihood(30)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), z=eng.o.get_z(), nwk=eng.o.get_type_topic_counts(), phi=eng.o.get_phi(),
-             theta=eng.o.get_theta(), tok_base=sh.tok_base, doc_base=sh.doc_base)
+             theta=eng.o.get_theta(), tok_base=sh.tok_base, doc_base=sh.doc_base, ho_total=ho_total, ho_docs=ho_docs)
     dist.destroy_process_group()
 
 
@@ -116,9 +124,12 @@ def test_two_rank_sharded_sweep_equals_unsharded(oracle, tmp_path, scheme):
     assert np.array_equal(np.concatenate([p["z"] for p in parts]), ref.get_z())
     if scheme == "ggs":
         assert np.array_equal(np.concatenate([p["theta"] for p in parts]).view(np.int64), ref.get_theta().view(np.int64))
+    t = random_corpus(23, 120, 40, seed=5, empty_every=6)
+    ho_total, ho_docs = ref.heldout_log_likelihood(t.doc_ptr, t.tokens, 30)
     for p in parts:
         assert np.array_equal(p["nwk"], ref.get_type_topic_counts())
         assert np.array_equal(p["phi"].view(np.int64), ref.get_phi().view(np.int64))
+        assert float(p["ho_total"]) == ho_total and np.array_equal(p["ho_docs"], ho_docs)   # sharded test set, same estimate
 
 
 def _local_shards(world):

@@ -194,3 +194,24 @@ def test_heldout_medium_slice(native, oracle):
     o.set_z(g.get_z(), redraw_phi=False)                                 # same counts; the estimator reads nothing else
     o.set_iteration(10)
     _same(g, o, test, 100)
+
+
+@pytest.mark.gpu
+def test_heldout_sharded_test_set(native, oracle):
+    """Three shards of the test documents, each with its doc_base (what ShardedGGS.set_test_corpus hands every rank):
+    the per-document values concatenate to the one-handle result, so the ordered total is the same."""
+    c = random_corpus(150, 200, 70, seed=77, empty_every=11)
+    train, _, _ = c.shard(0, 110)
+    test, _, _ = c.shard(110, 150)
+    g, o = _pair(native, oracle, train, 24, 0.2, 0.05, 5, 2)
+    whole = _same(g, o, test, 100)
+    parts = []
+    for lo, hi in ((0, 13), (13, 14), (14, 40)):
+        sub, db, _ = test.shard(lo, hi)
+        g.set_test_corpus(sub.doc_ptr, sub.tokens, db)
+        parts.append(g.heldout_log_likelihood(100)[1])
+    doc_ll = np.concatenate(parts)
+    total = 0.0
+    for v in doc_ll.tolist():
+        total += v
+    assert total == whole

@@ -1,0 +1,93 @@
+"""On-disk formats of the Java driver (ldagroupedgibbssampler_amd/formats.py).
+
+The binary and integer formats are byte-exact by construction and are checked against hand-packed bytes (what
+ByteBuffer.putDouble / putInt and DataInputStream do is fixed by the JDK specification: big-endian).  The
+double-to-text rules are restated from the JDK documentation; the reference holds no output file and the image no
+JVM, so those cases are the documentation's own examples -- parity unpinned.
+"""
+import os
+import struct
+
+import numpy as np
+
+from ldagroupedgibbssampler_amd import formats as F
+
+
+def test_binary_double_matrix_bytes(tmp_path):
+    m = np.array([[1.0, -2.5, 3.0e-310], [np.inf, 0.1, -0.0]])
+    fn = os.path.join(str(tmp_path), F.binary_matrix_name("phi", 2, 3, 7))
+    assert fn.endswith("phi_2_3_00007.BINARY")                            # LDAUtils.java:1127-1129
+    F.write_binary_double_matrix(m, fn)
+    raw = open(fn, "rb").read()
+    assert raw == b"".join(struct.pack(">d", v) for v in m.ravel())       # ByteBuffer.putDouble: big-endian
+    assert np.array_equal(F.read_binary_double_matrix(2, 3, fn).view(np.int64), m.view(np.int64))
+
+
+def test_binary_int_matrix_keeps_the_reference_file_size(tmp_path):
+    m = np.array([[1, -2, 3], [2**31 - 1, -2**31, 0]], np.int32)
+    fn = os.path.join(str(tmp_path), F.binary_matrix_name("N", 2, 3, 12345))
+    assert fn.endswith("N_2_3_12345.BINARY")
+    F.write_binary_int_matrix(m, fn)
+    raw = open(fn, "rb").read()
+    assert len(raw) == 8 * m.size                                         # mapped at 8*rows*cols (LDAUtils.java:1164)
+    assert raw[:4 * m.size] == b"".join(struct.pack(">i", int(v)) for v in m.ravel())
+    assert raw[4 * m.size:] == b"\0" * (4 * m.size)
+    assert np.array_equal(F.read_binary_int_matrix(2, 3, fn), m)          # readInt x rows*cols, the rest ignored
+
+
+def test_topic_indicator_and_int_csv(tmp_path):
+    doc_ptr = np.array([0, 3, 3, 5], np.int64)
+    z = np.array([4, 0, 11, 2, 2], np.int32)
+    fn = F.write_topic_indicators(doc_ptr, z, str(tmp_path), 42)
+    assert os.path.basename(fn) == "z_42.csv"
+    assert open(fn, newline="").read() == "4,0,11" + os.linesep + os.linesep + "2,2" + os.linesep
+    fn2 = os.path.join(str(tmp_path), "m.csv")
+    F.write_ascii_int_matrix(np.array([[1, 2], [3, -4]]), fn2, ";")
+    assert open(fn2, newline="").read() == "1;2" + os.linesep + "3;-4" + os.linesep
+
+
+def test_double_to_string_rules():
+    """java.lang.Double.toString as documented: at least one digit on either side of the point, plain notation for
+    1e-3 <= |d| < 1e7, computerized scientific notation otherwise."""
+    cases = [(1.0, "1.0"), (100.0, "100.0"), (0.001, "0.001"), (9999999.0, "9999999.0"), (1.0e7, "1.0E7"), (1.0e-4, "1.0E-4"),
+             (123456789.0, "1.23456789E8"), (-13123222.510316258, "-1.3123222510316258E7"), (0.5, "0.5"), (1.0e-5, "1.0E-5"),
+             (4.9e-324, "4.9E-324"), (1.7976931348623157e308, "1.7976931348623157E308"), (-0.0, "-0.0"), (0.0, "0.0"),
+             (float("nan"), "NaN"), (float("inf"), "Infinity"), (float("-inf"), "-Infinity"), (1234.5678, "1234.5678"),
+             (1e22, "1.0E22"), (2e-3, "0.002")]
+    for d, want in cases:
+        assert F.java_double_to_string(d) == want, (d, F.java_double_to_string(d), want)
+
+
+def test_format_double_rules():
+    """LDAUtils.formatDouble: "%.4f" (HALF_UP on the shortest decimal digits) from 1e-4 up, DecimalFormat("00.###E0")
+    (two integer digits, up to three fraction digits, HALF_EVEN) below."""
+    assert F.format_double(0.5) == "0.5000"
+    assert F.format_double(0.0) == "0.0000"
+    assert F.format_double(0.0001) == "0.0001"
+    assert F.format_double(0.00015) == "0.0002"                           # shortest digits "1.5E-4": a tie, HALF_UP
+    assert F.format_double(0.12345) == "0.1235"                           # the binary value is below the tie; Java rounds the digits
+    assert F.format_double(1.0) == "1.0000"
+    assert F.format_double(-2.00005) == "-2.0001"
+    assert F.format_double(0.00005) == "50E-6"
+    assert F.format_double(1.2345e-5) == "12.345E-6"
+    assert F.format_double(1.23456e-5) == "12.346E-6"
+    assert F.format_double(-9.9e-5) == "-99E-6"
+    assert F.format_double(9.99996e-5) == "10E-5"                         # 99.9996 rounds up to three integer digits: renormalised
+    assert F.format_double(3e-300) == "30E-301"
+    assert F.java_format_fixed(-13123893.66552341, 6) == "-13123893.665523"
+
+
+def test_text_logs_and_double_csv(tmp_path):
+    d = str(tmp_path)
+    F.append_log_likelihood(d, 10, -13123222.510316258)
+    F.append_log_likelihood(d, 20, -0.25)
+    assert open(os.path.join(d, "log-likelihood.txt"), newline="").read() == \
+        "10\t-1.3123222510316258E7" + os.linesep + "20\t-0.25" + os.linesep
+    F.append_heldout_log_likelihood(d, 10, -8544.048647764415)
+    assert open(os.path.join(d, "test_held_out_log_likelihood.txt"), newline="").read() == "10\t-8544.048647764415" + os.linesep
+    F.append_log_posterior(d, 3, -1234.5678915, 1700000000000)
+    assert open(os.path.join(d, "log-posterior.txt"), newline="").read() == "3\t-1234.567892\t1700000000000" + os.linesep
+    fn = F.ascii_matrix_name(d, "Phi_KxV", 2, 3, 5)
+    assert os.path.basename(fn) == "Phi_KxV_2_3_00005.csv"
+    F.write_ascii_double_matrix(np.array([[0.5, 0.25, 0.25], [0.99995, 2e-5, 3e-5]]), fn)
+    assert open(fn, newline="").read() == "0.5000,0.2500,0.2500" + os.linesep + "1.0000,20E-6,30E-6" + os.linesep

@@ -126,7 +126,8 @@ def main():
 
     from ldagroupedgibbssampler_amd import native
     from ldagroupedgibbssampler_amd.corpus import synthetic_lda_corpus
-    from ldagroupedgibbssampler_amd.sharded import ShardedGGS, TorchHipExchange, java_lcg_initial_z
+    from ldagroupedgibbssampler_amd.sharded import (ShardedGGS, TorchHipExchange, gather_shard_sizes, java_lcg_initial_z,
+                                                    java_lcg_initial_z_slice)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -150,13 +151,9 @@ def main():
     weak = sharded and args.scaling == "weak"
     corpus = synthetic_lda_corpus(args.docs, args.types, args.mean_len, true_topics=100, seed=args.seed + (rank if weak else 0))
     if weak:
-        sizes = torch.zeros(world, 2, dtype=torch.int64, device="cuda")
-        sizes[rank, 0], sizes[rank, 1] = corpus.num_docs, corpus.num_tokens
-        dist.all_reduce(sizes)
-        sizes = [(int(d), int(t)) for d, t in sizes.cpu().tolist()]
+        sizes = gather_shard_sizes(corpus, rank, world, device="cuda")
         total_docs, total_tokens = sum(d for d, _ in sizes), sum(t for _, t in sizes)
-        tok_base = sum(t for _, t in sizes[:rank])
-        z0 = java_lcg_initial_z(tok_base + corpus.num_tokens, K, args.seed)[tok_base:]   # one sequential stream over the global corpus
+        z0 = java_lcg_initial_z_slice(sum(t for _, t in sizes[:rank]), corpus.num_tokens, K, args.seed)   # one sequential stream over the global corpus
     else:
         total_docs, total_tokens = corpus.num_docs, corpus.num_tokens
         z0 = java_lcg_initial_z(corpus.num_tokens, K, args.seed)

@@ -130,6 +130,23 @@ class ShardedGGS:
             (self.engine.sweep_end if i == n - 1 else end_async)()
 
 
+def gather_shard_sizes(shard, rank, world_size, device=None, group=None):
+    """[(num_docs, num_tokens)] of every rank's own shard, in rank order (one small all-reduce): what
+    ShardedGGS.from_local_shard needs when every rank loads or generates its own documents."""
+    import torch
+    import torch.distributed as dist
+    sizes = torch.zeros(world_size, 2, dtype=torch.int64, device=device)
+    sizes[rank, 0], sizes[rank, 1] = shard.num_docs, shard.num_tokens
+    dist.all_reduce(sizes, group=group)
+    return [(int(d), int(t)) for d, t in sizes.cpu().tolist()]
+
+
+def java_lcg_initial_z_slice(tok_base, num_tokens, num_topics, seed):
+    """This shard's part of the corpus-wide seeded z0: java.util.Random is one sequential stream, so the draws before
+    tok_base are generated and dropped."""
+    return java_lcg_initial_z(tok_base + num_tokens, num_topics, seed)[tok_base:]
+
+
 def java_lcg_initial_z(num_tokens, num_topics, seed):
     """z0 = java.util.Random(seed).nextInt(K) per token in (doc, position) order
     (UPLDA:398-406,458-460), computed on the host once for a sharded start-up."""

@@ -140,22 +140,18 @@ def _local_shards(world):
 def _worker_local(rank, world, port, out_dir):
     """Every rank brings its OWN documents (bench.py --scaling weak): ShardedGGS.from_local_shard."""
     sys.path.insert(0, ROOT)
-    import torch
     import torch.distributed as dist
-    from ldagroupedgibbssampler_amd.sharded import ShardedGGS, java_lcg_initial_z
+    from ldagroupedgibbssampler_amd.sharded import ShardedGGS, gather_shard_sizes, java_lcg_initial_z_slice
     from oracle import oracle as O
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     c = _local_shards(world)[rank]
-    sizes = torch.zeros(world, 2, dtype=torch.int64)
-    sizes[rank, 0], sizes[rank, 1] = c.num_docs, c.num_tokens
-    dist.all_reduce(sizes)
-    sizes = [tuple(r) for r in sizes.tolist()]
+    sizes = gather_shard_sizes(c, rank, world)                         # the helpers bench.py --scaling weak uses
     K = 9
     eng = OracleEngine(O, K, c.num_types, 0.1, 0.01, 4242)
     sh = ShardedGGS.from_local_shard(eng, GlooExchange, c, sizes, rank, world)
-    sh.set_z_local(java_lcg_initial_z(sh.tok_base + c.num_tokens, K, 77)[sh.tok_base:])
+    sh.set_z_local(java_lcg_initial_z_slice(sh.tok_base, c.num_tokens, K, 77))
     sh.sweep(2)
     np.savez(os.path.join(out_dir, "rank%d.npz" % rank), z=eng.o.get_z(), nwk=eng.o.get_type_topic_counts(), phi=eng.o.get_phi(),
              theta=eng.o.get_theta(), global_tokens=sh.global_tokens)

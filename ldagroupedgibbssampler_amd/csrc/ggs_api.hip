@@ -1134,8 +1134,13 @@ int ggs_heldout_log_likelihood(ggs_handle *h, int32_t num_particles, double *doc
   if (!waves16 || !waves8) return set_err(h, GGS_ERR_UNSUPPORTED, "num_topics too large for the held-out estimator's per-particle counts in LDS");
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(waves8, 1)));
   HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(waves16, 2)));
-  // wordProbabilities of a batch of documents: tokens x particles doubles, at most ~1 GiB at a time
-  const int64_t cap_cells = std::max<int64_t>((int64_t)1 << 27, 2 * (int64_t)GGS_MAX_BLOCKS * num_particles);
+  // wordProbabilities of a batch of documents: tokens x particles doubles, at most ~4 GiB at a time (one launch for
+  // the 2 M-token test set of the benchmark: every extra launch has its own tail of half-empty CUs)
+  int64_t want_cells = (int64_t)1 << 29;
+  if (const char *e = std::getenv("GGS_DEBUG_HELDOUT_CELLS")) want_cells = std::max<int64_t>(1, std::atoll(e));   // tests: force several batches
+  int64_t longest = 1;
+  for (int64_t d = 0; d < D; ++d) longest = std::max(longest, h->test_ptr[d + 1] - h->test_ptr[d]);
+  const int64_t cap_cells = std::max<int64_t>(want_cells, longest * num_particles);                                 // a document is never split
   int64_t max_cells = 0;
   std::vector<int64_t> cuts{0};
   for (int64_t d = 0; d < D;) {

@@ -197,6 +197,24 @@ def test_heldout_medium_slice(native, oracle):
 
 
 @pytest.mark.gpu
+def test_heldout_in_several_batches(native, oracle, monkeypatch):
+    """The word probabilities of a large test set are produced a batch of documents at a time (GGS_DEBUG_HELDOUT_CELLS
+    shrinks the batch here; the default is 2^29 cells): same values, short and long documents mixed in every batch."""
+    rng = np.random.default_rng(3)
+    c = random_corpus(200, 300, 80, seed=31, empty_every=9)
+    train, _, _ = c.shard(0, 150)
+    rows = [list(rng.integers(0, 300, int(n))) for n in rng.integers(0, 120, 40)] + [list(rng.integers(0, 300, 400))] + \
+           [list(rng.integers(0, 300, int(n))) for n in rng.integers(200, 300, 10)]
+    test = _docs(rows, c.num_types)
+    g, o = _pair(native, oracle, train, 30, 0.1, 0.02, 8, 2)
+    whole = _same(g, o, test, 100)
+    for cells in (1, 50000, 200000):
+        monkeypatch.setenv("GGS_DEBUG_HELDOUT_CELLS", str(cells))
+        assert _same(g, o, test, 100) == whole
+    monkeypatch.delenv("GGS_DEBUG_HELDOUT_CELLS")
+
+
+@pytest.mark.gpu
 def test_heldout_sharded_test_set(native, oracle):
     """Three shards of the test documents, each with its doc_base (what ShardedGGS.set_test_corpus hands every rank):
     the per-document values concatenate to the one-handle result, so the ordered total is the same."""

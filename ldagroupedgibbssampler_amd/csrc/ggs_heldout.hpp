@@ -25,7 +25,7 @@ struct HeldoutParams {
   const int32_t *tok;       // test tokens; ids >= V are out of vocabulary and skipped (MPE:341-345)
   const int32_t *n_wk;      // typeTopicCounts [V][K]
   const double *tab;        // [0] smoothingOnlyMass, then alpha[K], then denom[K] = tokensPerTopic + betaSum
-  double *probs;            // wordProbabilities of the batch: ((doc_ptr[d] - doc_ptr[d0]) + position) * P + particle
+  double *probs;            // wordProbabilities of the batch: (doc_ptr[d] - doc_ptr[d0]) * P + particle * len_d + position
   double *doc_ll;           // [D]
   uint32_t *status;
   double beta, alpha_sum;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kerne
   const int particle = (int)(unit % p.blocks_per_doc) * 64 + lane;
   const bool live = particle < p.P;                                     // dead lanes compute along, store nothing
   const int64_t beg = p.doc_ptr[d], len = p.doc_ptr[d + 1] - beg;
-  double *out = p.probs + (beg - p.doc_ptr[p.d0]) * p.P + particle;     // [position][particle]: one wave's store is contiguous
+  double *out = p.probs + (beg - p.doc_ptr[p.d0]) * p.P + (int64_t)particle * len;   // [particle][position]: the reduce kernel's reads coalesce
   for (int k = 0; k < K; ++k) cnt_s[k * 64 + lane] = 0;
   const double smoothing = p.tab[0], beta = p.beta;
   const uint64_t elem = (uint64_t)(p.doc_base + d) * (uint64_t)p.P + (uint64_t)particle;
@@ -120,7 +120,7 @@ __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kerne
   bool bad = false;
   for (int64_t limit = 0; limit < len; ++limit) {
     const int32_t type = __builtin_amdgcn_readfirstlane(p.tok[beg + limit]);
-    if (type >= p.V) { if (live) out[limit * p.P] = 0.0; continue; }
+    if (type >= p.V) { if (live) out[limit] = 0.0; continue; }
     const int32_t *row = p.n_wk + (size_t)type * K;
     // the row's non-zero cells in topic order (zero cells add +0.0 to the mass and nothing to the walk: skipped)
     int cells = 0;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kerne
       u = u_odd;
     }
     double sample = u * total;                                          // MPE:393
-    if (live) out[limit * p.P] = total / (p.alpha_sum + (double)so_far);   // MPE:399-401
+    if (live) out[limit] = total / (p.alpha_sum + (double)so_far);      // MPE:399-401
     ++so_far;
     int newTopic = -1;
     const bool in_term = sample < mass;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void heldout_reduce_kernel(HeldoutParams p) {
     double term = 0.0;
     if (pos < len) {
       double sum = 0.0;
-      for (int q = 0; q < p.P; ++q) sum += in[pos * p.P + q];
+      for (int q = 0; q < p.P; ++q) sum += in[(int64_t)q * len + pos];
       if (sum > 0.0) term = strict_log(sum) - log_particles;            // else: skipped, and x + 0.0 == x
     }
     const int n = (int)(len - pos0 < 64 ? len - pos0 : 64);

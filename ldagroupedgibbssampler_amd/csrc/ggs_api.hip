@@ -1120,20 +1120,33 @@ int ggs_heldout_log_likelihood(ggs_handle *h, int32_t num_particles, double *doc
   // LDS: alpha, the denominators and the coefficient table once per block; per wave the word's cell list and 1 or 2 bytes
   // per (particle, topic).  The block shape that puts most waves on a CU wins (the kernel is issue-bound).
   const size_t Kpad = (size_t)(K + 63) / 64 * 64;
-  auto lds_of = [&](int w, int cnt_bytes) { return (size_t)(16 + 8 * kHeldoutCoefCap) * K + (size_t)w * (Kpad * 8 + (size_t)K * 64 * cnt_bytes); };
-  auto shape_for = [&](int cnt_bytes) {
-    int waves = 0, best = 0;
+  auto lds_of = [&](int w, int cnt_bytes, int cap) { return (size_t)(16 + 8 * cap) * K + (size_t)w * (Kpad * 8 + (size_t)K * 64 * cnt_bytes); };
+  struct Shape { int waves = 0, per_cu = 0, cap = 0; };
+  auto shape_for = [&](int cnt_bytes, int cap) {
+    Shape s; s.cap = cap;
     for (int w = kHeldoutMaxWaves; w >= 1; w >>= 1) {
-      const size_t alloc = (lds_of(w, cnt_bytes) + 2047) / 2048 * 2048;    // LDS is handed out in 2 KiB granules
+      const size_t alloc = (lds_of(w, cnt_bytes, cap) + 2047) / 2048 * 2048;   // LDS is handed out in 2 KiB granules
       const int per_cu = alloc <= (size_t)160 * 1024 ? std::min((int)((size_t)160 * 1024 / alloc) * w, 32) : 0;
-      if (per_cu && per_cu >= best) { best = per_cu; waves = w; }            // ties: the smaller block (documents differ in length)
+      if (per_cu && per_cu >= s.per_cu) { s.per_cu = per_cu; s.waves = w; }       // ties: the smaller block (documents differ in length)
     }
-    return waves;
+    return s;
   };
-  const int waves8 = shape_for(1), waves16 = shape_for(2);
-  if (!waves16 || !waves8) return set_err(h, GGS_ERR_UNSUPPORTED, "num_topics too large for the held-out estimator's per-particle counts in LDS");
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(waves8, 1)));
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_of(waves16, 2)));
+  // the deepest coefficient table that costs no wave (measured at K=100: 16 -> 31 ms, 32 -> 26, 48 -> 24.6 per evaluation)
+  auto best_shape = [&](int cnt_bytes) {
+    const int n_caps = (int)(sizeof(kHeldoutCoefCaps) / sizeof(kHeldoutCoefCaps[0]));
+    const Shape floor = shape_for(cnt_bytes, kHeldoutCoefCaps[n_caps - 1]);
+    for (int i = 0; i < n_caps; ++i) {
+      const Shape s = shape_for(cnt_bytes, kHeldoutCoefCaps[i]);
+      if (s.per_cu && s.per_cu >= floor.per_cu) return s;
+    }
+    return floor;
+  };
+  const Shape shape8 = best_shape(1), shape16 = best_shape(2);
+  if (!shape16.waves || !shape8.waves) return set_err(h, GGS_ERR_UNSUPPORTED, "num_topics too large for the held-out estimator's per-particle counts in LDS");
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds_of(shape8.waves, 1, shape8.cap)));
+  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds_of(shape16.waves, 2, shape16.cap)));
   // wordProbabilities of a batch of documents: tokens x particles doubles, at most ~4 GiB at a time (one launch for
   // the 2 M-token test set of the benchmark: every extra launch has its own tail of half-empty CUs)
   int64_t want_cells = (int64_t)1 << 29;
@@ -1174,15 +1187,17 @@ int ggs_heldout_log_likelihood(ggs_handle *h, int32_t num_particles, double *doc
     size_t lo, hi;
     range(h->test_short, lo, hi);
     if (hi > lo) {
-      hp.docs = h->d_test_docs + lo; hp.n_docs = (int64_t)(hi - lo); hp.waves = waves8;
+      hp.docs = h->d_test_docs + lo; hp.n_docs = (int64_t)(hi - lo); hp.waves = shape8.waves; hp.cap = shape8.cap;
       const int64_t units = hp.n_docs * hp.blocks_per_doc;
-      hipLaunchKernelGGL(heldout_particles_kernel<uint8_t>, dim3((unsigned)((units + waves8 - 1) / waves8)), dim3(waves8 * 64), lds_of(waves8, 1), h->stream, hp);
+      hipLaunchKernelGGL(heldout_particles_kernel<uint8_t>, dim3((unsigned)((units + hp.waves - 1) / hp.waves)), dim3(hp.waves * 64),
+                         lds_of(hp.waves, 1, hp.cap), h->stream, hp);
     }
     range(h->test_long, lo, hi);
     if (hi > lo) {
-      hp.docs = h->d_test_docs + h->test_short.size() + lo; hp.n_docs = (int64_t)(hi - lo); hp.waves = waves16;
+      hp.docs = h->d_test_docs + h->test_short.size() + lo; hp.n_docs = (int64_t)(hi - lo); hp.waves = shape16.waves; hp.cap = shape16.cap;
       const int64_t units = hp.n_docs * hp.blocks_per_doc;
-      hipLaunchKernelGGL(heldout_particles_kernel<uint16_t>, dim3((unsigned)((units + waves16 - 1) / waves16)), dim3(waves16 * 64), lds_of(waves16, 2), h->stream, hp);
+      hipLaunchKernelGGL(heldout_particles_kernel<uint16_t>, dim3((unsigned)((units + hp.waves - 1) / hp.waves)), dim3(hp.waves * 64),
+                         lds_of(hp.waves, 2, hp.cap), h->stream, hp);
     }
     hipLaunchKernelGGL(heldout_reduce_kernel, dim3((unsigned)((hp.d1 - hp.d0 + 3) / 4)), dim3(256), 0, h->stream, hp);
   }

@@ -8,7 +8,7 @@
 // typeTopicCounts row is wave-uniform: it is read once, its non-zero cells found with a ballot, and only those enter
 // the score loop -- a zero count contributes +0.0 to topicTermMass and nothing to the walk (MPE:352-365,409-415), so
 // skipping it is exact.  cachedCoefficients[k] is a function of (k, this particle's count of k) alone (MPE:78,502-504,
-// 514-519): (alpha_k + n) / (tokensPerTopic_k + betaSum) -- a block-wide LDS table for n < 16 and the same IEEE division
+// 514-519): (alpha_k + n) / (tokensPerTopic_k + betaSum) -- a block-wide LDS table for small n (as deep as LDS allows without costing a wave: 48 at K=100) and the same IEEE division
 // beyond, which leaves 2 bytes per (particle, topic) of state in LDS instead of 10.
 //
 // The reference draws from a clock-seeded Randoms (MPE:64,87): the stream is ours -- purpose GGS_PURPOSE_HELDOUT,
@@ -35,11 +35,15 @@ struct HeldoutParams {
   int64_t n_docs;
   int64_t d0, d1, doc_base; // this batch covers test documents [d0, d1); the reduce kernel takes all of them
   int32_t K, V, P, blocks_per_doc, waves;
+  int32_t cap;              // counts below cap take their coefficient from the LDS table [K][cap]
 };
 
 constexpr int kHeldoutMaxWaves = 16;
-constexpr int kHeldoutCoefCap = 16;
-constexpr int kHeldoutBatch = 8;
+#ifndef GGS_HELDOUT_BATCH
+#define GGS_HELDOUT_BATCH 8
+#endif
+constexpr int kHeldoutCoefCaps[] = {64, 56, 48, 40, 32, 24, 16, 8};   // table depths the host chooses from (the deepest that costs no wave)
+constexpr int kHeldoutBatch = GGS_HELDOUT_BATCH;   // cells per round of LDS reads (must divide 64; 4 and 8 measure the same, 16 slower)
 
 // alpha, denominators and smoothingOnlyMass (MPE:63,75-78), one thread: the mass is one running double
 __global__ void heldout_setup_kernel(const double *alpha, const int32_t *n_k, double beta, double beta_sum, int32_t K, double *tab) {
@@ -63,19 +67,20 @@ __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kerne
   const int K = p.K;
   double *alpha_s = reinterpret_cast<double *>(smem);
   double *denom_s = alpha_s + K;
-  double *coef_s = denom_s + K;                                         // [K][kHeldoutCoefCap]: (alpha_k + n) / denom_k for small n
+  const int cap = p.cap;
+  double *coef_s = denom_s + K;                                         // [K][cap]: (alpha_k + n) / denom_k for n < cap
   for (int k = threadIdx.x; k < 2 * K; k += blockDim.x) alpha_s[k] = p.tab[1 + k];
   __syncthreads();
-  for (int i = threadIdx.x; i < K * kHeldoutCoefCap; i += blockDim.x) {
-    const int k = i / kHeldoutCoefCap, n = i - k * kHeldoutCoefCap;
+  for (int i = threadIdx.x; i < K * cap; i += blockDim.x) {
+    const int k = i / cap, n = i - k * cap;
     coef_s[i] = (alpha_s[k] + (double)n) / denom_s[k];
   }
   __syncthreads();
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int Kpad = (K + 63) & ~63;
   // the current word's non-zero (topic, count) cells, compacted in topic order: what both passes iterate
-  int2 *list_s = reinterpret_cast<int2 *>(coef_s + (size_t)K * kHeldoutCoefCap) + (size_t)wave * Kpad;
-  CntT *cnt_s = reinterpret_cast<CntT *>(reinterpret_cast<int2 *>(coef_s + (size_t)K * kHeldoutCoefCap) + (size_t)p.waves * Kpad) + (size_t)wave * K * 64;
+  int2 *list_s = reinterpret_cast<int2 *>(coef_s + (size_t)K * cap) + (size_t)wave * Kpad;
+  CntT *cnt_s = reinterpret_cast<CntT *>(reinterpret_cast<int2 *>(coef_s + (size_t)K * cap) + (size_t)p.waves * Kpad) + (size_t)wave * K * 64;
   // The loops below are chains of dependent LDS reads (count -> coefficient) with a data-dependent trip count: what they
   // cost is latency, not arithmetic (8 waves fit a CU).  They therefore take the non-zero cells kHeldoutBatch at a time
   // -- all counts first, then all coefficients, then the ordered adds -- padding the last batch with cells of count 0,
@@ -96,13 +101,13 @@ __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kerne
     int n[kHeldoutBatch];
     bool big = false;
 #pragma unroll
-    for (int j = 0; j < kHeldoutBatch; ++j) { n[j] = cnt_s[kk[j] * 64 + lane]; big |= n[j] >= kHeldoutCoefCap; }
+    for (int j = 0; j < kHeldoutBatch; ++j) { n[j] = cnt_s[kk[j] * 64 + lane]; big |= n[j] >= cap; }
 #pragma unroll
-    for (int j = 0; j < kHeldoutBatch; ++j) cf[j] = coef_s[kk[j] * kHeldoutCoefCap + (n[j] < kHeldoutCoefCap ? n[j] : kHeldoutCoefCap - 1)];
+    for (int j = 0; j < kHeldoutBatch; ++j) cf[j] = coef_s[kk[j] * cap + (n[j] < cap ? n[j] : cap - 1)];
     if (__ballot(big)) {
 #pragma unroll
       for (int j = 0; j < kHeldoutBatch; ++j)
-        if (__ballot(n[j] >= kHeldoutCoefCap)) cf[j] = (alpha_s[kk[j]] + (double)n[j]) / denom_s[kk[j]];
+        if (__ballot(n[j] >= cap)) cf[j] = (alpha_s[kk[j]] + (double)n[j]) / denom_s[kk[j]];
     }
   };
   const int64_t unit = (int64_t)blockIdx.x * p.waves + wave;

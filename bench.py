@@ -117,6 +117,9 @@ def main():
     ap.add_argument("--scheme", default="ggs", choices=["ggs", "pcgs"], help="ggs = the headline path; pcgs = the partially collapsed z loop (SURVEY 8f-1), for comparison")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = D documents PER RANK (default), strong = the N=1 corpus split across the ranks")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process group backend; gloo + --single-device rehearses N ranks on ONE GPU (RCCL refuses two ranks per device)")
+    ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (rehearsal only; the number is not a multi-GPU result)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the doc-sharded path (process group + RCCL all-reduce) even with one rank; for testing")
     args = ap.parse_args()
@@ -138,6 +141,8 @@ def main():
         sys.exit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         sys.exit("no GPU visible: the HIP path has no CPU fallback")
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     sharded = world > 1 or args.force_sharded
@@ -145,7 +150,10 @@ def main():
         import torch.distributed as dist
         if "MASTER_ADDR" not in os.environ:          # single-rank self test without a launcher
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29531"
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
     K = args.topics
     weak = sharded and args.scaling == "weak"
@@ -226,7 +234,9 @@ def main():
                 "workload": "LDAGroupedGibbsSampler sweep, synthetic LDA corpus D=%d V=%d N=%d tokens K=%d alpha=%g beta=%g seed=%d"
                             % (total_docs, corpus.num_types, total_tokens, K, args.alpha, args.beta, args.seed)
                             + (" (%d documents per rank)" % args.docs if weak else ""),
-                "parallelism": "doc-sharded x%d, int32 count all-reduce (RCCL) per sweep" % world if sharded else "1 GPU",
+                "parallelism": ("doc-sharded x%d, int32 count all-reduce (%s) per sweep%s"
+                                % (world, "RCCL" if args.backend == "nccl" else "gloo", ", ALL RANKS ON ONE GPU (rehearsal)" if args.single_device else ""))
+                               if sharded else "1 GPU",
             },
             "roofline": {
                 "bound": "hbm",

@@ -8,8 +8,9 @@
 // typeTopicCounts row is wave-uniform: it is read once, its non-zero cells found with a ballot, and only those enter
 // the score loop -- a zero count contributes +0.0 to topicTermMass and nothing to the walk (MPE:352-365,409-415), so
 // skipping it is exact.  cachedCoefficients[k] is a function of (k, this particle's count of k) alone (MPE:78,502-504,
-// 514-519): (alpha_k + n) / (tokensPerTopic_k + betaSum) -- a block-wide LDS table for small n (as deep as LDS allows without costing a wave: 48 at K=100) and the same IEEE division
-// beyond, which leaves 2 bytes per (particle, topic) of state in LDS instead of 10.
+// 514-519): (alpha_k + n) / (tokensPerTopic_k + betaSum) -- a block-wide LDS table for small n (as deep as LDS allows
+// without costing a wave: 48 at K=100) and the same IEEE division beyond, which leaves the count itself, 1 or 2 bytes
+// per (particle, topic), as the only per-particle state in LDS.
 //
 // The reference draws from a clock-seeded Randoms (MPE:64,87): the stream is ours -- purpose GGS_PURPOSE_HELDOUT,
 // element = global test document * numParticles + particle, one uniform per in-vocabulary token, in sequence.
@@ -81,12 +82,11 @@ __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kerne
   // the current word's non-zero (topic, count) cells, compacted in topic order: what both passes iterate
   int2 *list_s = reinterpret_cast<int2 *>(coef_s + (size_t)K * cap) + (size_t)wave * Kpad;
   CntT *cnt_s = reinterpret_cast<CntT *>(reinterpret_cast<int2 *>(coef_s + (size_t)K * cap) + (size_t)p.waves * Kpad) + (size_t)wave * K * 64;
-  // The loops below are chains of dependent LDS reads (count -> coefficient) with a data-dependent trip count: what they
-  // cost is latency, not arithmetic (8 waves fit a CU).  They therefore take the non-zero cells kHeldoutBatch at a time
-  // -- all counts first, then all coefficients, then the ordered adds -- padding the last batch with cells of count 0,
-  // which add +0.0 to the mass and subtract 0.0 in the walk.  And what they cost beyond latency is instruction issue
-  // (a wave issues one instruction per ~8 cycles): the cells are compacted once per word so that the loops index them
-  // by a counter instead of peeling bits off a ballot mask.
+  // The score loops are bound by instruction issue (a wave issues one instruction per ~8 cycles; SQ counters in
+  // profiles/): the cells are compacted once per word so that the loops index them by a counter instead of peeling
+  // bits off a ballot mask, and are taken kHeldoutBatch at a time -- all counts, then all coefficients, then the
+  // ordered adds -- so that the dependent LDS reads (count -> coefficient) overlap.  The last batch is padded with cells
+  // of count 0, which add +0.0 to the mass and subtract 0.0 in the walk.
   int kk[kHeldoutBatch];
   int32_t cc[kHeldoutBatch];
   double cf[kHeldoutBatch];
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kerne
   const int particle = (int)(unit % p.blocks_per_doc) * 64 + lane;
   const bool live = particle < p.P;                                     // dead lanes compute along, store nothing
   const int64_t beg = p.doc_ptr[d], len = p.doc_ptr[d + 1] - beg;
-  double *out = p.probs + (beg - p.doc_ptr[p.d0]) * p.P + (int64_t)particle * len;   // [particle][position]: the reduce kernel's reads coalesce
+  double *out = p.probs + (beg - p.doc_ptr[p.d0]) * p.P + (int64_t)particle * len;   // [particle][position]: the reduce's reads coalesce
   for (int k = 0; k < K; ++k) cnt_s[k * 64 + lane] = 0;
   const double smoothing = p.tab[0], beta = p.beta;
   const uint64_t elem = (uint64_t)(p.doc_base + d) * (uint64_t)p.P + (uint64_t)particle;

@@ -38,6 +38,11 @@ class SimpleLDAConfiguration:
         self.phi_mean_thin = int(kw.pop("phi_mean_thin", 1))         # PHI_THIN_DEFAULT
         self.paranoid = bool(kw.pop("paranoid", False))              # run the UPLDA:299-338 invariants every sweep
         self.device_id = int(kw.pop("device_id", 0))                 # optional gpu_* key; default first visible GPU
+        # the diagnostics of the sampling loop (UPLDA:695-905), computed on the device and written in the Java driver's formats
+        self.compute_likelihood = bool(kw.pop("compute_likelihood", False))   # model LL (+ held-out LL with a test set) every iteration, UPLDA:838-850
+        self.start_diagnostic = int(kw.pop("start_diagnostic", 500))          # START_DIAG_DEFAULT; log posterior from this iteration on, UPLDA:706,818-821
+        self.log_topic_indicators = bool(kw.pop("log_topic_indicators", False))  # z_<iteration>.csv, UPLDA:637-638,871-872
+        self.log_dir = kw.pop("log_dir", None)                       # where the files go (LoggingUtils' run directory in Java); None = no files
         if kw:
             raise TypeError("unknown configuration keys: %s" % sorted(kw))
 
@@ -116,6 +121,7 @@ class LDAGroupedGibbsSampler:
         self._corpus = None
         self.zSamplingTimeCum = 0.0      # ms, as UPLDA:642-693 accumulates them
         self.phiSamplingTimeCum = 0.0
+        self.loglikelihood, self.heldOutLoglikelihood, self.logPosterior = [], [], []   # the Java lists (MSLDA:114-115; UPLDA:591,843,849) + the posterior values
 
     # ---- LDAGibbsSampler ----
     def setConfiguration(self, config):
@@ -185,10 +191,35 @@ class LDAGroupedGibbsSampler:
             t1 = self._h.get_timings()
             self.zSamplingTimeCum += (t1["theta_ms"] - t0["theta_ms"]) + (t1["z_ms"] - t0["z_ms"]) + (t1["merge_ms"] - t0["merge_ms"])
             self.phiSamplingTimeCum += t1["phi_ms"] - t0["phi_ms"]
+            self._diagnostics(iteration)
             self.postIteration()
             if self.zSamplingTimeCum + self.phiSamplingTimeCum > max_exec_ms:    # UPLDA:926-928
                 break
         self.postSample()
+
+    def _diagnostics(self, iteration):
+        """The per-iteration diagnostics of UPLDA:695-905 that have a device implementation, in the Java order: log
+        posterior (ggs, from start_diagnostic on), held-out and model log likelihood (compute_likelihood), topic
+        indicators; each value is kept in the Java-named list and, with a log_dir, appended in the Java file format."""
+        cfg = self.config
+        from . import formats as F
+        if cfg.start_diagnostic > 0 and iteration >= cfg.start_diagnostic and not (self._scheme_flags & native.FLAG_PCGS):
+            lp = self.computeLogPosterior()                               # UPLDA:818-821
+            self.logPosterior.append(lp)
+            if cfg.log_dir:
+                F.append_log_posterior(cfg.log_dir, iteration, lp, int(time.time() * 1000))
+        if cfg.compute_likelihood:
+            if getattr(self, "_test_set", None) is not None:             # UPLDA:840-844
+                ho = self.heldOutLogLikelihood(100)
+                self.heldOutLoglikelihood.append(ho)
+                if cfg.log_dir:
+                    F.append_heldout_log_likelihood(cfg.log_dir, iteration, ho)
+            ll = self.modelLogLikelihood()                                # UPLDA:846-850
+            self.loglikelihood.append(ll)
+            if cfg.log_dir:
+                F.append_log_likelihood(cfg.log_dir, iteration, ll)
+            if cfg.log_topic_indicators and cfg.log_dir:                  # UPLDA:871-872
+                F.write_topic_indicators(self._corpus.doc_ptr, self._h.get_z(), cfg.log_dir, iteration)
 
     def sampleZGivenPhi(self, iterations):
         self._need_data()

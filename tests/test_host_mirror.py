@@ -217,3 +217,31 @@ def test_python_mirror_pcgs_matches_oracle(oracle, cats):
     o.sweep(3)
     assert np.array_equal(np.concatenate(m.getZIndicators()), o.get_z())
     assert np.array_equal(m.getPhi().view(np.int64), o.get_phi().view(np.int64))
+
+
+@pytest.mark.gpu
+def test_python_mirror_writes_the_driver_files(oracle, cats, tmp_path):
+    """sample() with the diagnostics on: the device values land in the Java-named lists and, formatted like the Java
+    driver's files (ldagroupedgibbssampler_amd/formats.py), under log_dir."""
+    from ldagroupedgibbssampler_amd import formats as F
+    from ldagroupedgibbssampler_amd.corpus import Corpus
+    train, _, _ = cats.shard(0, 18)
+    test, _, _ = cats.shard(18, cats.num_docs)
+    d = str(tmp_path)
+    m = create_model(SimpleLDAConfiguration(topics=5, alpha=0.5, beta=0.1, seed=31, iterations=4, exec_time=1800, compute_likelihood=True,
+                                            start_diagnostic=3, log_topic_indicators=True, log_dir=d))
+    m.setRandomSeed(31)
+    m.addInstances(train)
+    m.addTestInstances(Corpus(test.doc_ptr, test.tokens, train.num_types))
+    m.sample(4)
+    assert len(m.loglikelihood) == 4 and len(m.heldOutLoglikelihood) == 4 and len(m.logPosterior) == 2
+    assert m.loglikelihood[-1] == m.modelLogLikelihood() and m.heldOutLoglikelihood[-1] == m.heldOutLogLikelihood()
+    ll = open(os.path.join(d, "log-likelihood.txt")).read().splitlines()
+    assert ll == ["%d\t%s" % (i + 1, F.java_double_to_string(v)) for i, v in enumerate(m.loglikelihood)]
+    ho = open(os.path.join(d, "test_held_out_log_likelihood.txt")).read().splitlines()
+    assert ho == ["%d\t%s" % (i + 1, F.java_double_to_string(v)) for i, v in enumerate(m.heldOutLoglikelihood)]
+    lp = [l.split("\t") for l in open(os.path.join(d, "log-posterior.txt")).read().splitlines()]
+    assert [l[0] for l in lp] == ["3", "4"] and [l[1] for l in lp] == [F.java_format_fixed(v, 6) for v in m.logPosterior]
+    z4 = [list(map(int, l.split(","))) if l else [] for l in open(os.path.join(d, "z_4.csv")).read().splitlines()]
+    assert [t for doc in z4 for t in doc] == [int(t) for doc in m.getZIndicators() for t in doc]
+    assert sorted(f for f in os.listdir(d) if f.startswith("z_")) == ["z_1.csv", "z_2.csv", "z_3.csv", "z_4.csv"]

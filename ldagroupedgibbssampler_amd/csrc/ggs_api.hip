@@ -1142,11 +1142,15 @@ int ggs_heldout_log_likelihood(ggs_handle *h, int32_t num_particles, double *doc
     return floor;
   };
   const Shape shape8 = best_shape(1), shape16 = best_shape(2);
-  if (!shape16.waves || !shape8.waves) return set_err(h, GGS_ERR_UNSUPPORTED, "num_topics too large for the held-out estimator's per-particle counts in LDS");
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds_of(shape8.waves, 1, shape8.cap)));
-  HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)lds_of(shape16.waves, 2, shape16.cap)));
+  if ((!h->test_short.empty() && !shape8.waves) || (!h->test_long.empty() && !shape16.waves))
+    return set_err(h, GGS_ERR_UNSUPPORTED, "num_topics too large for the held-out estimator's per-particle counts in LDS "
+                                           "(up to 1704 topics with test documents of at most 255 tokens, 1024 with longer ones)");
+  if (shape8.waves)
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds_of(shape8.waves, 1, shape8.cap)));
+  if (shape16.waves)
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds_of(shape16.waves, 2, shape16.cap)));
   // wordProbabilities of a batch of documents: tokens x particles doubles, at most ~4 GiB at a time (one launch for
   // the 2 M-token test set of the benchmark: every extra launch has its own tail of half-empty CUs)
   int64_t want_cells = (int64_t)1 << 29;

@@ -43,7 +43,7 @@ constexpr int kHeldoutMaxWaves = 16;
 #ifndef GGS_HELDOUT_BATCH
 #define GGS_HELDOUT_BATCH 8
 #endif
-constexpr int kHeldoutCoefCaps[] = {64, 56, 48, 40, 32, 24, 16, 8};   // table depths the host chooses from (the deepest that costs no wave)
+constexpr int kHeldoutCoefCaps[] = {64, 56, 48, 40, 32, 24, 16, 8, 4, 1};   // table depths the host chooses from (the deepest that costs no wave)
 constexpr int kHeldoutBatch = GGS_HELDOUT_BATCH;   // cells per round of LDS reads (must divide 64; 4 and 8 measure the same, 16 slower)
 
 // alpha, denominators and smoothingOnlyMass (MPE:63,75-78), one thread: the mass is one running double

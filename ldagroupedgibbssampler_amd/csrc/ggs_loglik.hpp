@@ -11,7 +11,8 @@
 // its published source: shift z up to >= 2, Stirling series to 1/(1260 z^5), undo the shift).
 // A diagnostic, not sampler state: the reference adds ~15 M terms of mixed sign in one running
 // double; here partial sums are reduced in a FIXED tree (run-to-run identical, not order-identical
-// to Java), so against the oracle's sequential sum the result agrees to ~1e-12 relative, and the
+// to Java), so against the oracle's sequential sum the result agrees to ~1e-12 relative (the sequential sum's own
+// rounding error grows with the number of terms: 5e-11 measured at K=1024 and 18 M tokens), and the
 // test states that tolerance.
 #pragma once
 #include "ggs_device_math.hpp"

@@ -197,6 +197,23 @@ def test_heldout_medium_slice(native, oracle):
 
 
 @pytest.mark.gpu
+def test_heldout_wide_topic_rows(native, oracle):
+    """K = 1024 (BASELINE config 3's width): the per-particle counts still fit LDS with a shallower coefficient table,
+    for short and for long test documents; beyond 1024 topics only documents of at most 255 tokens do."""
+    rng = np.random.default_rng(9)
+    c = random_corpus(120, 400, 100, seed=61, empty_every=13)
+    rows = [list(rng.integers(0, 400, int(n))) for n in (3, 40, 255, 256, 300, 0, 120)]
+    test = _docs(rows, c.num_types)
+    g, o = _pair(native, oracle, c, 1024, 0.05, 0.01, 17, 1)
+    _same(g, o, test, 100)
+    g, o = _pair(native, oracle, c, 1100, 0.05, 0.01, 18, 1)
+    _same(g, o, _docs([r for r in rows if len(r) <= 255], c.num_types), 70)
+    g.set_test_corpus(test.doc_ptr, test.tokens)
+    with pytest.raises(native.GGSError):
+        g.heldout_log_likelihood(70)                                     # a 256-token document needs two-byte counts: too wide
+
+
+@pytest.mark.gpu
 def test_heldout_in_several_batches(native, oracle, monkeypatch):
     """The word probabilities of a large test set are produced a batch of documents at a time (GGS_DEBUG_HELDOUT_CELLS
     shrinks the batch here; the default is 2^29 cells): same values, short and long documents mixed in every batch."""

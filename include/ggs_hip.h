@@ -208,7 +208,9 @@ int ggs_set_test_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr /*D+1*/
  * left-to-right estimate of the test set's log likelihood, without the resampling pass (MPE:125).  doc_ll (D or NULL)
  * = the per-document values (what Java prints to docProbabilityStream); *total = their sum in document order.
  * Bit-identical to the oracle's restatement under the Philox stream GGS_PURPOSE_HELDOUT (the reference's Randoms is
- * clock-seeded).  The estimator's IllegalStateException ("Sampled invalid topic") -> GGS_ERR_INVALID_TOPIC. */
+ * clock-seeded).  The estimator's IllegalStateException ("Sampled invalid topic") -> GGS_ERR_INVALID_TOPIC.
+ * GGS_ERR_UNSUPPORTED when the per-particle topic counts do not fit LDS: more than 1704 topics, or more than 1024 with
+ * a test document longer than 255 tokens. */
 int ggs_heldout_log_likelihood(ggs_handle *h, int32_t num_particles, double *doc_ll, double *total);
 /* out[k] = x[0][k] + x[1][k] + ... in index order (exactly one of x / counts given; with counts the addends are
  * beta + counts[v][k]): the Phi normalisers' exact parallel column sum on its own, for adversarial inputs */

@@ -604,3 +604,26 @@ def test_log_posterior_on_device(native, oracle, cats):
     with pytest.raises(native.GGSError) as e:
         p.log_posterior()
     assert e.value.code == native.ERR_UNSUPPORTED
+
+
+@pytest.mark.parametrize("scheme", ["ggs", "pcgs"])
+def test_resume_from_exported_state(native, oracle, scheme):
+    """The reference has no resume path, only the state exports (getZIndicators / setZIndicators-without-redraw,
+    getPhi / setPhi) -- with counter-based streams keyed by the iteration they are enough: a second handle fed z, Phi and
+    the iteration number of the first continues bit-identically to the uninterrupted run."""
+    c = random_corpus(180, 260, 90, seed=44, empty_every=12)
+    K, alpha, beta, seed = 14, 0.2, 0.05, 321
+    flags = native.FLAG_PCGS if scheme == "pcgs" else 0
+    a, o = make_pair(native, oracle, c, K, alpha, beta, seed, flags=flags, zseed=9)
+    o.set_scheme(scheme)
+    a.sweep(3)
+    b = native.GGSHandle(K, c.num_types, alpha, beta, seed, flags=flags)
+    b.set_corpus(c.doc_ptr, c.tokens)
+    b.set_z(a.get_z(), redraw_phi=False)
+    b.set_phi(a.get_phi())
+    b.set_iteration(a.iteration)
+    a.sweep(2)
+    b.sweep(2)
+    o.sweep(5)
+    for h, tag in ((a, "uninterrupted"), (b, "resumed")):
+        compare_state(h, o, tag, theta=scheme == "ggs")

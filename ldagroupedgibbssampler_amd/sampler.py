@@ -12,6 +12,7 @@ The reference toolchain (JDK, Maven, MALLET) is absent from the build image, so 
 Python over ctypes for the tests and the benchmark; include/ggs_sampler.hpp is the same mirror
 in C++, and INTEGRATION.md shows the JNI subclass a maintainer would add on the Java side.
 """
+import os
 import time
 
 import numpy as np
@@ -193,6 +194,8 @@ class LDAGroupedGibbsSampler:
             self.phiSamplingTimeCum += t1["phi_ms"] - t0["phi_ms"]
             self._diagnostics(iteration)
             self.postIteration()
+            if os.path.exists("abort"):                  # the sentinel file of UPLDA:131,908-910 (relative to the working directory)
+                self.abort()
             if self.zSamplingTimeCum + self.phiSamplingTimeCum > max_exec_ms:    # UPLDA:926-928
                 break
         self.postSample()

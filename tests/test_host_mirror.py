@@ -74,7 +74,7 @@ def test_configuration_defaults_and_registry():
 
 # ---- on the GPU: the mirrors drive the C-ABI
 @pytest.mark.gpu
-def test_python_mirror_matches_oracle(oracle, cats):
+def test_python_mirror_matches_oracle(oracle, cats, tmp_path, monkeypatch):
     cfg = SimpleLDAConfiguration(topics=3, alpha=5.0, beta=7.0, seed=2019, iterations=4, exec_time=1800, paranoid=True,
                                  save_phi_mean=True, phi_mean_burnin=25, phi_mean_thin=1)           # plda-cats-test.cfg:16-25
     m = create_model(cfg)
@@ -119,6 +119,13 @@ def test_python_mirror_matches_oracle(oracle, cats):
     m3.postIteration = lambda: m3.abort() if m3.getCurrentIteration() >= 2 else None
     m3.sample(50)
     assert m3.getAbort() and m3.getCurrentIteration() == 2
+    # the `abort` sentinel file in the working directory (UPLDA:131,908-910)
+    m4 = create_model(SimpleLDAConfiguration(topics=3, alpha=5.0, beta=7.0, seed=1, exec_time=1800))
+    m4.addInstances(cats)
+    monkeypatch.chdir(tmp_path)
+    m4.postIteration = lambda: open("abort", "w").close() if m4.getCurrentIteration() >= 3 else None
+    m4.sample(50)
+    assert m4.getAbort() and m4.getCurrentIteration() == 3
 
 
 @pytest.mark.gpu

@@ -13,6 +13,7 @@
 // non-zero C-ABI return becomes ggs::SamplerError carrying the code and ggs_last_error().
 #pragma once
 #include <atomic>
+#include <fstream>
 #include <cstdint>
 #include <limits>
 #include <stdexcept>
@@ -103,6 +104,7 @@ class LDAGroupedGibbsSampler {
       zSamplingTimeCum += (t1.theta_ms - t0.theta_ms) + (t1.z_ms - t0.z_ms) + (t1.merge_ms - t0.merge_ms);
       phiSamplingTimeCum += t1.phi_ms - t0.phi_ms;
       postIteration();
+      if (std::ifstream("abort").good()) abort();                           // the sentinel file of UPLDA:131,908-910
       if (zSamplingTimeCum + phiSamplingTimeCum > maxExecMs) break;         // UPLDA:926-928
     }
     postSample();

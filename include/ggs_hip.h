@@ -16,6 +16,10 @@
  * handle is driven by ONE coordinator thread (as the Java sampler is,
  * UPLDA:552-943).  Host layouts mirror the Java getters: counts are
  * int32 [V][K] (getTypeTopicMatrix), Phi is double [K][V] (getPhi).
+ *
+ * One handle = one GPU.  Several live handles on the SAME device in one process are correct but slow: each brings
+ * three streams and the runtime multiplexes all of them onto the device's few hardware queues (measured: a second
+ * handle's sweeps ran 6x slower beside an idle first one) -- destroy a handle before building its successor.
  */
 #ifndef GGS_HIP_H
 #define GGS_HIP_H

@@ -5,17 +5,20 @@
 
 A "step" is one full sweep of BASELINE.json's configs[1]: synthetic LDA corpus D=100k,
 V=50k, mean 200 tokens/doc (~20M tokens), K=100, alpha=0.1, beta=0.01 -- theta draw +
-z draw + count merge (+ RCCL all-reduce of the deltas when N>1) + Phi re-draw, i.e. what
+z draw + count merge (+ the exchange when N>1) + Phi re-draw, i.e. what
 UncollapsedParallelLDA.sample does between preZ() and postPhi() (UPLDA:659-687).
 Inputs are resident in HBM before the timed region; rank 0 prints ONE JSON line.
 
-N>1 shards the documents across the ranks (one count all-reduce per sweep).  Default
-`--scaling weak`: every rank holds a configs[1]-sized shard (rank r generates its D documents
-with seed+r; rank 0's shard IS the N=1 corpus), i.e. the corpus grows with the node, V and K
-stay -- the per-GPU work is fixed, `value` = tokens of all ranks / time.  `--scaling strong`
-keeps the N=1 corpus and splits it (2.5 M tokens per GPU at N=8: the replicated Phi draw and
-the all-reduce then dominate).  At N>1 the default run measures that split too, after the
-headline measurement, and reports it in the same line as "strong_scaling" (--no-strong-leg skips it).
+N>1 shards the documents across the ranks, one process per GPU, joined by the library's NATIVE exchange
+(ggs_attach_rccl: RCCL reduce-scatter of the int32 counts by topic slice, Phi drawn for the rank's own topics,
+all-gather of the fp64 Phi slices; torch.distributed only carries the unique id, the barrier and the max over
+ranks).  Default `--scaling strong`, BASELINE.json's reading ("... at 1, 2, 4 and 8 GPUs ... >=6x strong scaling"):
+the N=1 corpus is split across the ranks, `value` = its tokens / time.  The same run then measures the weak-scaling
+regime (every rank brings a configs[1]-sized shard, rank r generated with seed+r) and reports it as "weak_scaling"
+(--no-weak-leg skips it); `--scaling weak` makes that the headline instead.
+
+At N=1 the line also carries `extra_configs` (BASELINE configs 3 and the config-4 stand-in: ms per sweep, phase times,
+row-byte accounting) and `cpu_baseline` (the CPU restatement in three variants, on a bounded sample).
 
 N>1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -30,7 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+MALL_GATHER_PEAK_GBS = 8600.0  # measured Infinity-Cache random-row gather ceiling, same guide
 
 
 def algorithmic_bytes_per_token(K):
@@ -39,66 +43,219 @@ def algorithmic_bytes_per_token(K):
     return 8 * K + 28
 
 
-def measured_traffic(kernel_prefixes):
-    """HBM bytes per z step (summed over its kernels) from the committed PMC passes of this same
-    command (profiles/r*_pmc_counters.txt; FETCH_SIZE and WRITE_SIZE are collected in separate
-    rocprofv3 runs, in KiB).  gfx950: FETCH_SIZE counts 128-byte requests at 64 bytes for wide
-    coalesced reads, so it is doubled (MI355X_MICROARCH.md, HBM).  None if no profile is present."""
+def csrc_sha16():
+    """Hash of the kernel sources this run was built from: stamps profiles, so a counter file is only ever quoted for
+    the build and workload it was collected on."""
+    import hashlib
+    d = os.path.join(ROOT, "ldagroupedgibbssampler_amd", "csrc")
+    hs = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            hs.update(f.encode())
+            hs.update(open(os.path.join(d, f), "rb").read())
+    return hs.hexdigest()[:16]
+
+
+def measured_traffic(kernel_prefixes, workload, sha):
+    """HBM bytes per z step (summed over its kernels) from a committed PMC profile of THIS workload and THIS build:
+    profiles/r*_pmc_counters.txt whose first line (written by scripts/collect_profiles.sh) carries the same workload
+    string and csrc hash -- anything else is somebody else's counter and the answer is None.  FETCH_SIZE and WRITE_SIZE
+    are collected in separate rocprofv3 runs, in KiB; gfx950 counts 128-byte read requests at 64 bytes for wide coalesced
+    reads, so FETCH_SIZE is doubled (MI355X_MICROARCH.md, HBM).  Returns (bytes, file name) or (None, reason)."""
     import ast
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_counters.txt")))
-    if not files:
-        return None
-    total = 0.0
-    for kernel_prefix in kernel_prefixes:
-        fetch = write = None
-        for line in open(files[-1]):
-            if kernel_prefix not in line.split("{")[0]:
-                continue
-            try:
-                d = ast.literal_eval(line[line.index("{"):line.rindex("}") + 1])
-            except (ValueError, SyntaxError):
-                continue
-            fetch = d.get("FETCH_SIZE", fetch)
-            write = d.get("WRITE_SIZE", write)
-        if fetch is None or write is None:
-            return None
-        total += 2.0 * fetch + write
-    return int(total * 1024)
+    want = "# workload: %s | csrc_sha16: %s" % (workload, sha)
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*pmc_counters.txt")), reverse=True):
+        lines = open(path).read().splitlines()
+        if not lines or lines[0].strip() != want:
+            continue
+        total = 0.0
+        for kernel_prefix in kernel_prefixes:
+            fetch = write = None
+            for line in lines[1:]:
+                if kernel_prefix not in line.split("{")[0]:
+                    continue
+                try:
+                    d = ast.literal_eval(line[line.index("{"):line.rindex("}") + 1])
+                except (ValueError, SyntaxError):
+                    continue
+                fetch = d.get("FETCH_SIZE", fetch)
+                write = d.get("WRITE_SIZE", write)
+            if fetch is None or write is None:
+                return None, "profile %s lacks FETCH/WRITE_SIZE of %s" % (os.path.basename(path), kernel_prefix)
+            total += 2.0 * fetch + write
+        return int(total * 1024), os.path.basename(path)
+    return None, "no profiles/r*pmc_counters.txt stamped with this workload and csrc hash"
+
+
+def z_kernels(K, scheme):
+    kmax = 8 * ((K + 7) // 8)
+    if scheme == "pcgs":
+        return ["pcgs_sliced_kernel<%d>" % kmax] if K <= 192 else ["pcgs_z_kernel"]
+    return ["z_sliced_kernel<%d>" % kmax, "z_hot_kernel<%d>" % kmax] if K <= 192 else ["z_stream_kernel"]
+
+
+def row_stats(corpus, K, num_hot):
+    """Byte accounting of one z step over `corpus` (per launch):
+      compulsory   what must cross HBM at least once: the chunk lists / token ids, z read + two z writes, theta rows
+                   once per document, one pass over phiT
+      cold_rows    phiT row bytes the kernels gather from L2 / Infinity Cache / HBM (tokens of the num_hot most
+                   frequent words are served from the LDS table instead; 0 hot words for K > 192)"""
+    import numpy as np
+    N, D, V = corpus.num_tokens, corpus.num_docs, corpus.num_types
+    freq = np.bincount(corpus.tokens, minlength=V)
+    hot_tokens = int(np.sort(freq)[::-1][:num_hot].sum()) if num_hot > 0 else 0
+    row = 8 * (K + (K & 1))
+    return {
+        "compulsory_bytes": int(N * (3 * 4 + 4 + 2 * 4) + D * K * 8 + V * row),
+        "cold_row_bytes": int((N - hot_tokens) * row),
+        "hot_token_frac": round(hot_tokens / max(N, 1), 4),
+    }
+
+
+def roofline_block(corpus, K, scheme, n_local, z_ms, workload, sha, num_hot):
+    """What bounds the dominant kernel (the z step), in three consistent readings:
+      achieved / frac    HBM bytes per launch over the launch time against the HBM peak -- from the PMC counters when a
+                         profile of this very workload and build is committed (`traffic`), else from the compulsory
+                         bytes (a lower bound of the traffic).  Never above 1 by construction of what is counted.
+      algorithmic        SURVEY 8(d)'s per-token figure x tokens: what a kernel without on-chip reuse would move.  The
+                         phiT rows are served from the LDS hot-word table and L2 / Infinity Cache, so this exceeds the
+                         HBM peak at K=100 -- it is a statement about reuse, not a fraction of a roofline.
+      cache_gather       cold-row bytes over the launch time against the guide's measured Infinity-Cache random-row
+                         ceiling: the memory-side limit that actually applies to the row gather."""
+    btok = algorithmic_bytes_per_token(K)
+    zk = z_kernels(K, scheme)
+    rs = row_stats(corpus, K, num_hot)
+    traffic, src = measured_traffic(["ggs::" + k.split("<")[0] for k in zk], workload, sha)
+    secs = z_ms * 1e-3
+
+    def gbs(b):
+        return round(b / secs / 1e9, 1) if secs > 0 else 0.0
+    hbm_bytes = traffic if traffic is not None else rs["compulsory_bytes"]
+    alg = n_local * btok
+    return {
+        "bound": "hbm",
+        "kernel": " + ".join(zk),
+        "achieved": gbs(hbm_bytes),
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": round(gbs(hbm_bytes) / HBM_PEAK_GBS, 4),
+        "basis": "measured HBM traffic (PMC)" if traffic is not None else "compulsory bytes (lower bound of the HBM traffic; no matching PMC profile)",
+        "traffic": traffic,
+        "traffic_source": src,
+        "compulsory_bytes": rs["compulsory_bytes"],
+        "limiter": ("instruction issue + L2/Infinity-Cache row gather (the sweep is far from the HBM roofline: see cache_gather and profiles/)"
+                    if K <= 192 else "L2/Infinity-Cache/HBM row gather: phiT exceeds the 256 MB Infinity Cache"),
+        "cache_gather": {"cold_row_bytes": rs["cold_row_bytes"], "GBps": gbs(rs["cold_row_bytes"]), "ceiling_GBps": MALL_GATHER_PEAK_GBS,
+                         "frac": round(gbs(rs["cold_row_bytes"]) / MALL_GATHER_PEAK_GBS, 4), "hot_token_frac_in_lds": rs["hot_token_frac"]},
+        "algorithmic": {"bytes_per_token": btok, "bytes_per_launch": alg, "GBps": gbs(alg), "over_hbm_peak": round(gbs(alg) / HBM_PEAK_GBS, 4),
+                        "note": "SURVEY 8(d) figure; rows served from LDS/L2/MALL make it exceed the HBM peak -- not a roofline fraction"},
+        "tokens_per_launch": n_local,
+        "avg_launch_ms": round(z_ms, 4),
+    }
 
 
 def cpu_baseline(corpus, K, alpha, beta, seed, z0, sample_docs):
-    """The oracle (a C restatement of the Java GGS sweep, Java layouts kept: phi[K][V],
-    atomic [K][V] deltas, dynamic chunks of 100 documents) on all host cores, on the first
-    `sample_docs` documents with the full vocabulary.  kind = "port": not a JVM run."""
+    """BASELINE.md section 3, timed on this box's host cores on the first `sample_docs` documents with the full vocabulary:
+      cpu_ref_mt    the oracle: C restatement of the Java GGS sweep with the Java layouts kept (phi[K][V] column gather,
+                    atomic [K][V] deltas, dynamic chunks of 100 documents), all cores -- the headline `value`
+      cpu_ref_1t    the same on one thread, on a fiftieth of the sample
+      cpu_tuned_mt  what a good CPU implementation does with the same arithmetic: transposed phiT rows, no per-document
+                    allocation, no atomics (counts rebuilt per word), all cores
+    kind = "port": not a JVM run (no JDK on the box)."""
     from oracle import oracle as O
     cores = os.cpu_count() or 1
-    sub, _, _ = corpus.shard(0, min(sample_docs, corpus.num_docs))
-    o = O.OracleSampler(K, corpus.num_types, alpha, beta, seed, threads=cores)
-    o.set_corpus(sub.doc_ptr, sub.tokens)
-    o.set_z(z0[:sub.num_tokens], redraw_phi=True)
-    o.sweep(1)                     # warm-up (page in, first-touch)
-    t0 = time.perf_counter()
-    n_sw = 2
-    for _ in range(n_sw):
-        o.set_iteration(o.iteration + 1)
-        t_a = time.perf_counter()
-        o.z_step()
-        t_b = time.perf_counter()
-        o.update_counts()
-        o.sample_phi()
-        t_c = time.perf_counter()
-    dt = time.perf_counter() - t0
-    o.close()
+    out = {}
+
+    def run(tag, docs, threads, tuned, n_sw):
+        sub, _, _ = corpus.shard(0, min(docs, corpus.num_docs))
+        o = O.OracleSampler(K, corpus.num_types, alpha, beta, seed, threads=threads)
+        o.set_corpus(sub.doc_ptr, sub.tokens)
+        o.set_z(z0[:sub.num_tokens], redraw_phi=True)
+        sweep = o.sweep_tuned if tuned else o.sweep
+        sweep(1)                       # warm-up (page in, first-touch)
+        t0 = time.perf_counter()
+        sweep(n_sw)
+        dt = time.perf_counter() - t0
+        o.close()
+        out[tag] = {"value": round(sub.num_tokens * n_sw / dt / 1e6, 3), "unit": "M tokens/s", "threads": threads,
+                    "sample": "first %d docs (%d tokens), full V=%d, K=%d, %d full sweeps" % (sub.num_docs, sub.num_tokens, corpus.num_types, K, n_sw)}
+
+    run("cpu_ref_mt", sample_docs, cores, False, 2)
+    run("cpu_tuned_mt", sample_docs, cores, True, 2)
+    run("cpu_ref_1t", max(sample_docs // 50, 200), 1, False, 1)
     return {
-        "value": round(sub.num_tokens * n_sw / dt / 1e6, 3),
+        "value": out["cpu_ref_mt"]["value"],
         "unit": "M tokens/s",
         "cores": cores,
         "kind": "port",
-        "sample": "first %d docs (%d tokens) of the same corpus, full V=%d and K=%d, %d full sweeps "
-                  "(z step %.2fs + merge/Phi %.2fs in the last one; the K*V Phi draw does not shrink with the sample)"
-                  % (sub.num_docs, sub.num_tokens, corpus.num_types, K, n_sw, t_b - t_a, t_c - t_b),
+        "sample": out["cpu_ref_mt"]["sample"] + " (the K*V Phi draw does not shrink with the sample)",
+        "variants": out,
     }
+
+
+def make_handle(native, K, V, args, local_rank):
+    return native.GGSHandle(K, V, args.alpha, args.beta, args.seed, device_id=local_rank,
+                            flags=native.FLAG_PCGS if args.scheme == "pcgs" else 0)
+
+
+def phases(tm):
+    n = max(tm["sweeps"], 1)
+    return {k: round(tm[k] / n, 4) for k in ("theta_ms", "z_ms", "merge_ms", "phi_ms", "exchange_ms")}
+
+
+def run_single(native, corpus, z0, K, args, local_rank, steps, warmup, fence):
+    """One handle over the whole corpus: (seconds for `steps` sweeps, per-sweep phase ms, launch info)."""
+    h = make_handle(native, K, corpus.num_types, args, local_rank)
+    if args.simulate_world > 1:
+        h.attach_null_exchange(args.simulate_rank, args.simulate_world)
+    h.set_corpus(corpus.doc_ptr, corpus.tokens)
+    h.set_z(z0, redraw_phi=True)
+
+    def run(n):
+        # batches of 5 sweeps: only the last sweep of a ggs_sweep call is waited for (no per-sweep host round trip)
+        for i in range(0, n, 5):
+            h.sweep(min(5, n - i))
+    run(warmup)
+    h.reset_timings()
+    fence()
+    t0 = time.perf_counter()
+    run(steps)
+    fence()
+    dt = time.perf_counter() - t0
+    tm = h.get_timings()
+    if args.simulate_world <= 1:
+        h.check_invariants()
+    info = h.launch_info()
+    h.close()
+    return dt, phases(tm), info
+
+
+def workload_string(D, V, N, K, args):
+    return ("LDAGroupedGibbsSampler sweep, synthetic LDA corpus D=%d V=%d N=%d tokens K=%d alpha=%g beta=%g seed=%d"
+            % (D, V, N, K, args.alpha, args.beta, args.seed))
+
+
+def extra_configs(native, corpus2, args, local_rank, fence, sha):
+    """BASELINE configs 3 (the same corpus at K=1024) and 4 (stand-in for 20-Newsgroups, whose file is not in the image:
+    D=18 846, V=60 000, mean 150 tokens, K=200) on one GPU: a few sweeps each, same timing discipline as the headline."""
+    import copy
+
+    from ldagroupedgibbssampler_amd.corpus import synthetic_lda_corpus
+    from ldagroupedgibbssampler_amd.sharded import java_lcg_initial_z
+    out = {}
+    for tag, K, corpus, steps, warmup in (("config3_K1024", 1024, corpus2, 5, 1), ("config4_standin_20ng_K200", 200, None, 10, 2)):
+        a = copy.copy(args)
+        a.topics, a.simulate_world = K, 1
+        if corpus is None:
+            corpus = synthetic_lda_corpus(18846, 60000, 150, true_topics=100, seed=args.seed)
+        z0 = java_lcg_initial_z(corpus.num_tokens, K, args.seed)
+        dt, ph, info = run_single(native, corpus, z0, K, a, local_rank, steps, warmup, fence)
+        workload = workload_string(corpus.num_docs, corpus.num_types, corpus.num_tokens, K, args)
+        out[tag] = {"workload": workload, "value": round(corpus.num_tokens * steps / dt / 1e6, 3), "unit": "M tokens/s", "steps": steps,
+                    "ms_per_step": round(dt / steps * 1e3, 4), "phase_ms_per_sweep": ph,
+                    "roofline": roofline_block(corpus, K, "ggs", corpus.num_tokens, ph["z_ms"], workload, sha, info.get("num_hot", 0))}
+    return out
 
 
 def main():
@@ -115,24 +272,32 @@ def main():
     ap.add_argument("--seed", type=int, default=2019)
     ap.add_argument("--cpu-sample-docs", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra-configs", action="store_true", help="skip the extra_configs legs (configs 3 and 4 stand-in) of the default N=1 run")
     ap.add_argument("--scheme", default="ggs", choices=["ggs", "pcgs"], help="ggs = the headline path; pcgs = the partially collapsed z loop (SURVEY 8f-1), for comparison")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N>1: weak = D documents PER RANK (default), strong = the N=1 corpus split across the ranks")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N>1: strong = the N=1 corpus split across the ranks (default, BASELINE.json), weak = D documents PER RANK")
+    ap.add_argument("--exchange", default="native", choices=["native", "torch"],
+                    help="N>1: native = the library's own RCCL exchange, topic-sliced Phi draw (default); torch = dense count all-reduce "
+                         "through torch.distributed, Phi re-drawn on every rank (the round-1 form, kept as a cross-check)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="process group backend; gloo + --single-device rehearses N ranks on ONE GPU (RCCL refuses two ranks per device)")
+                    help="process group backend; gloo + --single-device rehearses N ranks on ONE GPU (RCCL refuses two ranks per device): "
+                         "the native exchange then runs over its callback provider with host staging")
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (rehearsal only; the number is not a multi-GPU result)")
-    ap.add_argument("--no-strong-leg", action="store_true", help="N>1, weak scaling: skip the extra measurement of the N=1 corpus split across the ranks")
+    ap.add_argument("--no-weak-leg", action="store_true", help="N>1: skip the second measurement (the other scaling regime)")
     ap.add_argument("--force-sharded", action="store_true",
-                    help="run the doc-sharded path (process group + RCCL all-reduce) even with one rank; for testing")
+                    help="run the doc-sharded path (process group + RCCL exchange) even with one rank; for testing")
+    ap.add_argument("--simulate-rank", type=int, default=0)
+    ap.add_argument("--simulate-world", type=int, default=1,
+                    help="N=1 only, a TIMING AID: run as rank --simulate-rank of this many with the peers missing (ggs_attach_null_exchange) on that "
+                         "rank's share of the corpus; the sampler's results are wrong by construction, the per-rank phase times are what is read")
     args = ap.parse_args()
 
-    import numpy as np
-    import torch  # device plumbing + torch.distributed (RCCL); imported before libggs_hip so both share one HIP runtime
+    import torch  # device plumbing + torch.distributed (barrier, max over ranks, the unique id); imported before libggs_hip so both share one HIP runtime and one RCCL
 
     from ldagroupedgibbssampler_amd import native
-    from ldagroupedgibbssampler_amd.corpus import synthetic_lda_corpus
-    from ldagroupedgibbssampler_amd.sharded import (ShardedGGS, TorchHipExchange, gather_shard_sizes, java_lcg_initial_z,
-                                                    java_lcg_initial_z_slice)
+    from ldagroupedgibbssampler_amd.corpus import even_split, synthetic_lda_corpus
+    from ldagroupedgibbssampler_amd.sharded import (ShardedGGS, TorchHipExchange, gather_shard_sizes, gloo_callback_exchange, java_lcg_initial_z,
+                                                    java_lcg_initial_z_slice, rccl_exchange)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -157,138 +322,118 @@ def main():
         else:
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
-    K = args.topics
-    weak = sharded and args.scaling == "weak"
-    corpus = synthetic_lda_corpus(args.docs, args.types, args.mean_len, true_topics=100, seed=args.seed + (rank if weak else 0))
-    if weak:
-        sizes = gather_shard_sizes(corpus, rank, world, device="cuda")
-        total_docs, total_tokens = sum(d for d, _ in sizes), sum(t for _, t in sizes)
-        z0 = java_lcg_initial_z_slice(sum(t for _, t in sizes[:rank]), corpus.num_tokens, K, args.seed)   # one sequential stream over the global corpus
-    else:
-        total_docs, total_tokens = corpus.num_docs, corpus.num_tokens
-        z0 = java_lcg_initial_z(corpus.num_tokens, K, args.seed)
-
-    h = native.GGSHandle(K, corpus.num_types, args.alpha, args.beta, args.seed, device_id=local_rank,
-                         flags=native.FLAG_PCGS if args.scheme == "pcgs" else 0)
-    if sharded:
-        if weak:
-            sh = ShardedGGS.from_local_shard(h, TorchHipExchange, corpus, sizes, rank, world)
-            sh.set_z_local(z0)
-        else:
-            sh = ShardedGGS(h, TorchHipExchange, corpus, rank, world)
-            sh.set_z_global(z0)
-        def run(n):
-            # one count exchange per sweep, enqueued back to back; the host waits once per batch of 5
-            for i in range(0, n, 5):
-                sh.sweep(min(5, n - i))
-        n_local = sh.local.num_tokens
-    else:
-        h.set_corpus(corpus.doc_ptr, corpus.tokens)
-        h.set_z(z0, redraw_phi=True)
-        def run(n):
-            # batches of 5 sweeps: only the last sweep of a ggs_sweep call is waited for and timed by the library
-            # (no per-sweep host round trip); 20 steps still give 4 samples of every phase
-            for i in range(0, n, 5):
-                h.sweep(min(5, n - i))
-        n_local = corpus.num_tokens
-
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    run(args.warmup)
-    h.reset_timings()
-    fence()
-    t0 = time.perf_counter()
-    run(args.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    def max_over_ranks(dt):
+        if dist is None:
+            return dt
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    tm = h.get_timings()
-    h.check_invariants()
+        return float(t.item())
 
-    # N>1, weak scaling: the same run also measures the N=1 corpus SPLIT across the ranks (the strong-scaling reading of
-    # BASELINE's "reported at 1, 2, 4 and 8 GPUs"), reported beside the headline value as "strong_scaling".
-    strong = None
-    if weak and world > 1 and not args.no_strong_leg:
-        h.close()                     # its streams first: hardware queues are few, and a second handle beside it runs serialised
-        corpus1 = corpus if rank == 0 else synthetic_lda_corpus(args.docs, args.types, args.mean_len, true_topics=100, seed=args.seed)
-        h1 = native.GGSHandle(K, corpus1.num_types, args.alpha, args.beta, args.seed, device_id=local_rank,
-                              flags=native.FLAG_PCGS if args.scheme == "pcgs" else 0)
-        sh1 = ShardedGGS(h1, TorchHipExchange, corpus1, rank, world)
-        sh1.set_z_global(java_lcg_initial_z(corpus1.num_tokens, K, args.seed))
-        for i in range(0, args.warmup, 5):
-            sh1.sweep(min(5, args.warmup - i))
+    def exchange_factory():
+        if args.exchange == "torch":
+            return TorchHipExchange
+        return rccl_exchange(rank, world) if args.backend == "nccl" else gloo_callback_exchange(rank, world)
+
+    K = args.topics
+
+    def run_sharded(weak):
+        """One measurement over `world` ranks: dict(dt, phases, docs, tokens, n_local, V, info, local corpus)"""
+        corpus = synthetic_lda_corpus(args.docs, args.types, args.mean_len, true_topics=100, seed=args.seed + (rank if weak else 0))
+        h = make_handle(native, K, corpus.num_types, args, local_rank)
+        if weak:
+            sizes = gather_shard_sizes(corpus, rank, world, device="cuda" if args.backend == "nccl" else None)
+            total_docs, total_tokens = sum(d for d, _ in sizes), sum(t for _, t in sizes)
+            sh = ShardedGGS.from_local_shard(h, exchange_factory(), corpus, sizes, rank, world)
+            sh.set_z_local(java_lcg_initial_z_slice(sh.tok_base, corpus.num_tokens, K, args.seed))   # one sequential stream over the global corpus
+        else:
+            total_docs, total_tokens = corpus.num_docs, corpus.num_tokens
+            sh = ShardedGGS(h, exchange_factory(), corpus, rank, world)
+            sh.set_z_global(java_lcg_initial_z(corpus.num_tokens, K, args.seed))
+
+        def run(n):
+            # the sweeps are enqueued back to back, exchange included; the host waits once per batch of 5
+            for i in range(0, n, 5):
+                sh.sweep(min(5, n - i))
+        run(args.warmup)
+        h.reset_timings()
         fence()
-        t1 = time.perf_counter()
-        for i in range(0, args.steps, 5):
-            sh1.sweep(min(5, args.steps - i))
+        t0 = time.perf_counter()
+        run(args.steps)
         fence()
-        dt1 = time.perf_counter() - t1
-        t = torch.tensor([dt1], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt1 = float(t.item())
-        h1.check_invariants()
-        tm1 = h1.get_timings()
-        strong = {"value": round(corpus1.num_tokens * args.steps / dt1 / 1e6, 3), "unit": "M tokens/s", "ms_per_step": round(dt1 / args.steps * 1e3, 4),
-                  "phase_ms_per_sweep": {k: round(tm1[k] / max(tm1["sweeps"], 1), 4) for k in ("theta_ms", "z_ms", "merge_ms", "phi_ms")},
-                  "workload": "the N=1 corpus (D=%d, N=%d tokens) split across the %d ranks" % (corpus1.num_docs, corpus1.num_tokens, world)}
-        h1.close()
+        dt = max_over_ranks(time.perf_counter() - t0)
+        tm = h.get_timings()
+        h.check_invariants()            # with the native exchange: a collective call (gathers the corpus-wide counts)
+        res = dict(dt=dt, phases=phases(tm), docs=total_docs, tokens=total_tokens, n_local=sh.local.num_tokens, V=corpus.num_types,
+                   info=h.launch_info(), local=sh.local)
+        h.close()                       # before a second leg builds its handle: hardware queues are few
+        return res
+
+    sha = csrc_sha16()
+    other = None
+    corpus = z0 = None
+    if sharded:
+        weak_first = args.scaling == "weak"
+        r = run_sharded(weak_first)
+        if world > 1 and not args.no_weak_leg:
+            r2 = run_sharded(not weak_first)
+            other = {"value": round(r2["tokens"] * args.steps / r2["dt"] / 1e6, 3), "unit": "M tokens/s",
+                     "ms_per_step": round(r2["dt"] / args.steps * 1e3, 4), "phase_ms_per_sweep": r2["phases"],
+                     "workload": ("every rank brings D=%d documents: D=%d, N=%d tokens over %d ranks" % (args.docs, r2["docs"], r2["tokens"], world)) if not weak_first
+                     else "the N=1 corpus (D=%d, N=%d tokens) split across the %d ranks" % (r2["docs"], r2["tokens"], world)}
+    else:
+        corpus = synthetic_lda_corpus(args.docs, args.types, args.mean_len, true_topics=100, seed=args.seed)
+        z0 = java_lcg_initial_z(corpus.num_tokens, K, args.seed)
+        run_corpus, run_z0 = corpus, z0
+        if args.simulate_world > 1:
+            b = even_split(corpus.num_docs, args.simulate_world)
+            run_corpus, _, tb = corpus.shard(b[args.simulate_rank], b[args.simulate_rank + 1])
+            run_z0 = z0[tb:tb + run_corpus.num_tokens]
+        dt, ph, info = run_single(native, run_corpus, run_z0, K, args, local_rank, args.steps, args.warmup, fence)
+        r = dict(dt=dt, phases=ph, docs=run_corpus.num_docs, tokens=run_corpus.num_tokens, n_local=run_corpus.num_tokens, V=corpus.num_types,
+                 info=info, local=run_corpus)
 
     if rank == 0:
-        btok = algorithmic_bytes_per_token(K)
-        z_ms = tm["z_ms"] / max(tm["sweeps"], 1)            # HIP events on the handle's stream, over the timed region
-        achieved = n_local * btok / (z_ms * 1e-3) / 1e9 if z_ms > 0 else 0.0
-        # the z step: for K <= 192 the cold-chunk kernel and, beside it on a second stream, the hot-chunk kernel
-        kmax = 8 * ((K + 7) // 8)
-        zkernels = ((["pcgs_sliced_kernel<%d>" % kmax] if K <= 192 else ["pcgs_z_kernel"]) if args.scheme == "pcgs" else
-                    ["z_sliced_kernel<%d>" % kmax, "z_hot_kernel<%d>" % kmax] if K <= 192 else ["z_stream_kernel"])
+        workload = (workload_string(r["docs"], r["V"], r["tokens"], K, args)
+                    + (" (%d documents per rank)" % args.docs if sharded and args.scaling == "weak" else "")
+                    + (" [TIMING AID: rank %d of a simulated %d-rank split, peers missing]" % (args.simulate_rank, args.simulate_world) if args.simulate_world > 1 else ""))
+        if sharded:
+            how = ("native exchange: RCCL reduce-scatter of int32 counts by topic slice + Phi slice draw + fp64 all-gather" if args.exchange == "native" and args.backend == "nccl"
+                   else "native exchange over the callback provider (gloo, host staged)" if args.exchange == "native"
+                   else "torch.distributed int32 count all-reduce (%s), Phi re-drawn on every rank" % ("RCCL" if args.backend == "nccl" else "gloo"))
+            par = "doc-sharded x%d, %s%s" % (world, how, ", ALL RANKS ON ONE GPU (rehearsal)" if args.single_device else "")
+        else:
+            par = "1 GPU"
         line = {
             "metric": "M tokens sampled/sec (whole node) per Gibbs sweep at K=%d" % K + ("" if args.scheme == "ggs" else " (scheme=%s)" % args.scheme),
-            "value": round(total_tokens * args.steps / dt / 1e6, 3),
+            "value": round(r["tokens"] * args.steps / r["dt"] / 1e6, 3),
             "unit": "M tokens/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "ms_per_step": round(r["dt"] / args.steps * 1e3, 4),
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": args.scaling if sharded else "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {
-                "workload": "LDAGroupedGibbsSampler sweep, synthetic LDA corpus D=%d V=%d N=%d tokens K=%d alpha=%g beta=%g seed=%d"
-                            % (total_docs, corpus.num_types, total_tokens, K, args.alpha, args.beta, args.seed)
-                            + (" (%d documents per rank)" % args.docs if weak else ""),
-                "parallelism": ("doc-sharded x%d, int32 count all-reduce (%s) per sweep%s"
-                                % (world, "RCCL" if args.backend == "nccl" else "gloo", ", ALL RANKS ON ONE GPU (rehearsal)" if args.single_device else ""))
-                               if sharded else "1 GPU",
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": " + ".join(zkernels),
-                "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": measured_traffic(["ggs::" + k.split("<")[0] for k in zkernels]),
-                "bytes_per_token": btok,
-                "tokens_per_launch": n_local,
-                "avg_launch_ms": round(z_ms, 4),
-            },
-            "phase_ms_per_sweep": {k: round(tm[k] / max(tm["sweeps"], 1), 4) for k in ("theta_ms", "z_ms", "merge_ms", "phi_ms")},
+            "config": {"workload": workload, "parallelism": par},
+            "roofline": roofline_block(r["local"], K, args.scheme, r["n_local"], r["phases"]["z_ms"], workload, sha, r["info"].get("num_hot", 0)),
+            "phase_ms_per_sweep": r["phases"],
+            "build": {"csrc_sha16": sha},
         }
-        if strong is not None:
-            line["strong_scaling"] = strong
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(corpus, K, args.alpha, args.beta, args.seed, z0, args.cpu_sample_docs)
+        if other is not None:
+            line["weak_scaling" if args.scaling == "strong" else "strong_scaling"] = other
+        if not sharded and args.simulate_world <= 1:
+            if not args.no_extra_configs and args.scheme == "ggs" and K == 100 and args.docs == 100000:
+                line["extra_configs"] = extra_configs(native, corpus, args, local_rank, fence, sha)
+            if not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(corpus, K, args.alpha, args.beta, args.seed, z0, args.cpu_sample_docs)
         print(json.dumps(line), flush=True)
-    if strong is None:
-        h.close()
     if dist is not None:
         dist.destroy_process_group()
 

@@ -20,6 +20,15 @@
  * One handle = one GPU.  Several live handles on the SAME device in one process are correct but slow: each brings
  * three streams and the runtime multiplexes all of them onto the device's few hardware queues (measured: a second
  * handle's sweeps ran 6x slower beside an idle first one) -- destroy a handle before building its successor.
+ *
+ * Several GPUs: documents are sharded contiguously, one handle per shard (doc_base / tok_base of ggs_set_corpus), and
+ * the handles are joined by an EXCHANGE (section "multi-GPU" below): ggs_attach_rccl* (RCCL over xGMI, one process per
+ * GPU or one process for all), or ggs_attach_exchange (caller-supplied transport).  With an exchange attached the
+ * sweep itself contains the per-sweep merge of the reference (UPLDA:1107-1221; ADLDA.java:302-332), in the form
+ * SURVEY.md 8e prefers: reduce-scatter of the int32 counts by TOPIC SLICE (even-split rule of
+ * randomscan/topic/EvenSplitTopicBatchBuilder.java:28-39), Phi drawn for the rank's own topics only (the topic-parallel
+ * samplePhi of GGS:139-171 with one batch per GPU), all-gather of the fp64 Phi slices.  Results are bit-identical to
+ * one handle over the whole corpus: the Philox element ids are global (token, document*K+k, k*V+v).
  */
 #ifndef GGS_HIP_H
 #define GGS_HIP_H
@@ -30,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GGS_ABI_VERSION 1
+#define GGS_ABI_VERSION 2
 
 typedef struct ggs_handle ggs_handle;
 
@@ -89,9 +98,11 @@ typedef struct ggs_timings {
   double theta_ms;  /* cumulative: per-document theta draw (GGS:57-72)                         */
   double z_ms;      /* cumulative: token loop (GGS:79-130)                                     */
   double merge_ms;  /* cumulative: count rebuild, the device form of updateCounts (UPLDA:1107-1221) */
-  double phi_ms;    /* cumulative: samplePhi (GGS:139-198)                                     */
+  double phi_ms;    /* cumulative: samplePhi (GGS:139-198); with an exchange: this rank's topic slice + the repack */
   int64_t sweeps;
   int64_t tokens_sampled;
+  double exchange_ms; /* cumulative: the collectives of an attached exchange (count reduce-scatter + Phi all-gather);
+                         0 without one.  ABI version 2. */
 } ggs_timings;
 
 /* ---- lifecycle ------------------------------------------------------------ */
@@ -154,13 +165,62 @@ int ggs_sample_z_given_phi(ggs_handle *h, int32_t n_sweeps);
  * deltas (batchLocalTopicTypeUpdates, UPLDA:102,1107-1221; ADLDA's sumTypeTopicCounts,
  * ADLDA.java:302): n_wk(new) = n_wk(old) + sum of deltas = sum over shards of the local
  * (word, z) histograms -- the same integers. */
-int ggs_counts_device_ptr(ggs_handle *h, void **dev_ptr, int64_t *num_elems);
+int ggs_counts_device_ptr(ggs_handle *h, void **dev_ptr, int64_t *num_elems);   /* GGS_ERR_STATE with an exchange attached */
 /* Corpus-wide token count (all shards); what ggs_check_invariants expects the
  * counts to sum to.  Defaults to this handle's own token count. */
 int ggs_set_global_token_count(ggs_handle *h, int64_t n_tokens);
 /* Block until everything queued on the handle's stream has finished; surfaces
  * device-side error flags (what Java throws from the worker threads). */
 int ggs_synchronize(ggs_handle *h);
+
+/* ---- multi-GPU: the exchange --------------------------------------------------------------------------------------
+ * Replaces the thread-shared merge of the reference -- updateCounts/updateTopics (UPLDA:1107-1221), the blocking queue
+ * of topic batches in samplePhi (GGS:139-171), ADLDA's sumTypeTopicCounts + copy-back (ADLDA.java:302-332) -- by three
+ * collectives over `nranks` handles, rank r owning the documents of shard r and the TOPICS of slice r
+ * (sizes K/nranks + (K % nranks > r), EvenSplitTopicBatchBuilder.java:28-39; Ksm = the largest slice):
+ *   reduce_scatter_i32  send int32 [nranks][V][Ksm] (this shard's (word, topic) histogram, slice-major, zero padded)
+ *                       -> recv int32 [V][Ksm] = the corpus-wide counts of the rank's own topics
+ *   all_gather_f64      send fp64 [V][Ksm] (the rank's normalised Phi slice) -> recv fp64 [nranks][V][Ksm]
+ *   all_gather_i32      the same for the count slices; only when a getter / diagnostic needs corpus-wide counts
+ * Attach after ggs_create and before ggs_set_corpus.  From then on ggs_sweep / ggs_sweep_end / ggs_init_phi /
+ * ggs_set_z(redraw) / ggs_sample_z_given_phi contain the collectives, and every call that reads corpus-wide counts
+ * (ggs_get_type_topic_counts, ggs_get_topic_totals, ggs_check_invariants, ggs_model_log_likelihood,
+ * ggs_heldout_log_likelihood) gathers them first: all of these are COLLECTIVE calls -- every rank makes them in the
+ * same order.  The handle then runs on a stream of its own (not the legacy default stream) and orders the collectives
+ * on it; nothing relies on another library's current-stream convention. */
+typedef struct ggs_exchange_ops {
+  int32_t struct_size;   /* = sizeof(ggs_exchange_ops) */
+  int32_t reserved;
+  void *ctx;
+  /* Each callback enqueues (or performs) the collective in order behind the work already queued on hip_stream and
+   * returns 0 on success; counts are ELEMENTS per rank. */
+  int (*reduce_scatter_i32)(void *ctx, const void *send, void *recv, int64_t recv_count, void *hip_stream);
+  int (*all_gather_f64)(void *ctx, const void *send, void *recv, int64_t send_count, void *hip_stream);
+  int (*all_gather_i32)(void *ctx, const void *send, void *recv, int64_t send_count, void *hip_stream);
+} ggs_exchange_ops;
+/* Caller-supplied transport (tests: gloo through host staging; a JVM with its own collectives). */
+int ggs_attach_exchange(ggs_handle *h, int32_t rank, int32_t nranks, const ggs_exchange_ops *ops);
+/* RCCL, one process per GPU: rank 0 calls ggs_rccl_unique_id and hands the 128 bytes to every rank (any channel);
+ * every rank then calls ggs_attach_rccl, which is ncclCommInitRank on the handle's device (collective, blocking).
+ * librccl is dlopen'ed on first use (librccl.so.1: the copy already in the process if there is one). */
+#define GGS_RCCL_UNIQUE_ID_BYTES 128
+int ggs_rccl_unique_id(void *out_id /* GGS_RCCL_UNIQUE_ID_BYTES */);
+int ggs_attach_rccl(ggs_handle *h, int32_t rank, int32_t nranks, const void *unique_id);
+/* The same with a communicator the caller created (ncclComm_t; not destroyed by ggs_destroy). */
+int ggs_attach_rccl_comm(ggs_handle *h, int32_t rank, int32_t nranks, void *nccl_comm);
+/* RCCL, ONE process driving n GPUs (the JVM of the reference is one process): creates n handles on device_ids[0..n)
+ * from cfg (cfg->device_id ignored), joined by ncclCommInitAll.  The group entry points take the handles in rank
+ * order and issue every phase for all devices from the calling thread, the collectives inside ncclGroupStart/End. */
+int ggs_group_create(const ggs_config *cfg, int32_t n, const int32_t *device_ids, ggs_handle **out_handles /* n */);
+void ggs_group_destroy(ggs_handle **handles, int32_t n);
+int ggs_group_set_z(ggs_handle **handles, int32_t n, const int32_t *const *z /* n pointers, each shard's N */, int32_t redraw_phi);
+int ggs_group_sweep(ggs_handle **handles, int32_t n, int32_t n_sweeps);
+/* Timing aid, NOT a sampler: behaves as rank `rank` of `nranks` with the peers' contributions missing (the collectives
+ * become local copies), so that one GPU can time the per-rank compute phases of an N-GPU split.  Counts and Phi are
+ * then wrong by construction (ggs_check_invariants fails). */
+int ggs_attach_null_exchange(ggs_handle *h, int32_t rank, int32_t nranks);
+/* rank, nranks and the rank's topic slice [k_begin, k_end) (0, 1, 0, K without an exchange) */
+int ggs_get_exchange_info(const ggs_handle *h, int32_t *rank, int32_t *nranks, int32_t *k_begin, int32_t *k_end);
 
 /* ---- state copy-back (the Java getters) ------------------------------------ */
 int ggs_get_z(ggs_handle *h, int32_t *z /*N*/);                         /* getZIndicators, MSLDA:464-477 */
@@ -180,6 +240,9 @@ int ggs_reset_timings(ggs_handle *h);
 int ggs_check_invariants(ggs_handle *h);
 /* Launch geometry of the z kernel, for bench.py's roofline accounting. */
 int ggs_get_launch_info(ggs_handle *h, int64_t *num_chunks, int32_t *lds_bytes_z, int32_t *docs_per_block_theta);
+/* Rows of the z kernels' LDS hot-word table for the current corpus (0 for K > 192 and scheme pcgs): tokens of these
+ * words read no phiT row from memory -- bench.py's cold-row byte accounting. */
+int ggs_get_num_hot_words(ggs_handle *h, int32_t *num_hot);
 /* ---- primitives, exported so the parity tests can pin each layer ----------- */
 int ggs_debug_philox(int32_t device_id, int64_t n, const uint32_t *ctr /*n*4*/, const uint32_t *key /*n*2*/, uint32_t *out /*n*4*/);
 int ggs_debug_math(int32_t device_id, int32_t op /*0 log,1 pow,2 sqrt,3 div*/, int64_t n, const double *x, const double *y, double *out);

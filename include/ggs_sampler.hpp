@@ -105,7 +105,7 @@ class LDAGroupedGibbsSampler {
       phiSamplingTimeCum += t1.phi_ms - t0.phi_ms;
       postIteration();
       if (std::ifstream("abort").good()) abort();                           // the sentinel file of UPLDA:131,908-910
-      if (zSamplingTimeCum + phiSamplingTimeCum > maxExecMs) break;         // UPLDA:926-928
+      if (zSamplingTimeCum + phiSamplingTimeCum >= maxExecMs) break;        // UPLDA:926-928
     }
     postSample();
   }

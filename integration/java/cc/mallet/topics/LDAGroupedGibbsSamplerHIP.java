@@ -14,7 +14,9 @@
  *   - Java-side arrays that diagnostics read as FIELDS (typeTopicCounts, topicTypeCountMapping,
  *     tokensPerTopic, phi, thetaMatrix, each document's topicSequence; UPLDA:1573-1758) are
  *     refreshed lazily by syncToJava(), called from postPhi() only when a diagnostic of this
- *     iteration needs them, and always from postSample().
+ *     iteration needs them, and always from postSample();
+ *   - getPhiMeans() reads the device's running mean (Java's phiMean[][] stays empty) and setPhi()
+ *     uploads the matrix, so the two LDASamplerWithPhi methods act on the state that is sampled from.
  */
 package cc.mallet.topics;
 
@@ -180,6 +182,38 @@ public class LDAGroupedGibbsSamplerHIP extends LDAGroupedGibbsSampler {
 	}
 
 	@Override public double[][] getPhi() { syncToJava(); return phi; }
+
+	/** UPLDA:1954-1966.  The running sum lives on the device (GGS:193-197 accumulates there), so Java's own phiMean[][]
+	 *  is never filled: return the device mean, [K][V], or null with the reference's warning when nothing was sampled. */
+	@Override
+	public double[][] getPhiMeans() {
+		double[] flat = new double[numTopics * numTypes];
+		int n = nGetPhiMean(handle, flat);            // phiMean / noSampledPhi, the division of UPLDA:1959-1964 done natively
+		if (n == 0) {
+			logger.warning("No Phi has yet been sampled! getPhiMeans returns 'null'. Ensure that you have correctly configured 'phi_mean_burnin' and 'phi_mean_thin'");
+			return null;
+		}
+		double[][] result = new double[numTopics][numTypes];
+		for (int k = 0; k < numTopics; k++) System.arraycopy(flat, k * numTypes, result[k], 0, numTypes);
+		return result;
+	}
+
+	/** UPLDA:1897-1902: the device must sample from the Phi the caller set, not from its own last draw
+	 *  (ggs_set_phi also restarts the running phi mean at zero, as `phiMean = new double[..][..]` does). */
+	@Override
+	public void setPhi(double[][] phi) {
+		super.setPhi(phi);
+		double[] flat = new double[numTopics * numTypes];
+		for (int k = 0; k < numTopics; k++) System.arraycopy(phi[k], 0, flat, k * numTypes, numTypes);
+		nSetPhi(handle, flat);
+		javaStateStale = true;                        // z, counts and theta on the Java side are refreshed lazily as before
+	}
+
+	@Override
+	public void setPhi(double[][] phi, cc.mallet.types.Alphabet dataAlphabet, cc.mallet.types.Alphabet targetAlphabet) {
+		super.setPhi(phi, dataAlphabet, targetAlphabet);   // the alphabet checks and ensureConsistentPhi of UPLDA:1913-1920
+		setPhi(phi);
+	}
 	@Override public int[][] getTypeTopicMatrix() { syncToJava(); return super.getTypeTopicMatrix(); }
 	@Override public int[] getTopicTotals() { syncToJava(); return super.getTopicTotals(); }
 	@Override public int[][] getZIndicators() { syncToJava(); return super.getZIndicators(); }

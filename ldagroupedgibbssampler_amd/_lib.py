@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GGS_HIP_LIB") or os.path.join(CSRC, "libggs_hip.so")   # override: kernel experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ggs_hip.h")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 
 class GGSConfig(C.Structure):
@@ -41,6 +41,22 @@ class GGSTimings(C.Structure):
         ("phi_ms", C.c_double),
         ("sweeps", C.c_int64),
         ("tokens_sampled", C.c_int64),
+        ("exchange_ms", C.c_double),
+    ]
+
+
+# int cb(void *ctx, const void *send, void *recv, int64_t count, void *hip_stream)
+EXCHANGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+
+
+class GGSExchangeOps(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32),
+        ("reserved", C.c_int32),
+        ("ctx", C.c_void_p),
+        ("reduce_scatter_i32", EXCHANGE_CB),
+        ("all_gather_f64", EXCHANGE_CB),
+        ("all_gather_i32", EXCHANGE_CB),
     ]
 
 
@@ -85,6 +101,17 @@ SIGNATURES = {
     "ggs_reset_timings": (C.c_int, [_vp]),
     "ggs_check_invariants": (C.c_int, [_vp]),
     "ggs_get_launch_info": (C.c_int, [_vp, _lp, _ip, _ip]),
+    "ggs_get_num_hot_words": (C.c_int, [_vp, _ip]),
+    "ggs_attach_exchange": (C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(GGSExchangeOps)]),
+    "ggs_rccl_unique_id": (C.c_int, [_vp]),
+    "ggs_attach_rccl": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),
+    "ggs_attach_rccl_comm": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),
+    "ggs_group_create": (C.c_int, [C.POINTER(GGSConfig), C.c_int32, _ip, C.POINTER(_vp)]),
+    "ggs_group_destroy": (None, [C.POINTER(_vp), C.c_int32]),
+    "ggs_group_set_z": (C.c_int, [C.POINTER(_vp), C.c_int32, C.POINTER(_ip), C.c_int32]),
+    "ggs_group_sweep": (C.c_int, [C.POINTER(_vp), C.c_int32, C.c_int32]),
+    "ggs_attach_null_exchange": (C.c_int, [_vp, C.c_int32, C.c_int32]),
+    "ggs_get_exchange_info": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
     "ggs_debug_philox": (C.c_int, [C.c_int32, C.c_int64, _up, _up, _up]),
     "ggs_debug_math": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _dp, _dp, _dp]),
     "ggs_debug_draw": (C.c_int, [C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int64,
@@ -130,6 +157,24 @@ def _share_hip_runtime_with_torch():
     cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
     if os.path.exists(cand):
         C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
+def share_rccl_with_torch():
+    """One process must hold ONE RCCL as well.  libggs_hip dlopen()s "librccl.so.1" on the first use of its multi-GPU
+    exchange; if torch is installed its wheel brings a librccl.so of its own (same SONAME), and a process that maps
+    /opt/rocm's copy first and torch's later aborts in teardown (double free) -- and so does one that maps torch's copy
+    by hand before `import torch`.  The order that works is torch first: then the library's request resolves to the
+    copy already mapped.  Without torch (the JNI deployment) this is a no-op and /opt/rocm's RCCL is the only one."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        if importlib.util.find_spec("torch") is None:
+            return
+    except (ImportError, ValueError):
+        return
+    import torch  # noqa: F401
 
 
 def load():

@@ -19,6 +19,7 @@
 #include "ggs_z_pcgs.hpp"
 #include "ggs_loglik.hpp"
 #include "ggs_heldout.hpp"
+#include "ggs_exchange.hpp"
 
 using namespace ggs;
 
@@ -32,8 +33,9 @@ constexpr int kMaxLdsBytes = 160 * 1024;
 constexpr int kEvRing = 8;
 struct Events {
   hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t x[3] = {nullptr, nullptr, nullptr};   // with an exchange: after the count reduce-scatter, after the slice's Phi draw, after the all-gather
   hipEvent_t th0 = nullptr, th1 = nullptr;   // side-stream theta draw consumed by this sweep
-  bool used_ahead = false;
+  bool used_ahead = false, exchanged = false;
 };
 
 }  // namespace
@@ -94,6 +96,18 @@ struct ggs_handle {
   bool have_test = false;
   void *d_scratch = nullptr;
   size_t scratch_bytes = 0;
+
+  // multi-GPU exchange (ggs_exchange.hpp).  Without one: Ks = Ksm = K, k0 = 0 and the counts live in d_n_wk.
+  Exchange *xg = nullptr;
+  hipStream_t own_stream = nullptr;                    // with an exchange the handle leaves the legacy default stream
+  int32_t Ks = 0, Ksm = 0, k0 = 0;                     // this rank's topic slice [k0, k0 + Ks), widest slice Ksm
+  int64_t *d_koff = nullptr;                           // [K] column of topic k in the slice-major arrays
+  int32_t *d_cnt_send = nullptr, *d_cnt_own = nullptr, *d_cnt_all = nullptr, *d_n_k_own = nullptr;
+  double *d_phi_own = nullptr, *d_phi_all = nullptr, *d_mag_own = nullptr, *d_tot_own = nullptr;
+  bool counts_global = true;                           // d_n_wk holds the corpus-wide counts
+  bool cnt_own_valid = false;                          // d_cnt_own = reduce-scatter of the current d_cnt_send
+  bool n_k_valid = false;                              // d_n_k follows d_n_wk
+  std::vector<ggs_handle *> group;                     // ggs_group_create: the handles of the group, in rank order (rank 0 only)
 
   Events evs[kEvRing];
   int ev_head = 0, ev_pending = 0;                     // slot of the sweep in progress; sweeps enqueued but not settled
@@ -162,70 +176,162 @@ int launch_permute_z(ggs_handle *h) {
   return GGS_OK;
 }
 
-// n_wk = histogram of (word, z) over this handle's tokens (UPLDA:471-474 summed over the corpus).
+// n_wk = histogram of (word, z) over this handle's tokens (UPLDA:471-474 summed over the corpus).  With an exchange the
+// histogram goes straight into the slice-major send buffer of the count reduce-scatter.
 int launch_count_rebuild(ggs_handle *h) {
-  const size_t kv = (size_t)h->K * h->V;
-  HIP_TRY(h, hipMemsetAsync(h->d_n_wk, 0, kv * sizeof(int32_t), h->stream));
+  const size_t cells = h->xg ? (size_t)h->xg->nranks * h->V * h->Ksm : (size_t)h->K * h->V;
+  int32_t *dst = h->xg ? h->d_cnt_send : h->d_n_wk;
+  HIP_TRY(h, hipMemsetAsync(dst, 0, cells * sizeof(int32_t), h->stream));
   if (h->S > 0) {
     CountParams cp{};
-    cp.zw = h->d_zw; cp.seg_word = h->d_seg_word; cp.seg_begin = h->d_seg_begin; cp.n_wk = h->d_n_wk; cp.K = h->K; cp.num_segs = (int32_t)h->S;
+    cp.zw = h->d_zw; cp.seg_word = h->d_seg_word; cp.seg_begin = h->d_seg_begin; cp.n_wk = dst; cp.K = h->K; cp.num_segs = (int32_t)h->S;
+    cp.koff = h->xg ? h->d_koff : nullptr; cp.row_stride = h->xg ? h->Ksm : h->K;
     hipLaunchKernelGGL(count_sorted_kernel, dim3((unsigned)((h->S + kCountSegsPerBlock - 1) / kCountSegsPerBlock)), dim3(256), (size_t)h->K * sizeof(int32_t),
                        h->stream, cp);
   }
   HIP_TRY(h, hipGetLastError());
+  h->n_k_valid = false;
+  if (h->xg) { h->counts_global = false; h->cnt_own_valid = false; }
   return GGS_OK;
 }
 
-// out[k] = sum over v, in index order, of src[v][k] (MAGNITUDE: of beta + src[v][k]) -- the exact
-// parallel formulation of ggs_exact_sum.hpp, or the element-by-element chain it replaces
+// out[k] = sum over v, in index order, of src[v][k] (MAGNITUDE: of beta + src[v][k]) for the Ks columns of a topic
+// slice -- the exact parallel formulation of ggs_exact_sum.hpp, or the element-by-element chain it replaces
 template <typename T, bool MAGNITUDE>
-void launch_column_sum(ggs_handle *h, const T *src, int32_t pitch, double *out, int32_t *n_k = nullptr) {
+void launch_column_sum(ggs_handle *h, const T *src, int32_t pitch, int32_t Ks, double *out, int32_t *n_k = nullptr) {
+  if (Ks <= 0) return;
   if (!h->exact_sum) {
-    hipLaunchKernelGGL((column_chain_kernel<T, MAGNITUDE>), dim3((h->K + 7) / 8), dim3(256), 0, h->stream, src, pitch, h->K, h->V, h->beta, out);
+    hipLaunchKernelGGL((column_chain_kernel<T, MAGNITUDE>), dim3((Ks + 7) / 8), dim3(256), 0, h->stream, src, pitch, Ks, h->V, h->beta, out);
     return;
   }
   SumParams sp{};
   sp.src = src; sp.pref = h->d_sum_pref; sp.fn = h->d_sum_fn; sp.out = out; sp.beta = h->beta; sp.n_k = n_k;
-  sp.pitch = pitch; sp.K = h->K; sp.V = h->V; sp.nseg = h->sum_nseg;
-  const dim3 rows((unsigned)h->sum_nseg, (unsigned)((h->K + kSumBlock - 1) / kSumBlock));
+  sp.pitch = pitch; sp.K = Ks; sp.V = h->V; sp.nseg = h->sum_nseg;
+  const dim3 rows((unsigned)h->sum_nseg, (unsigned)((Ks + kSumBlock - 1) / kSumBlock));
   hipLaunchKernelGGL((sum_seg_kernel<T, MAGNITUDE>), rows, dim3(kSumBlock), 0, h->stream, sp);
-  hipLaunchKernelGGL(sum_prefix_kernel, dim3((unsigned)h->K), dim3(64), 0, h->stream, sp);
+  hipLaunchKernelGGL(sum_prefix_kernel, dim3((unsigned)Ks), dim3(64), 0, h->stream, sp);
   hipLaunchKernelGGL((sum_segfn_kernel<T, MAGNITUDE>), rows, dim3(kSumBlock), 0, h->stream, sp);
-  hipLaunchKernelGGL((sum_walk_kernel<T, MAGNITUDE>), dim3((unsigned)h->K), dim3(64), 0, h->stream, sp);
+  hipLaunchKernelGGL((sum_walk_kernel<T, MAGNITUDE>), dim3((unsigned)Ks), dim3(64), 0, h->stream, sp);
 }
 
-int launch_magnitude(ggs_handle *h) {
-  HIP_TRY(h, hipMemsetAsync(h->d_n_k, 0, sizeof(int32_t) * (size_t)h->K, h->stream));
+// magnitude_k = sum_v (beta + n_kv) and tokensPerTopic for the Ks columns of `cnt`
+int launch_magnitude_on(ggs_handle *h, const int32_t *cnt, int32_t pitch, int32_t Ks, double *mag, int32_t *n_k) {
+  if (Ks <= 0) return GGS_OK;
+  HIP_TRY(h, hipMemsetAsync(n_k, 0, sizeof(int32_t) * (size_t)Ks, h->stream));
   if (h->exact_sum) {
-    launch_column_sum<int32_t, true>(h, h->d_n_wk, h->K, h->d_mag, h->d_n_k);   // tokensPerTopic falls out of the first pass
+    launch_column_sum<int32_t, true>(h, cnt, pitch, Ks, mag, n_k);   // tokensPerTopic falls out of the first pass
   } else {
-    launch_column_sum<int32_t, true>(h, h->d_n_wk, h->K, h->d_mag);
-    hipLaunchKernelGGL(topic_totals_kernel, dim3(grid_for((int64_t)h->K * h->V, 256, 16)), dim3(256), (size_t)h->K * sizeof(int32_t), h->stream, h->d_n_wk,
-                       h->K, h->V, h->d_n_k);
+    launch_column_sum<int32_t, true>(h, cnt, pitch, Ks, mag);
+    hipLaunchKernelGGL(topic_totals_kernel, dim3(grid_for((int64_t)Ks * h->V, 256, 16)), dim3(256), (size_t)Ks * sizeof(int32_t), h->stream, cnt,
+                       Ks, pitch, h->V, n_k);
   }
   HIP_TRY(h, hipGetLastError());
   return GGS_OK;
 }
 
-// Phi draw: initial (K8) or per sweep (K6).  Always refreshes n_k.
-int launch_phi(ggs_handle *h, bool initial, bool accumulate_mean) {
-  const int K = h->K, V = h->V;
-  int rc = launch_magnitude(h);
+// One collective of the attached exchange, on the handle's stream.
+int xcall(ggs_handle *h, int rc, const char *what) {
+  if (!rc) return GGS_OK;
+  return set_err(h, GGS_ERR_HIP, std::string("exchange ") + what + " failed" + (h->xg->err.empty() ? "" : ": " + h->xg->err));
+}
+int exchange_reduce_scatter(ggs_handle *h) {
+  if (h->cnt_own_valid) return GGS_OK;
+  int rc = xcall(h, h->xg->ops.reduce_scatter_i32(h->xg->ops.ctx, h->d_cnt_send, h->d_cnt_own, (int64_t)h->V * h->Ksm, h->stream), "reduce_scatter_i32");
+  if (!rc) h->cnt_own_valid = true;
+  return rc;
+}
+
+// Corpus-wide counts in d_n_wk: with an exchange, gathered from the ranks' slices on demand (a COLLECTIVE call).
+int ensure_global_counts(ggs_handle *h) {
+  if (!h->xg || h->counts_global) return GGS_OK;
+  int rc;
+  if ((rc = exchange_reduce_scatter(h))) return rc;
+  const size_t cells = (size_t)h->xg->nranks * h->V * h->Ksm;
+  if (!h->d_cnt_all && (rc = dev_alloc(h, &h->d_cnt_all, cells))) return rc;
+  if ((rc = xcall(h, h->xg->ops.all_gather_i32(h->xg->ops.ctx, h->d_cnt_own, h->d_cnt_all, (int64_t)h->V * h->Ksm, h->stream), "all_gather_i32"))) return rc;
+  hipLaunchKernelGGL(counts_unslice_kernel, dim3(grid_for((int64_t)h->K * h->V, 256)), dim3(256), 0, h->stream, h->d_cnt_all, h->d_koff, h->Ksm, h->d_n_wk,
+                     h->K, h->V);
+  HIP_TRY(h, hipGetLastError());
+  h->counts_global = true; h->n_k_valid = false;
+  return GGS_OK;
+}
+
+// tokensPerTopic (and the Dirichlet magnitudes) of the corpus-wide counts
+int launch_magnitude(ggs_handle *h) {
+  int rc = ensure_global_counts(h);
+  if (rc) return rc;
+  if (h->n_k_valid) return GGS_OK;
+  if ((rc = launch_magnitude_on(h, h->d_n_wk, h->K, h->K, h->d_mag, h->d_n_k))) return rc;
+  h->n_k_valid = true;
+  return GGS_OK;
+}
+
+// Phi draw: initial (K8) or per sweep (K6) for the topics [k0, k0 + Ks) from their corpus-wide counts
+// cnt [V][cnt_pitch]; normalised rows into out [V][out_pitch].
+int launch_phi_slice(ggs_handle *h, bool initial, const int32_t *cnt, int32_t cnt_pitch, int32_t Ks, int32_t k0, double *out, int32_t out_pitch,
+                     double *mag, double *tot, int32_t *n_k, double *phi_mean) {
+  if (Ks <= 0) return GGS_OK;
+  const int V = h->V;
+  int rc = launch_magnitude_on(h, cnt, cnt_pitch, Ks, mag, n_k);
   if (rc) return rc;
   PhiGammaParams gp{};
-  gp.n_wk = h->d_n_wk; gp.mag = h->d_mag; gp.phiT = h->d_phiT; gp.status = h->d_status;
+  gp.n_wk = cnt; gp.mag = mag; gp.phiT = out; gp.status = h->d_status;
   gp.seed = h->seed; gp.iteration = (uint32_t)h->iteration;
   gp.purpose = initial ? GGS_PURPOSE_INIT_PHI : GGS_PURPOSE_PHI;
-  gp.K = K; gp.Kp = h->Kp; gp.V = V; gp.beta = h->beta;
+  gp.K = Ks; gp.Kp = out_pitch; gp.V = V; gp.cnt_pitch = cnt_pitch; gp.k0 = k0; gp.beta = h->beta;
   // Dirichlet(int size, double beta): magnitude = V*beta, partition = 1.0/V
   gp.prior_pm = (1.0 / (double)V) * ((double)V * h->beta);
   gp.initial = initial ? 1 : 0;
-  const int64_t kv = (int64_t)K * V;
+  const int64_t kv = (int64_t)Ks * V;
   hipLaunchKernelGGL(phi_gamma_kernel, dim3(grid_for(kv, 256, 2)), dim3(256), 0, h->stream, gp);
-  launch_column_sum<double, false>(h, h->d_phiT, h->Kp, h->d_tot);
-  hipLaunchKernelGGL(phi_normalise_kernel, dim3(grid_for(kv, 256, 2)), dim3(256), 0, h->stream, h->d_phiT, h->d_tot, K, h->Kp, V,
-                     accumulate_mean ? h->d_phi_mean : nullptr);
+  launch_column_sum<double, false>(h, out, out_pitch, Ks, tot);
+  hipLaunchKernelGGL(phi_normalise_kernel, dim3(grid_for(kv, 256, 2)), dim3(256), 0, h->stream, out, tot, Ks, out_pitch, V, phi_mean);
   HIP_TRY(h, hipGetLastError());
+  return GGS_OK;
+}
+
+// The three steps of the Phi phase with an exchange attached (ggs_group_sweep issues each step for all handles of a
+// one-process group inside ncclGroupStart/End; one handle per process runs them back to back):
+//   A  reduce-scatter of the counts by topic slice
+//   B  this rank's slice: magnitudes, gammas, normalisers; then the all-gather of the fp64 slices
+//   C  repack [nranks][V][Ksm] -> phiT [V][Kp] (+ the running phi mean)
+int phi_step_a(ggs_handle *h, Events *E) {
+  int rc = exchange_reduce_scatter(h);
+  if (rc) return rc;
+  if (E) HIP_TRY(h, hipEventRecord(E->x[0], h->stream));
+  return GGS_OK;
+}
+int phi_step_b_compute(ggs_handle *h, bool initial, Events *E) {
+  int rc = launch_phi_slice(h, initial, h->d_cnt_own, h->Ksm, h->Ks, h->k0, h->d_phi_own, h->Ksm, h->d_mag_own, h->d_tot_own, h->d_n_k_own, nullptr);
+  if (rc) return rc;
+  if (E) HIP_TRY(h, hipEventRecord(E->x[1], h->stream));
+  return GGS_OK;
+}
+int phi_step_b_gather(ggs_handle *h, Events *E) {
+  int rc = xcall(h, h->xg->ops.all_gather_f64(h->xg->ops.ctx, h->d_phi_own, h->d_phi_all, (int64_t)h->V * h->Ksm, h->stream), "all_gather_f64");
+  if (rc) return rc;
+  if (E) HIP_TRY(h, hipEventRecord(E->x[2], h->stream));
+  return GGS_OK;
+}
+int phi_step_c(ggs_handle *h, bool accumulate_mean) {
+  hipLaunchKernelGGL(phi_unslice_kernel, dim3(grid_for((int64_t)h->K * h->V, 256, 2)), dim3(256), 0, h->stream, h->d_phi_all, h->d_koff, h->Ksm, h->d_phiT,
+                     h->K, h->Kp, h->V, accumulate_mean ? h->d_phi_mean : nullptr);
+  HIP_TRY(h, hipGetLastError());
+  h->have_phi = true;
+  return GGS_OK;
+}
+
+// Phi draw: initial (K8) or per sweep (K6).  One GPU: the whole matrix in place (and tokensPerTopic refreshed);
+// with an exchange: steps A, B, C above.
+int launch_phi(ggs_handle *h, bool initial, bool accumulate_mean, Events *E = nullptr) {
+  int rc;
+  if (h->xg) {
+    if ((rc = phi_step_a(h, E)) || (rc = phi_step_b_compute(h, initial, E)) || (rc = phi_step_b_gather(h, E))) return rc;
+    return phi_step_c(h, accumulate_mean);
+  }
+  if ((rc = launch_phi_slice(h, initial, h->d_n_wk, h->K, h->K, 0, h->d_phiT, h->Kp, h->d_mag, h->d_tot, h->d_n_k, accumulate_mean ? h->d_phi_mean : nullptr)))
+    return rc;
+  h->n_k_valid = true;
   h->have_phi = true;
   return GGS_OK;
 }
@@ -380,7 +486,14 @@ int settle_sweeps(ggs_handle *h) {
     h->tm.theta_ms += ms;
     HIP_TRY(h, hipEventElapsedTime(&ms, E.e[1], E.e[2])); h->tm.z_ms += ms;
     HIP_TRY(h, hipEventElapsedTime(&ms, E.e[2], E.e[3])); h->tm.merge_ms += ms;
-    HIP_TRY(h, hipEventElapsedTime(&ms, E.e[4], E.e[5])); h->tm.phi_ms += ms;
+    if (E.exchanged) {   // reduce-scatter | slice draw | all-gather | repack
+      HIP_TRY(h, hipEventElapsedTime(&ms, E.e[4], E.x[0])); h->tm.exchange_ms += ms;
+      HIP_TRY(h, hipEventElapsedTime(&ms, E.x[0], E.x[1])); h->tm.phi_ms += ms;
+      HIP_TRY(h, hipEventElapsedTime(&ms, E.x[1], E.x[2])); h->tm.exchange_ms += ms;
+      HIP_TRY(h, hipEventElapsedTime(&ms, E.x[2], E.e[5])); h->tm.phi_ms += ms;
+    } else {
+      HIP_TRY(h, hipEventElapsedTime(&ms, E.e[4], E.e[5])); h->tm.phi_ms += ms;
+    }
     h->tm.sweeps += 1;
     h->tm.tokens_sampled += h->N;
   }
@@ -454,23 +567,83 @@ int z_phase(ggs_handle *h) {
 // `settle` = wait for the device, raise what the sweeps flagged and add their phase times to the timings.  A batch
 // (ggs_sweep with n_sweeps > 1) settles once, after its last sweep: the device flags are sticky, and the ~40 us host
 // round trip per sweep is 2 % of a 1.9 ms sweep.
-int finish_sweep(ggs_handle *h, bool with_phi, bool settle = true) {
+int finish_sweep_enqueue(ggs_handle *h, bool with_phi) {
   int rc;
   Events &E = h->evs[h->ev_head];
   HIP_TRY(h, hipEventRecord(E.e[4], h->stream));
   bool acc = false;
+  E.exchanged = false;
   if (with_phi) {
     acc = (h->flags & GGS_FLAG_SAVE_PHI_MEAN) && sample_phi_this_iteration(h);
-    if ((rc = launch_phi(h, false, acc))) return rc;
+    E.exchanged = h->xg != nullptr;
+    if ((rc = launch_phi(h, false, acc, &E))) return rc;
   }
   HIP_TRY(h, hipEventRecord(E.e[5], h->stream));
   if (acc) h->n_sampled_phi++;             // GGS:168-170
   h->ev_pending += 1;
-  if (!settle && !(h->flags & GGS_FLAG_PARANOID)) return GGS_OK;
+  return GGS_OK;
+}
+int finish_sweep_settle(ggs_handle *h) {
+  int rc;
   if ((rc = check_status(h))) return rc;   // synchronises the stream
   if ((rc = settle_sweeps(h))) return rc;
   if (h->flags & GGS_FLAG_PARANOID) return ggs_check_invariants(h);
   return GGS_OK;
+}
+int finish_sweep(ggs_handle *h, bool with_phi, bool settle = true) {
+  int rc = finish_sweep_enqueue(h, with_phi);
+  if (rc) return rc;
+  if (!settle && !(h->flags & GGS_FLAG_PARANOID)) return GGS_OK;
+  return finish_sweep_settle(h);
+}
+
+// Buffers and the column map of an attached exchange; the handle moves to a stream of its own.
+int setup_exchange(ggs_handle *h, Exchange *x) {
+  int rc = bind_device(h);
+  if (rc) { delete x; return rc; }
+  if (h->xg) { delete x; return set_err(h, GGS_ERR_STATE, "an exchange is already attached"); }
+  if (h->have_corpus) { delete x; return set_err(h, GGS_ERR_STATE, "attach the exchange before ggs_set_corpus"); }
+  if (x->nranks < 1 || x->rank < 0 || x->rank >= x->nranks) { delete x; return set_err(h, GGS_ERR_BAD_ARG, "rank outside [0, nranks)"); }
+  const std::vector<int32_t> sl = topic_slices(h->K, x->nranks);
+  h->xg = x;
+  h->k0 = sl[(size_t)x->rank]; h->Ks = sl[(size_t)x->rank + 1] - h->k0; h->Ksm = (h->K + x->nranks - 1) / x->nranks;
+  std::vector<int64_t> koff((size_t)h->K);
+  for (int32_t r = 0; r < x->nranks; ++r)
+    for (int32_t k = sl[(size_t)r]; k < sl[(size_t)r + 1]; ++k) koff[(size_t)k] = (int64_t)r * h->V * h->Ksm + (k - sl[(size_t)r]);
+  const size_t slice = (size_t)h->V * h->Ksm, all = slice * (size_t)x->nranks;
+  if ((rc = dev_alloc(h, &h->d_koff, (size_t)h->K)) || (rc = dev_alloc(h, &h->d_cnt_send, all)) || (rc = dev_alloc(h, &h->d_cnt_own, slice)) ||
+      (rc = dev_alloc(h, &h->d_phi_own, slice)) || (rc = dev_alloc(h, &h->d_phi_all, all)) || (rc = dev_alloc(h, &h->d_mag_own, (size_t)h->Ksm)) ||
+      (rc = dev_alloc(h, &h->d_tot_own, (size_t)h->Ksm)) || (rc = dev_alloc(h, &h->d_n_k_own, (size_t)h->Ksm)))
+    return rc;
+  HIP_TRY(h, hipMemcpy(h->d_koff, koff.data(), sizeof(int64_t) * koff.size(), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemset(h->d_cnt_send, 0, all * sizeof(int32_t)));
+  HIP_TRY(h, hipMemset(h->d_cnt_own, 0, slice * sizeof(int32_t)));
+  HIP_TRY(h, hipMemset(h->d_phi_own, 0, slice * sizeof(double)));
+  HIP_TRY(h, hipMemset(h->d_phi_all, 0, all * sizeof(double)));
+  if (!h->stream) {
+    // collectives are ordered by THIS stream alone: not the legacy default stream, whose implicit synchronisation with
+    // other libraries' blocking streams is exactly the convention not to rely on
+    HIP_TRY(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    h->stream = h->own_stream;
+  }
+  HIP_TRY(h, hipDeviceSynchronize());
+  h->counts_global = false; h->cnt_own_valid = false; h->n_k_valid = false;
+  return GGS_OK;
+}
+
+Exchange *new_rccl_exchange(ggs_handle *h, int32_t rank, int32_t nranks, int *rc) {
+  std::string err;
+  RcclApi *api = RcclApi::get(err);
+  if (!api) { *rc = set_err(h, GGS_ERR_UNSUPPORTED, err); return nullptr; }
+  auto *x = new (std::nothrow) Exchange();
+  if (!x) { *rc = GGS_ERR_HIP; return nullptr; }
+  x->rank = rank; x->nranks = nranks; x->api = api;
+  x->ops.struct_size = (int32_t)sizeof(ggs_exchange_ops); x->ops.ctx = x;
+  x->ops.reduce_scatter_i32 = xops::rccl_reduce_scatter_i32;
+  x->ops.all_gather_f64 = xops::rccl_all_gather_f64;
+  x->ops.all_gather_i32 = xops::rccl_all_gather_i32;
+  *rc = GGS_OK;
+  return x;
 }
 
 }  // namespace
@@ -491,6 +664,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
   ggs_handle *h = new (std::nothrow) ggs_handle();
   if (!h) return GGS_ERR_HIP;
   h->K = cfg->num_topics; h->V = cfg->num_types; h->device = cfg->device_id;
+  h->Ks = h->Ksm = h->K; h->k0 = 0;
   h->Kp = (h->K + 1) & ~1;
   h->pitch16 = (h->Kp / 2) | 1;             // odd number of 16-byte units per LDS row
   h->beta = cfg->beta; h->seed = cfg->seed; h->flags = cfg->flags;
@@ -584,11 +758,13 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
   const void *zk[] = {reinterpret_cast<const void *>(z_kernel<1>), reinterpret_cast<const void *>(z_kernel<2>),
                       reinterpret_cast<const void *>(z_kernel<4>), reinterpret_cast<const void *>(z_kernel<8>),
                       reinterpret_cast<const void *>(z_kernel<16>), reinterpret_cast<const void *>(z_kernel<20>)};
-  if (h->z_stream && hipFuncSetAttribute(reinterpret_cast<const void *>(z_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, h->z_lds) != hipSuccess)
+  // The attribute is process-global per kernel, not per handle: always the hardware maximum, so that a later handle
+  // with a smaller K never lowers the cap under a live one.
+  if (h->z_stream && hipFuncSetAttribute(reinterpret_cast<const void *>(z_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess)
     return bail(GGS_ERR_HIP);
   for (const void *f : zk)
-    if (!h->z_sliced && !h->z_stream &&hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, h->z_lds) != hipSuccess) return bail(GGS_ERR_HIP);
-  if (hipFuncSetAttribute(reinterpret_cast<const void *>(theta_kernel<kThetaBlock>), hipFuncAttributeMaxDynamicSharedMemorySize, h->theta_lds) != hipSuccess)
+    if (!h->z_sliced && !h->z_stream && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess) return bail(GGS_ERR_HIP);
+  if (hipFuncSetAttribute(reinterpret_cast<const void *>(theta_kernel<kThetaBlock>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess)
     return bail(GGS_ERR_HIP);
   const size_t kv = (size_t)h->K * h->V;
   if ((rc = dev_alloc(h, &h->d_alpha, h->K)) || (rc = dev_alloc(h, &h->d_phiT, (size_t)h->V * h->Kp + kPhiTailPadBytes / 8)) ||
@@ -621,11 +797,13 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     if (h->pcgs_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);
     h->pcgs_waves_per_cu = std::max(1, std::min(8, kMaxLdsBytes / ((h->pcgs_lds + 2047) / 2048 * 2048)));
     if (hipFuncSetAttribute(h->pcgs_sliced ? pcgs_kernel_for(h->K) : reinterpret_cast<const void *>(pcgs_z_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            h->pcgs_lds) != hipSuccess)
+                            kMaxLdsBytes) != hipSuccess)
       return bail(GGS_ERR_HIP);
   }
   for (auto &E : h->evs) {
     for (auto &e : E.e)
+      if (hipEventCreate(&e) != hipSuccess) return bail(GGS_ERR_HIP);
+    for (auto &e : E.x)
       if (hipEventCreate(&e) != hipSuccess) return bail(GGS_ERR_HIP);
     if (hipEventCreate(&E.th0) != hipSuccess || hipEventCreate(&E.th1) != hipSuccess) return bail(GGS_ERR_HIP);
   }
@@ -641,6 +819,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
         hipEventCreate(&h->ev_hot_join) != hipSuccess)
       return bail(GGS_ERR_HIP);
   }
+  if (hipDeviceSynchronize() != hipSuccess) return bail(GGS_ERR_HIP);   // the memsets above ran on the null stream
   *out = h;
   return GGS_OK;
 }
@@ -652,11 +831,19 @@ void ggs_destroy(ggs_handle *h) {
   void *bufs[] = {h->d_doc_ptr, h->d_chunk_start, h->d_tok, h->d_z, h->d_chunk_doc, h->d_chunk_len, h->d_alpha, h->d_theta, h->d_theta_next,
                   h->d_phiT, h->d_mag, h->d_tot, h->d_phi_mean, h->d_n_wk, h->d_n_k, h->d_perm, h->d_inv_perm, h->d_zw, h->d_seg_word, h->d_seg_begin,
                   h->d_status, h->d_scratch, h->d_sum_pref, h->d_sum_fn, h->d_ct_tok, h->d_ct_idx, h->d_ct_ip, h->d_c_docs, h->d_hot_words, h->d_order,
-                  h->d_test_ptr, h->d_test_tok, h->d_test_ll, h->d_test_docs};
+                  h->d_test_ptr, h->d_test_tok, h->d_test_ll, h->d_test_docs, h->d_koff, h->d_cnt_send, h->d_cnt_own, h->d_cnt_all, h->d_n_k_own,
+                  h->d_phi_own, h->d_phi_all, h->d_mag_own, h->d_tot_own};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
+  if (h->xg) {
+    if (h->xg->own_comm && h->xg->comm && h->xg->api) (void)h->xg->api->CommDestroy(h->xg->comm);
+    delete h->xg;
+  }
+  if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   for (auto &E : h->evs) {
     for (auto &e : E.e)
+      if (e) (void)hipEventDestroy(e);
+    for (auto &e : E.x)
       if (e) (void)hipEventDestroy(e);
     if (E.th0) (void)hipEventDestroy(E.th0);
     if (E.th1) (void)hipEventDestroy(E.th1);
@@ -674,6 +861,7 @@ int ggs_set_stream(ggs_handle *h, void *hip_stream) {
   if (rc) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   if ((rc = drop_theta_ahead(h))) return rc;
+  if (h->xg && !hip_stream) return set_err(h, GGS_ERR_BAD_ARG, "with an exchange attached the handle does not run on the legacy default stream");
   h->stream = reinterpret_cast<hipStream_t>(hip_stream);
   return GGS_OK;
 }
@@ -832,8 +1020,10 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
     HIP_TRY(h, hipMemcpy(h->d_chunk_doc, cdoc.data(), sizeof(int32_t) * cdoc.size(), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_chunk_len, clen.data(), sizeof(int32_t) * clen.size(), hipMemcpyHostToDevice));
   }
+  HIP_TRY(h, hipDeviceSynchronize());   // the uploads and memsets above ran on the null stream; the handle's stream may not synchronise with it
   h->have_corpus = true; h->have_phi = false; h->in_sweep = false; h->global_tokens = -1;
   h->z_split = h->z_split_allowed; h->z_split_tried = false;
+  h->counts_global = h->xg == nullptr; h->cnt_own_valid = false; h->n_k_valid = false;
   return GGS_OK;
 }
 
@@ -870,7 +1060,7 @@ int ggs_set_z(ggs_handle *h, const int32_t *z, int32_t redraw_phi) {
 int ggs_init_phi(ggs_handle *h) {
   int rc = require_ready(h, false);
   if (rc) return rc;
-  if ((rc = launch_phi(h, true, false))) return rc;
+  if ((rc = launch_phi(h, true, false))) return rc;   // with an exchange: the start-up count reduce-scatter, the slice, the all-gather
   return check_status(h);
 }
 
@@ -922,7 +1112,7 @@ int ggs_sample_z_given_phi(ggs_handle *h, int32_t n_sweeps) {
     if ((rc = z_phase(h))) return rc;
     if ((rc = finish_sweep(h, false))) return rc;
   }
-  // tokensPerTopic follows the rebuilt counts
+  // tokensPerTopic follows the rebuilt counts (with an exchange: the counts are merged here, UPLDA:993)
   if ((rc = launch_magnitude(h))) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   return GGS_OK;
@@ -930,13 +1120,209 @@ int ggs_sample_z_given_phi(ggs_handle *h, int32_t n_sweeps) {
 
 int ggs_counts_device_ptr(ggs_handle *h, void **dev_ptr, int64_t *num_elems) {
   if (!h || !dev_ptr || !num_elems) return GGS_ERR_BAD_ARG;
+  if (h->xg) return set_err(h, GGS_ERR_STATE, "an exchange is attached: the library merges the counts itself");
   *dev_ptr = h->d_n_wk; *num_elems = (int64_t)h->K * h->V;
+  h->n_k_valid = false;          // the caller may sum other shards' counts into the buffer
   return GGS_OK;
 }
 
 int ggs_set_global_token_count(ggs_handle *h, int64_t n_tokens) {
   if (!h || n_tokens < 0) return GGS_ERR_BAD_ARG;
   h->global_tokens = n_tokens;
+  return GGS_OK;
+}
+
+// ---- multi-GPU: the exchange (include/ggs_hip.h) ------------------------------------------------------------------
+int ggs_attach_exchange(ggs_handle *h, int32_t rank, int32_t nranks, const ggs_exchange_ops *ops) {
+  if (!h) return GGS_ERR_BAD_ARG;
+  if (!ops || ops->struct_size != (int32_t)sizeof(ggs_exchange_ops) || !ops->reduce_scatter_i32 || !ops->all_gather_f64 || !ops->all_gather_i32)
+    return set_err(h, GGS_ERR_BAD_ARG, "ggs_exchange_ops: wrong struct_size or a null callback");
+  auto *x = new (std::nothrow) Exchange();
+  if (!x) return GGS_ERR_HIP;
+  x->rank = rank; x->nranks = nranks; x->ops = *ops;
+  return setup_exchange(h, x);
+}
+
+int ggs_attach_null_exchange(ggs_handle *h, int32_t rank, int32_t nranks) {
+  if (!h) return GGS_ERR_BAD_ARG;
+  auto *x = new (std::nothrow) Exchange();
+  if (!x) return GGS_ERR_HIP;
+  x->rank = rank; x->nranks = nranks;
+  x->ops.struct_size = (int32_t)sizeof(ggs_exchange_ops); x->ops.ctx = x;
+  x->ops.reduce_scatter_i32 = xops::null_reduce_scatter_i32;
+  x->ops.all_gather_f64 = xops::null_all_gather<double>;
+  x->ops.all_gather_i32 = xops::null_all_gather<int32_t>;
+  return setup_exchange(h, x);
+}
+
+int ggs_rccl_unique_id(void *out_id) {
+  if (!out_id) return GGS_ERR_BAD_ARG;
+  std::string err;
+  RcclApi *api = RcclApi::get(err);
+  if (!api) return GGS_ERR_UNSUPPORTED;
+  static_assert(sizeof(ncclUniqueId) == GGS_RCCL_UNIQUE_ID_BYTES, "ncclUniqueId size");
+  ncclUniqueId id;
+  if (api->GetUniqueId(&id) != ncclSuccess) return GGS_ERR_HIP;
+  std::memcpy(out_id, &id, sizeof id);
+  return GGS_OK;
+}
+
+int ggs_attach_rccl(ggs_handle *h, int32_t rank, int32_t nranks, const void *unique_id) {
+  if (!h) return GGS_ERR_BAD_ARG;
+  if (!unique_id || nranks < 1 || rank < 0 || rank >= nranks) return set_err(h, GGS_ERR_BAD_ARG, "bad rank / nranks / unique id");
+  if (h->xg) return set_err(h, GGS_ERR_STATE, "an exchange is already attached");
+  int rc = bind_device(h);
+  if (rc) return rc;
+  Exchange *x = new_rccl_exchange(h, rank, nranks, &rc);
+  if (!x) return rc;
+  ncclUniqueId id;
+  std::memcpy(&id, unique_id, sizeof id);
+  const ncclResult_t r = x->api->CommInitRank(&x->comm, nranks, id, rank);      // collective: every rank of the job is in here
+  if (r != ncclSuccess) {
+    const std::string msg = std::string("ncclCommInitRank: ") + x->api->GetErrorString(r);
+    delete x;
+    return set_err(h, GGS_ERR_HIP, msg);
+  }
+  x->own_comm = true;
+  return setup_exchange(h, x);
+}
+
+int ggs_attach_rccl_comm(ggs_handle *h, int32_t rank, int32_t nranks, void *nccl_comm) {
+  if (!h) return GGS_ERR_BAD_ARG;
+  if (!nccl_comm || nranks < 1 || rank < 0 || rank >= nranks) return set_err(h, GGS_ERR_BAD_ARG, "bad rank / nranks / communicator");
+  if (h->xg) return set_err(h, GGS_ERR_STATE, "an exchange is already attached");
+  int rc = bind_device(h);
+  if (rc) return rc;
+  Exchange *x = new_rccl_exchange(h, rank, nranks, &rc);
+  if (!x) return rc;
+  x->comm = static_cast<ncclComm_t>(nccl_comm);
+  return setup_exchange(h, x);
+}
+
+int ggs_get_exchange_info(const ggs_handle *h, int32_t *rank, int32_t *nranks, int32_t *k_begin, int32_t *k_end) {
+  if (!h) return GGS_ERR_BAD_ARG;
+  if (rank) *rank = h->xg ? h->xg->rank : 0;
+  if (nranks) *nranks = h->xg ? h->xg->nranks : 1;
+  if (k_begin) *k_begin = h->k0;
+  if (k_end) *k_end = h->k0 + h->Ks;
+  return GGS_OK;
+}
+
+// ---- one process, n GPUs ----
+namespace {
+bool is_group(ggs_handle **hs, int32_t n) {
+  if (!hs || n < 1 || !hs[0] || (int32_t)hs[0]->group.size() != n) return false;
+  for (int32_t i = 0; i < n; ++i)
+    if (hs[i] != hs[0]->group[(size_t)i] || !hs[i]->xg || !hs[i]->xg->api) return false;
+  return true;
+}
+// the Phi phase for every handle of the group: each collective step for all devices inside ncclGroupStart/End
+int group_phi(ggs_handle **hs, int32_t n, bool initial, bool in_sweep) {
+  RcclApi *api = hs[0]->xg->api;
+  std::vector<char> acc((size_t)n, 0);
+  int rc = GGS_OK;
+  for (int32_t i = 0; i < n && !rc; ++i) {
+    ggs_handle *h = hs[i];
+    if ((rc = bind_device(h))) break;
+    if (in_sweep) {
+      Events &E = h->evs[h->ev_head];
+      if (hipEventRecord(E.e[4], h->stream) != hipSuccess) { rc = set_err(h, GGS_ERR_HIP, "hipEventRecord"); break; }
+      E.exchanged = true;
+      acc[(size_t)i] = (h->flags & GGS_FLAG_SAVE_PHI_MEAN) && sample_phi_this_iteration(h);
+    }
+  }
+  if (rc) return rc;
+  auto grouped = [&](auto step) {
+    int r = GGS_OK;
+    api->GroupStart();
+    for (int32_t i = 0; i < n && !r; ++i) {
+      ggs_handle *h = hs[i];
+      if ((r = bind_device(h))) break;
+      r = step(h, in_sweep ? &h->evs[h->ev_head] : nullptr);
+    }
+    if (api->GroupEnd() != ncclSuccess && !r) r = set_err(hs[0], GGS_ERR_HIP, "ncclGroupEnd failed");
+    return r;
+  };
+  if ((rc = grouped([](ggs_handle *h, Events *E) { return phi_step_a(h, E); }))) return rc;
+  for (int32_t i = 0; i < n; ++i) {
+    if ((rc = bind_device(hs[i])) || (rc = phi_step_b_compute(hs[i], initial, in_sweep ? &hs[i]->evs[hs[i]->ev_head] : nullptr))) return rc;
+  }
+  if ((rc = grouped([](ggs_handle *h, Events *E) { return phi_step_b_gather(h, E); }))) return rc;
+  for (int32_t i = 0; i < n; ++i) {
+    ggs_handle *h = hs[i];
+    if ((rc = bind_device(h)) || (rc = phi_step_c(h, acc[(size_t)i] != 0))) return rc;
+    if (in_sweep) {
+      HIP_TRY(h, hipEventRecord(h->evs[h->ev_head].e[5], h->stream));
+      if (acc[(size_t)i]) h->n_sampled_phi++;
+      h->ev_pending += 1;
+    }
+  }
+  return GGS_OK;
+}
+}  // namespace
+
+int ggs_group_create(const ggs_config *cfg, int32_t n, const int32_t *device_ids, ggs_handle **out) {
+  if (!cfg || n < 1 || !device_ids || !out) return GGS_ERR_BAD_ARG;
+  for (int32_t i = 0; i < n; ++i) out[i] = nullptr;
+  std::string err;
+  RcclApi *api = RcclApi::get(err);
+  if (!api) return GGS_ERR_UNSUPPORTED;
+  int rc = GGS_OK;
+  for (int32_t i = 0; i < n && !rc; ++i) {
+    ggs_config c = *cfg;
+    c.device_id = device_ids[i];
+    rc = ggs_create(&c, &out[i]);
+  }
+  std::vector<ncclComm_t> comms((size_t)n, nullptr);
+  if (!rc && api->CommInitAll(comms.data(), n, device_ids) != ncclSuccess) rc = GGS_ERR_HIP;
+  for (int32_t i = 0; i < n && !rc; ++i) {
+    Exchange *x = new_rccl_exchange(out[i], i, n, &rc);
+    if (!x) break;
+    x->comm = comms[(size_t)i]; x->own_comm = true; comms[(size_t)i] = nullptr;
+    rc = setup_exchange(out[i], x);
+  }
+  if (rc) {
+    for (ncclComm_t c : comms) if (c) (void)api->CommDestroy(c);
+    for (int32_t i = 0; i < n; ++i) { ggs_destroy(out[i]); out[i] = nullptr; }
+    return rc;
+  }
+  out[0]->group.assign(out, out + n);
+  return GGS_OK;
+}
+
+void ggs_group_destroy(ggs_handle **handles, int32_t n) {
+  if (!handles) return;
+  for (int32_t i = 0; i < n; ++i) { ggs_destroy(handles[i]); handles[i] = nullptr; }
+}
+
+int ggs_group_set_z(ggs_handle **hs, int32_t n, const int32_t *const *z, int32_t redraw_phi) {
+  if (!is_group(hs, n) || !z) return GGS_ERR_BAD_ARG;
+  int rc;
+  for (int32_t i = 0; i < n; ++i)
+    if ((rc = ggs_set_z(hs[i], z[i], 0))) return rc;          // this shard's counts
+  if (!redraw_phi) return GGS_OK;
+  if ((rc = group_phi(hs, n, true, false))) return rc;
+  for (int32_t i = 0; i < n; ++i)
+    if ((rc = bind_device(hs[i])) || (rc = check_status(hs[i]))) return rc;
+  return GGS_OK;
+}
+
+int ggs_group_sweep(ggs_handle **hs, int32_t n, int32_t n_sweeps) {
+  if (!is_group(hs, n)) return GGS_ERR_BAD_ARG;
+  int rc;
+  for (int32_t s = 0; s < n_sweeps; ++s) {
+    for (int32_t i = 0; i < n; ++i) {
+      ggs_handle *h = hs[i];
+      if ((rc = require_ready(h, true))) return rc;
+      if (h->in_sweep) return set_err(h, GGS_ERR_STATE, "inside a split sweep");
+      h->iteration += 1;
+      if ((rc = z_phase(h))) return rc;
+    }
+    if ((rc = group_phi(hs, n, false, true))) return rc;
+    if (s == n_sweeps - 1 || (hs[0]->flags & GGS_FLAG_PARANOID))
+      for (int32_t i = 0; i < n; ++i)
+        if ((rc = bind_device(hs[i])) || (rc = check_status(hs[i])) || (rc = settle_sweeps(hs[i]))) return rc;
+  }
   return GGS_OK;
 }
 
@@ -964,13 +1350,15 @@ int ggs_get_type_topic_counts(ggs_handle *h, int32_t *n_wk) {
   if (!h || !n_wk) return GGS_ERR_BAD_ARG;
   int rc = bind_device(h);
   if (rc) return rc;
+  if ((rc = ensure_global_counts(h))) return rc;
   return copy_out(h, n_wk, h->d_n_wk, sizeof(int32_t) * (size_t)h->K * h->V);
 }
 int ggs_get_topic_totals(ggs_handle *h, int32_t *n_k) {
   if (!h || !n_k) return GGS_ERR_BAD_ARG;
   int rc = bind_device(h);
   if (rc) return rc;
-  // n_k is refreshed by every Phi draw; recompute here so the getter is valid right after set_z(redraw=0)
+  // valid whatever came last: a sweep, ggs_set_z(redraw=0), an external all-reduce on ggs_counts_device_ptr
+  h->n_k_valid = h->n_k_valid && h->xg != nullptr;
   if ((rc = launch_magnitude(h))) return rc;
   return copy_out(h, n_k, h->d_n_k, sizeof(int32_t) * (size_t)h->K);
 }
@@ -1036,6 +1424,7 @@ int ggs_model_log_likelihood(ggs_handle *h, double *doc_side, double *topic_side
   int rc = require_ready(h, false);
   if (rc) return rc;
   if (!doc_side || !topic_side) return set_err(h, GGS_ERR_BAD_ARG, "null output");
+  if ((rc = launch_magnitude(h))) return rc;       // corpus-wide counts gathered, tokensPerTopic in step with them
   const int K = h->K;
   const int64_t doc_blocks = (h->D + kLLBlock / 64 - 1) / (kLLBlock / 64), type_blocks = 1024;
   const size_t bytes = 32 + sizeof(double) * (size_t)(doc_blocks + type_blocks);
@@ -1115,6 +1504,7 @@ int ggs_heldout_log_likelihood(ggs_handle *h, int32_t num_particles, double *doc
   if (rc) return rc;
   if (!h->have_test) return set_err(h, GGS_ERR_STATE, "no test set: call ggs_set_test_corpus first");
   if (num_particles < 1 || !total) return set_err(h, GGS_ERR_BAD_ARG, "num_particles < 1 or null output");
+  if ((rc = launch_magnitude(h))) return rc;       // corpus-wide counts gathered, tokensPerTopic in step with them
   const int K = h->K;
   const int64_t D = (int64_t)h->test_ptr.size() - 1;
   // LDS: alpha, the denominators and the coefficient table once per block; per wave the word's cell list and 1 or 2 bytes
@@ -1146,11 +1536,9 @@ int ggs_heldout_log_likelihood(ggs_handle *h, int32_t num_particles, double *doc
     return set_err(h, GGS_ERR_UNSUPPORTED, "num_topics too large for the held-out estimator's per-particle counts in LDS "
                                            "(up to 1704 topics with test documents of at most 255 tokens, 1024 with longer ones)");
   if (shape8.waves)
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds_of(shape8.waves, 1, shape8.cap)));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
   if (shape16.waves)
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds_of(shape16.waves, 2, shape16.cap)));
+    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
   // wordProbabilities of a batch of documents: tokens x particles doubles, at most ~4 GiB at a time (one launch for
   // the 2 M-token test set of the benchmark: every extra launch has its own tail of half-empty CUs)
   int64_t want_cells = (int64_t)1 << 29;
@@ -1224,6 +1612,7 @@ int ggs_check_invariants(ggs_handle *h) {
   if (rc) return rc;
   const int K = h->K;
   const size_t bytes = 16 + sizeof(int32_t) * (size_t)K;
+  if ((rc = ensure_global_counts(h))) return rc;
   if ((rc = ensure_scratch(h, bytes))) return rc;
   auto *d_total = static_cast<unsigned long long *>(h->d_scratch);
   auto *d_flags = reinterpret_cast<uint32_t *>(static_cast<char *>(h->d_scratch) + 8);
@@ -1252,6 +1641,12 @@ int ggs_get_launch_info(ggs_handle *h, int64_t *num_chunks, int32_t *lds_bytes_z
   if (num_chunks) *num_chunks = h->z_sliced ? h->Cs : h->C;
   if (lds_bytes_z) *lds_bytes_z = h->z_lds;
   if (docs_per_block_theta) *docs_per_block_theta = h->theta_docs_per_block;
+  return GGS_OK;
+}
+
+int ggs_get_num_hot_words(ggs_handle *h, int32_t *num_hot) {
+  if (!h || !num_hot) return GGS_ERR_BAD_ARG;
+  *num_hot = (h->z_sliced && !(h->flags & GGS_FLAG_PCGS)) ? h->num_hot : 0;
   return GGS_OK;
 }
 
@@ -1323,8 +1718,8 @@ int ggs_debug_column_sum(int32_t device_id, int32_t V, int32_t K, const double *
   if (!tmp.d_sum_pref || !tmp.d_sum_fn || !dsrc || !dou) rc = GGS_ERR_HIP;
   else if (hipMemcpy(dsrc, x ? (const void *)x : (const void *)counts, kv * (x ? 8 : 4), hipMemcpyHostToDevice) != hipSuccess) rc = GGS_ERR_HIP;
   else {
-    if (x) launch_column_sum<double, false>(&tmp, static_cast<const double *>(dsrc), K, dou);
-    else launch_column_sum<int32_t, true>(&tmp, static_cast<const int32_t *>(dsrc), K, dou);
+    if (x) launch_column_sum<double, false>(&tmp, static_cast<const double *>(dsrc), K, K, dou);
+    else launch_column_sum<int32_t, true>(&tmp, static_cast<const int32_t *>(dsrc), K, K, dou);
     if (hipGetLastError() != hipSuccess || hipMemcpy(out, dou, (size_t)K * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = GGS_ERR_HIP;
   }
   tmp.d_sum_pref = nullptr; tmp.d_sum_fn = nullptr;   // owned by t

@@ -151,8 +151,10 @@ struct CountParams {
   const int32_t *zw;         // topic assignments in word-sorted order
   const int32_t *seg_word;   // [S]
   const int32_t *seg_begin;  // [S+1] offsets into zw
-  int32_t *n_wk;
-  int32_t K, num_segs;
+  int32_t *n_wk;             // cell (w, k) lives at n_wk[w * row_stride + (koff ? koff[k] : k)]
+  const int64_t *koff;       // null: the plain [V][K] layout.  With an exchange attached: the slice-major
+                             // [nranks][V][Ksm] send buffer of the count reduce-scatter, koff[k] = slice(k)*V*Ksm + (k - k0(slice))
+  int32_t K, num_segs, row_stride;
 };
 
 constexpr int kCountSegsPerBlock = 8;   // most words are rare: a workgroup per <= 256-token segment would be mostly dispatch overhead
@@ -164,9 +166,12 @@ __global__ __launch_bounds__(256) void count_sorted_kernel(CountParams p) {
   const int seg0 = blockIdx.x * kCountSegsPerBlock, seg1 = min(seg0 + kCountSegsPerBlock, p.num_segs);
   for (int seg = seg0; seg < seg1; ++seg) {
     const int beg = p.seg_begin[seg], end = p.seg_begin[seg + 1];
-    int32_t *row = p.n_wk + (size_t)p.seg_word[seg] * K;
+    int32_t *row = p.n_wk + (size_t)p.seg_word[seg] * p.row_stride;
     if (end - beg <= 256) {                    // uniform per block
-      if (beg + tid < end) atomicAdd(&row[p.zw[beg + tid]], 1);
+      if (beg + tid < end) {
+        const int k = p.zw[beg + tid];
+        atomicAdd(&row[p.koff ? p.koff[k] : (int64_t)k], 1);
+      }
       continue;
     }
     for (int k = tid; k < K; k += 256) hist[k] = 0;
@@ -180,7 +185,7 @@ __global__ __launch_bounds__(256) void count_sorted_kernel(CountParams p) {
     __syncthreads();
     for (int k = tid; k < K; k += 256) {
       const int32_t cnt = hist[k];
-      if (cnt) atomicAdd(&row[k], cnt);
+      if (cnt) atomicAdd(&row[p.koff ? p.koff[k] : (int64_t)k], cnt);
     }
     __syncthreads();                           // hist is reused by the next segment
   }
@@ -278,30 +283,36 @@ __global__ __launch_bounds__(256) void permute_z_kernel(const int32_t *perm, con
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) zw[i] = z[perm[i]];
 }
 
-// tokensPerTopic n_k = sum_v n_wk[v][k]: integers, any order.
-__global__ __launch_bounds__(256) void topic_totals_kernel(const int32_t *n_wk, int32_t K, int32_t V, int32_t *n_k) {
+// tokensPerTopic n_k = sum_v n_wk[v][k]: integers, any order (rows of `pitch` ints, the first K columns).
+__global__ __launch_bounds__(256) void topic_totals_kernel(const int32_t *n_wk, int32_t K, int32_t pitch, int32_t V, int32_t *n_k) {
   extern __shared__ __align__(16) unsigned char smem[];
   int32_t *part = reinterpret_cast<int32_t *>(smem);             // [K]
   for (int k = threadIdx.x; k < K; k += 256) part[k] = 0;
   __syncthreads();
   const int64_t n = (int64_t)V * K, stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) {
-    const int32_t c = n_wk[i];
-    if (c) atomicAdd(&part[(int)(i % K)], c);
+    const int v = (int)(i / K), k = (int)(i - (int64_t)v * K);
+    const int32_t c = n_wk[(size_t)v * pitch + k];
+    if (c) atomicAdd(&part[k], c);
   }
   __syncthreads();
   for (int k = threadIdx.x; k < K; k += 256)
     if (part[k]) atomicAdd(&n_k[k], part[k]);
 }
 
+// The Phi draw works on a TOPIC SLICE [k0, k0 + Ks): the whole matrix for one GPU (k0 = 0, Ks = K, counts [V][K],
+// output phiT [V][Kp]); with an exchange attached the rank's own topics (counts [V][Ksm] from the reduce-scatter,
+// output [V][Ksm] for the all-gather).  The Philox element id carries the GLOBAL topic, so a slice draws what the
+// one-GPU run draws for those topics.
 struct PhiGammaParams {
-  const int32_t *n_wk;
-  const double *mag;   // per topic (sweep draw) -- unused for the initial draw
-  double *phiT;
+  const int32_t *n_wk; // [V][cnt_pitch], column j = topic k0 + j
+  const double *mag;   // [Ks] per topic of the slice (sweep draw) -- unused for the initial draw
+  double *phiT;        // [V][Kp], column j = topic k0 + j
   uint32_t *status;
   uint64_t seed;
   uint32_t iteration, purpose;
-  int32_t K, Kp, V;
+  int32_t K, Kp, V;    // K = Ks: the slice width
+  int32_t cnt_pitch, k0;
   double beta;         // sweep draw: shape = ((beta+n)/mag)*mag
   double prior_pm;     // initial draw: partition*magnitude = (1.0/V)*(V*beta)
   int32_t initial;
@@ -312,7 +323,7 @@ __global__ __launch_bounds__(256) void phi_gamma_kernel(PhiGammaParams p) {
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const int v = (int)(i / p.K), k = (int)(i - (int64_t)v * p.K);
-    const int32_t cnt = p.n_wk[i];
+    const int32_t cnt = p.n_wk[(size_t)v * p.cnt_pitch + k];
     double shape;
     if (p.initial) {
       shape = (cnt == 0) ? p.prior_pm : p.prior_pm + (double)cnt;   // MarsagliaSparseDirichlet.java:37-41
@@ -323,7 +334,7 @@ __global__ __launch_bounds__(256) void phi_gamma_kernel(PhiGammaParams p) {
     }
     double g;
     if (shape > 0) {
-      DrawStream rs(p.seed, p.iteration, p.purpose, (uint64_t)k * (uint64_t)p.V + (uint64_t)v);
+      DrawStream rs(p.seed, p.iteration, p.purpose, (uint64_t)(p.k0 + k) * (uint64_t)p.V + (uint64_t)v);
       g = rgamma(rs, shape);
       if (rs.exhausted) atomicOr(p.status, ST_RNG_EXHAUSTED);
     } else {
@@ -348,6 +359,41 @@ __global__ __launch_bounds__(256) void phi_normalise_kernel(double *phiT, const 
       phiT[(size_t)v * Kp + k] = x;
     }
     if (phi_mean) phi_mean[i] += x;                                  // GGS:193-197
+  }
+}
+
+// ---- exchange layout <-> device layout (one GPU of several; see include/ggs_hip.h, "multi-GPU") ----
+// phi_all [nranks][V][Ksm] (the all-gathered slices) -> phiT [V][Kp]; the running phiMean += of GGS:193-197 rides along
+// (the value added is the normalised, clamped phi -- the same double the one-GPU normalise kernel adds).
+__global__ __launch_bounds__(256) void phi_unslice_kernel(const double *phi_all, const int64_t *koff, int32_t Ksm, double *phiT, int32_t K,
+                                                          int32_t Kp, int32_t V, double *phi_mean /* [V][K] or null */) {
+  const int64_t n = (int64_t)V * K;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int v = (int)(i / K), k = (int)(i - (int64_t)v * K);
+    const double x = phi_all[koff[k] + (int64_t)v * Ksm];
+    phiT[(size_t)v * Kp + k] = x;
+    if (phi_mean) phi_mean[i] += x;
+  }
+}
+// cnt_all [nranks][V][Ksm] (the all-gathered count slices) -> n_wk [V][K]
+__global__ __launch_bounds__(256) void counts_unslice_kernel(const int32_t *cnt_all, const int64_t *koff, int32_t Ksm, int32_t *n_wk, int32_t K,
+                                                             int32_t V) {
+  const int64_t n = (int64_t)V * K;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int v = (int)(i / K), k = (int)(i - (int64_t)v * K);
+    n_wk[i] = cnt_all[koff[k] + (int64_t)v * Ksm];
+  }
+}
+// n_wk [V][K] -> the slice-major send layout (ggs_set_type_topic_counts-style uploads; unused columns stay zero)
+__global__ __launch_bounds__(256) void counts_slice_kernel(const int32_t *n_wk, const int64_t *koff, int32_t Ksm, int32_t *cnt_send, int32_t K,
+                                                           int32_t V) {
+  const int64_t n = (int64_t)V * K;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int v = (int)(i / K), k = (int)(i - (int64_t)v * K);
+    cnt_send[koff[k] + (int64_t)v * Ksm] = n_wk[i];
   }
 }
 

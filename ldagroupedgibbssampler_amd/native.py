@@ -34,27 +34,48 @@ def _lp(a):
     return a.ctypes.data_as(C.POINTER(C.c_int64))
 
 
+def _make_config(num_topics, num_types, alpha, beta, seed, device_id, flags, phi_burn_in, phi_mean_thin):
+    """(ggs_config, the alpha array it points into -- keep it alive for the duration of the call)"""
+    cfg = _lib.GGSConfig()
+    cfg.struct_size = C.sizeof(_lib.GGSConfig)
+    cfg.num_topics, cfg.num_types, cfg.device_id = int(num_topics), int(num_types), int(device_id)
+    alpha = np.asarray(alpha, np.float64)
+    keep = None
+    if alpha.ndim == 0:
+        cfg.alpha = None
+        cfg.alpha_scalar = float(alpha)
+    else:
+        keep = np.ascontiguousarray(alpha)
+        if keep.size != int(num_topics):
+            raise ValueError("alpha must have num_topics entries")
+        cfg.alpha = _dp(keep)
+    cfg.beta = float(beta)
+    cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    cfg.flags, cfg.phi_burn_in, cfg.phi_mean_thin = int(flags), int(phi_burn_in), int(phi_mean_thin)
+    return cfg, keep
+
+
+def rccl_unique_id():
+    """128 bytes from ncclGetUniqueId (rank 0 creates it; every rank passes it to GGSHandle.attach_rccl)."""
+    _lib.share_rccl_with_torch()
+    buf = C.create_string_buffer(128)
+    rc = _lib.load().ggs_rccl_unique_id(C.cast(buf, C.c_void_p))
+    if rc:
+        raise GGSError(rc, "ggs_rccl_unique_id failed (librccl not loadable?)")
+    return buf.raw
+
+
 class GGSHandle:
-    def __init__(self, num_topics, num_types, alpha, beta, seed, device_id=0, flags=0, phi_burn_in=0, phi_mean_thin=1):
+    def __init__(self, num_topics, num_types, alpha, beta, seed, device_id=0, flags=0, phi_burn_in=0, phi_mean_thin=1, _adopt=None):
         self._L = _lib.load()
         self.K, self.V = int(num_topics), int(num_types)
         self.D = self.N = 0
-        cfg = _lib.GGSConfig()
-        cfg.struct_size = C.sizeof(_lib.GGSConfig)
-        cfg.num_topics, cfg.num_types, cfg.device_id = self.K, self.V, int(device_id)
-        alpha = np.asarray(alpha, np.float64)
-        self._alpha = None
-        if alpha.ndim == 0:
-            cfg.alpha = None
-            cfg.alpha_scalar = float(alpha)
-        else:
-            self._alpha = np.ascontiguousarray(alpha)
-            if self._alpha.size != self.K:
-                raise ValueError("alpha must have num_topics entries")
-            cfg.alpha = _dp(self._alpha)
-        cfg.beta = float(beta)
-        cfg.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
-        cfg.flags, cfg.phi_burn_in, cfg.phi_mean_thin = int(flags), int(phi_burn_in), int(phi_mean_thin)
+        self._owned = _adopt is None
+        self._keep = []
+        if _adopt is not None:             # a handle created by ggs_group_create
+            self._h = _adopt
+            return
+        cfg, self._alpha = _make_config(num_topics, num_types, alpha, beta, seed, device_id, flags, phi_burn_in, phi_mean_thin)
         h = C.c_void_p()
         rc = self._L.ggs_create(C.byref(cfg), C.byref(h))
         if rc:
@@ -63,8 +84,42 @@ class GGSHandle:
 
     def close(self):
         if getattr(self, "_h", None):
-            self._L.ggs_destroy(self._h)
+            if self._owned:
+                self._L.ggs_destroy(self._h)
             self._h = None
+
+    # ---- multi-GPU exchange (attach before set_corpus) ----
+    def attach_rccl(self, rank, nranks, unique_id):
+        """ncclCommInitRank on this handle's device: every rank of the job calls this together."""
+        _lib.share_rccl_with_torch()
+        uid = C.create_string_buffer(bytes(unique_id), 128)
+        self._chk(self._L.ggs_attach_rccl(self._h, int(rank), int(nranks), C.cast(uid, C.c_void_p)))
+
+    def attach_null_exchange(self, rank, nranks):
+        """Timing aid only (results are wrong by construction): rank `rank` of `nranks` with the peers missing."""
+        self._chk(self._L.ggs_attach_null_exchange(self._h, int(rank), int(nranks)))
+
+    def attach_exchange(self, rank, nranks, reduce_scatter_i32, all_gather_f64, all_gather_i32):
+        """Caller-supplied transport: three callables (send_ptr, recv_ptr, count, hip_stream_ptr) -> 0 on success."""
+        def wrap(fn):
+            def cb(_ctx, send, recv, count, stream):
+                try:
+                    return int(fn(send, recv, count, stream) or 0)
+                except Exception:          # an exception must not unwind through the C frame
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            return _lib.EXCHANGE_CB(cb)
+        ops = _lib.GGSExchangeOps()
+        ops.struct_size = C.sizeof(_lib.GGSExchangeOps)
+        ops.reduce_scatter_i32, ops.all_gather_f64, ops.all_gather_i32 = wrap(reduce_scatter_i32), wrap(all_gather_f64), wrap(all_gather_i32)
+        self._keep.append(ops)             # the library copies the table, the thunks must outlive the handle
+        self._chk(self._L.ggs_attach_exchange(self._h, int(rank), int(nranks), C.byref(ops)))
+
+    def exchange_info(self):
+        r, n, a, b = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        self._chk(self._L.ggs_get_exchange_info(self._h, C.byref(r), C.byref(n), C.byref(a), C.byref(b)))
+        return {"rank": r.value, "nranks": n.value, "k_begin": a.value, "k_end": b.value}
 
     def __del__(self):
         try:
@@ -219,9 +274,53 @@ class GGSHandle:
         return tot.value, doc_ll
 
     def launch_info(self):
-        c, l, b = C.c_int64(), C.c_int32(), C.c_int32()
+        c, l, b, nh = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
         self._chk(self._L.ggs_get_launch_info(self._h, C.byref(c), C.byref(l), C.byref(b)))
-        return {"num_chunks": c.value, "lds_bytes_z": l.value, "docs_per_block_theta": b.value}
+        self._chk(self._L.ggs_get_num_hot_words(self._h, C.byref(nh)))
+        return {"num_chunks": c.value, "lds_bytes_z": l.value, "docs_per_block_theta": b.value, "num_hot": nh.value}
+
+
+class GGSGroup:
+    """ONE process driving several GPUs (ggs_group_create): the handles of the group in rank order, joined by
+    ncclCommInitAll; sweeps are issued for all devices from the calling thread."""
+
+    def __init__(self, num_topics, num_types, alpha, beta, seed, device_ids, flags=0, phi_burn_in=0, phi_mean_thin=1):
+        self._L = _lib.load()
+        _lib.share_rccl_with_torch()
+        cfg, keep = _make_config(num_topics, num_types, alpha, beta, seed, 0, flags, phi_burn_in, phi_mean_thin)
+        n = len(device_ids)
+        devs = (C.c_int32 * n)(*[int(d) for d in device_ids])
+        self._arr = (C.c_void_p * n)()
+        rc = self._L.ggs_group_create(C.byref(cfg), n, devs, self._arr)
+        if rc:
+            raise GGSError(rc, "ggs_group_create failed")
+        self.handles = [GGSHandle(num_topics, num_types, alpha, beta, seed, _adopt=C.c_void_p(self._arr[i])) for i in range(n)]
+
+    def _chk(self, rc):
+        if rc:
+            msgs = [self._L.ggs_last_error(h._h).decode() for h in self.handles]
+            raise GGSError(rc, next((m for m in msgs if m), ""))
+
+    def set_z(self, z_list, redraw_phi=True):
+        zs = [np.ascontiguousarray(z, np.int32) for z in z_list]
+        ptrs = (C.POINTER(C.c_int32) * len(zs))(*[_ip(z) for z in zs])
+        self._chk(self._L.ggs_group_set_z(self._arr, len(zs), ptrs, int(bool(redraw_phi))))
+
+    def sweep(self, n=1):
+        self._chk(self._L.ggs_group_sweep(self._arr, len(self.handles), int(n)))
+
+    def close(self):
+        if getattr(self, "handles", None):
+            for h in self.handles:
+                h._h = None
+            self._L.ggs_group_destroy(self._arr, len(self.handles))
+            self.handles = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 # ---- primitives (parity tests) ----

@@ -196,7 +196,7 @@ class LDAGroupedGibbsSampler:
             self.postIteration()
             if os.path.exists("abort"):                  # the sentinel file of UPLDA:131,908-910 (relative to the working directory)
                 self.abort()
-            if self.zSamplingTimeCum + self.phiSamplingTimeCum > max_exec_ms:    # UPLDA:926-928
+            if self.zSamplingTimeCum + self.phiSamplingTimeCum >= max_exec_ms:   # UPLDA:926-928
                 break
         self.postSample()
 

@@ -1,4 +1,12 @@
-"""Doc-sharded Grouped Gibbs sweep: one process per GPU, torch.distributed for the exchange.
+"""Doc-sharded Grouped Gibbs sweep: one process per GPU.
+
+The exchange of the product path is NATIVE: libggs_hip joins the ranks' handles itself (ggs_attach_rccl: RCCL over xGMI)
+and a sweep contains its collectives -- reduce-scatter of the int32 counts by topic slice, Phi drawn for the rank's own
+topics, all-gather of the fp64 Phi slices (include/ggs_hip.h, "multi-GPU"; `rccl_exchange` below only hands the
+unique id around).  `TopicSliceLayout` restates that protocol's layout rules in numpy: the CPU tests run it over gloo
+with an oracle-backed engine, and `gloo_callback_exchange` plugs the same transport into the HIP handle's callback
+exchange for the two-processes-on-one-GPU test.  The older form, where the caller all-reduces the whole [V][K] count
+buffer and every rank re-draws all of Phi (`TorchHipExchange`), is kept as a cross-check.
 
 Given (theta, Phi) every z is conditionally independent and theta_d depends on document d
 alone, so contiguous document shards (the even-split rule of
@@ -79,9 +87,9 @@ class ShardedGGS:
 
     def _attach(self, exchange_factory, sub, doc_base, tok_base, global_tokens):
         self.local, self.doc_base, self.tok_base, self.global_tokens = sub, doc_base, tok_base, global_tokens
+        self.exchange = exchange_factory(self.engine)        # a native exchange must be attached before the corpus
         self.engine.set_corpus(sub.doc_ptr, sub.tokens, doc_base, tok_base)
         self.engine.set_global_token_count(global_tokens)
-        self.exchange = exchange_factory(self.engine)
 
     def set_z_global(self, z_global):
         """Start-up: every rank takes its slice of the corpus-wide z (e.g. the seeded
@@ -128,6 +136,118 @@ class ShardedGGS:
             self.engine.sweep_begin()
             self.exchange.allreduce_sweep()
             (self.engine.sweep_end if i == n - 1 else end_async)()
+
+
+class NativeExchange:
+    """The exchange lives inside the engine (libggs_hip with ggs_attach_*): sweep_end / init_phi contain the
+    collectives, nothing is left to do between the two halves of a sweep."""
+
+    def __init__(self, engine=None):
+        pass
+
+    def allreduce_startup(self):
+        pass
+
+    allreduce_sweep = allreduce_startup
+
+
+def rccl_exchange(rank, world_size, group=None):
+    """exchange_factory for ShardedGGS: rank 0 draws the RCCL unique id, torch.distributed (any backend) hands it to
+    the other ranks, every rank joins with ggs_attach_rccl.  From then on the library orders its collectives itself,
+    on the handle's own stream."""
+    def factory(engine):
+        import torch.distributed as dist
+        from . import native
+        box = [native.rccl_unique_id() if rank == 0 else None]
+        if world_size > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        engine.attach_rccl(rank, world_size, box[0])
+        return NativeExchange()
+    return factory
+
+
+class TopicSliceLayout:
+    """The layout rules of the native exchange, restated: rank r owns the topics of slice r (sizes K/n + (K % n > r),
+    randomscan/topic/EvenSplitTopicBatchBuilder.java:28-39); counts and Phi slices travel slice-major,
+    [nranks][V][Ksm] with Ksm the widest slice, unused columns zero."""
+
+    def __init__(self, num_topics, num_types, nranks):
+        self.K, self.V, self.n = int(num_topics), int(num_types), int(nranks)
+        self.bounds = even_split(self.K, self.n)
+        self.Ksm = -(-self.K // self.n)
+
+    def slice_of(self, rank):
+        return self.bounds[rank], self.bounds[rank + 1]
+
+    def pack(self, m_vk):
+        """[V][K] -> [nranks][V][Ksm]"""
+        out = np.zeros((self.n, self.V, self.Ksm), m_vk.dtype)
+        for r in range(self.n):
+            a, b = self.slice_of(r)
+            out[r, :, :b - a] = m_vk[:, a:b]
+        return out
+
+    def unpack(self, m_nvk):
+        """[nranks][V][Ksm] -> [V][K]"""
+        out = np.empty((self.V, self.K), m_nvk.dtype)
+        for r in range(self.n):
+            a, b = self.slice_of(r)
+            out[:, a:b] = m_nvk[r, :, :b - a]
+        return out
+
+
+class GlooSliceTransport:
+    """reduce-scatter / all-gather of host arrays over a torch.distributed group (gloo has no reduce-scatter: an
+    all-reduce of the whole send buffer, of which the rank keeps its own chunk -- the same integers)."""
+
+    def __init__(self, rank, world_size, group=None):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.rank, self.world, self.group = torch, dist, int(rank), int(world_size), group
+
+    def reduce_scatter(self, send_n_x):
+        t = self.torch.from_numpy(np.ascontiguousarray(send_n_x).copy())
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        return t.numpy()[self.rank].copy()
+
+    def all_gather(self, send_x):
+        t = self.torch.from_numpy(np.ascontiguousarray(send_x))
+        out = [self.torch.empty_like(t) for _ in range(self.world)]
+        self.dist.all_gather(out, t, group=self.group)
+        return np.stack([o.numpy() for o in out])
+
+
+def gloo_callback_exchange(rank, world_size, group=None):
+    """exchange_factory that plugs a gloo transport into the HIP handle's CALLBACK exchange (ggs_attach_exchange):
+    device buffers are staged through the host.  For tests that run several ranks on one GPU, where RCCL refuses to
+    form a communicator; the native sweep, its slice layout and its Phi-slice kernels are exactly the product's."""
+    def factory(engine):
+        import torch
+        tr = GlooSliceTransport(rank, world_size, group)
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+        def view(ptr, n, typestr):
+            return torch.as_tensor(_DevPtr(ptr, n, typestr), device=dev)
+
+        def reduce_scatter_i32(send, recv, count, stream):
+            torch.cuda.synchronize()
+            own = tr.reduce_scatter(view(send, count * world_size, "<i4").cpu().numpy().reshape(world_size, count))
+            view(recv, count, "<i4").copy_(torch.from_numpy(own))
+            torch.cuda.synchronize()
+            return 0
+
+        def all_gather(typestr):
+            def cb(send, recv, count, stream):
+                torch.cuda.synchronize()
+                allv = tr.all_gather(view(send, count, typestr).cpu().numpy())
+                view(recv, count * world_size, typestr).copy_(torch.from_numpy(allv.reshape(-1)))
+                torch.cuda.synchronize()
+                return 0
+            return cb
+
+        engine.attach_exchange(rank, world_size, reduce_scatter_i32, all_gather("<f8"), all_gather("<i4"))
+        return NativeExchange()
+    return factory
 
 
 def gather_shard_sizes(shard, rank, world_size, device=None, group=None):

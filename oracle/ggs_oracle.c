@@ -488,6 +488,8 @@ struct orc_state {
   int threads;
   int scheme;         /* 0 = ggs (LDAGroupedGibbsSampler), 1 = pcgs (LDAPartiallyCollapsedGibbsSampler) */
   jrandom collapsed_rng; int collapsed_rng_ready;
+  double *phiT;       /* [V][K]: orc_sweep_tuned only (the "tuned CPU" baseline of BASELINE.md section 3) */
+  int32_t *perm; int64_t *wptr;   /* token indices sorted by word, word run offsets [V+1]: orc_sweep_tuned only */
   char err[256];
 };
 
@@ -517,6 +519,7 @@ void orc_destroy(orc_state *s) {
   if (!s) return;
   free(s->alpha); free(s->phi); free(s->n_kw); free(s->n_wk); free(s->delta); free(s->n_k);
   free(s->doc_ptr); free(s->tokens); free(s->z); free(s->theta); free(s->phi_mean);
+  free(s->phiT); free(s->perm); free(s->wptr);
   free(s);
 }
 int orc_set_corpus(orc_state *s, int64_t D, const int64_t *doc_ptr, const int32_t *tokens,
@@ -527,6 +530,7 @@ int orc_set_corpus(orc_state *s, int64_t D, const int64_t *doc_ptr, const int32_
   for (int64_t i = 0; i < N; i++)
     if (tokens[i] < 0 || tokens[i] >= s->V) return fail(s, ORC_ERR_BAD_ARG, "token id out of range");
   free(s->doc_ptr); free(s->tokens); free(s->z); free(s->theta);
+  free(s->perm); free(s->wptr); s->perm = NULL; s->wptr = NULL;
   s->D = D; s->N = N; s->doc_base = doc_base; s->tok_base = tok_base;
   s->doc_ptr = malloc(sizeof(int64_t) * (D + 1));
   memcpy(s->doc_ptr, doc_ptr, sizeof(int64_t) * (D + 1));
@@ -563,13 +567,16 @@ static void zero_counts(orc_state *s) {
 /* UPLDA:1287-1294 initialSamplePhi -> MarsagliaSparseDirichlet.nextDistribution(int[])
  * (MarsagliaSparseDirichlet.java:31-55) built by Dirichlet(int size, double beta):
  * magnitude = V*beta, partition[i] = 1.0/V. */
-int orc_init_phi(orc_state *s) {
+int orc_init_phi(orc_state *s) { return orc_init_phi_range(s, 0, s->K); }
+/* initialSamplePhi(indices, phi) for the topic batch [k0, k1) (UPLDA:1287-1294 takes the batch's indices) */
+int orc_init_phi_range(orc_state *s, int32_t k0, int32_t k1) {
   s->err[0] = 0;
   int err = ORC_OK;
+  if (k0 < 0 || k1 > s->K || k0 > k1) return fail(s, ORC_ERR_BAD_ARG, "bad topic range");
   const double magnitude = (double)s->V * s->beta;
   const double partition = 1.0 / (double)s->V;
 #pragma omp parallel for num_threads(s->threads) schedule(static)
-  for (int32_t k = 0; k < s->K; k++) {
+  for (int32_t k = k0; k < k1; k++) {
     double *row = s->phi + (size_t)k * s->V;
     const int32_t *cnt = s->n_kw + (size_t)k * s->V;
     double sum = 0;
@@ -786,17 +793,19 @@ static int sample_phi_this_iteration(const orc_state *s) {
   return s->phi_burn_in > 0 && s->iteration > s->phi_burn_in && (s->iteration % s->phi_thin) == 0;
 }
 
-/* GGS:139-171 samplePhi + GGS:182-198 loopOverTopics */
-int orc_sample_phi(orc_state *s) {
+/* GGS:182-198 loopOverTopics(indices, phi) for the topic batch [k0, k1) -- samplePhi hands one such batch to every
+ * PhiSampler thread (GGS:139-171); a multi-GPU run hands one to every rank (EvenSplitTopicBatchBuilder.java:28-39). */
+int orc_sample_phi_range(orc_state *s, int32_t k0, int32_t k1) {
   s->err[0] = 0;
   int err = ORC_OK;
   const int32_t K = s->K, V = s->V;
+  if (k0 < 0 || k1 > K || k0 > k1) return fail(s, ORC_ERR_BAD_ARG, "bad topic range");
   const int accumulate = s->save_phi_mean && sample_phi_this_iteration(s);
 #pragma omp parallel num_threads(s->threads)
   {
     double *dirichletParams = malloc(sizeof(double) * V);
 #pragma omp for schedule(dynamic, 1)
-    for (int32_t topic = 0; topic < K; topic++) {
+    for (int32_t topic = k0; topic < k1; topic++) {
       const int32_t *relevantTypeTopicCounts = s->n_kw + (size_t)topic * V;
       for (int32_t type = 0; type < V; type++)
         dirichletParams[type] = s->beta + relevantTypeTopicCounts[type];
@@ -811,8 +820,15 @@ int orc_sample_phi(orc_state *s) {
     }
     free(dirichletParams);
   }
-  if (accumulate) s->n_sampled_phi++;     /* GGS:168-170 */
   if (err) return fail(s, err, "phi draw failed");
+  return ORC_OK;
+}
+
+/* GGS:139-171 samplePhi: every topic batch, then the noSampledPhi bookkeeping */
+int orc_sample_phi(orc_state *s) {
+  int e = orc_sample_phi_range(s, 0, s->K);
+  if (e) return e;
+  if (s->save_phi_mean && sample_phi_this_iteration(s)) s->n_sampled_phi++;     /* GGS:168-170 */
   return ORC_OK;
 }
 
@@ -823,6 +839,93 @@ int orc_sweep(orc_state *s, int32_t n_sweeps) {
     int e = orc_z_step(s);      if (e) return e;
     e = orc_update_counts(s);   if (e) return e;
     e = orc_sample_phi(s);      if (e) return e;
+  }
+  return ORC_OK;
+}
+
+/* ---- the "tuned CPU" baseline (cpu_tuned_mt) ----------------------------------------------
+ * The same sweep -- the same draws and the same arithmetic in the same order, hence the same bits as orc_sweep -- with
+ * the memory behaviour a CPU implementation would choose rather than the Java program's: Phi transposed to
+ * phiT[V][K] so that a token reads one contiguous row (GGS:98 gathers a column of phi[K][V]), no AtomicInteger deltas
+ * (UPLDA:1547-1557): the counts are rebuilt from z per word over a word-sorted token index, all threads for every
+ * phase (the reference merges on 2 threads, UPLDA:1085).  Timed by bench.py beside the Java-layout port; scheme ggs. */
+static int tuned_doc_step(orc_state *s, int64_t d, int32_t *localTopicCounts, double *thetaParameter, double *theta) {
+  const int32_t K = s->K;
+  const int64_t b = s->doc_ptr[d], e = s->doc_ptr[d + 1];
+  if (e == b) return ORC_OK;
+  memset(localTopicCounts, 0, sizeof(int32_t) * K);
+  for (int64_t i = b; i < e; i++) localTopicCounts[s->z[i]]++;
+  for (int32_t topic = 0; topic < K; topic++) thetaParameter[topic] = localTopicCounts[topic] + s->alpha[topic];
+  int err = orc_dirichlet(s->seed, (uint32_t)s->iteration, ORC_PURPOSE_THETA, (uint64_t)(s->doc_base + d) * (uint64_t)K, K, thetaParameter, theta);
+  if (err) return fail(s, err, "theta draw failed");
+  memcpy(s->theta + (size_t)d * K, theta, sizeof(double) * K);
+  for (int64_t i = b; i < e; i++) {
+    const double *row = s->phiT + (size_t)s->tokens[i] * K;
+    double sum = 0.0;
+    for (int32_t topic = 0; topic < K; topic++) sum += theta[topic] * row[topic];
+    draw_rng r; draw_init(&r, s->seed, (uint32_t)s->iteration, ORC_PURPOSE_Z, (uint64_t)(s->tok_base + i));
+    double sample = draw_next_double(&r) * sum;
+    int32_t newTopic = -1;
+    while (sample > 0.0) {
+      newTopic++;
+      if (newTopic >= K) break;
+      sample -= theta[newTopic] * row[newTopic];       /* the same single IEEE product as in the sum */
+    }
+    if (newTopic < 0 || newTopic >= K) { s->z[i] = newTopic < 0 ? 0 : K - 1; return fail(s, ORC_ERR_INVALID_TOPIC, "Topic sampled is invalid!"); }
+    s->z[i] = newTopic;
+  }
+  return ORC_OK;
+}
+int orc_sweep_tuned(orc_state *s, int32_t n_sweeps) {
+  s->err[0] = 0;
+  if (s->scheme != 0) return fail(s, ORC_ERR_BAD_ARG, "orc_sweep_tuned: scheme ggs only");
+  const int32_t K = s->K, V = s->V;
+  if (!s->phiT) s->phiT = malloc(sizeof(double) * (size_t)K * V);
+  if (!s->perm) {                                      /* counting sort of the token indices by word, once per corpus */
+    s->wptr = calloc((size_t)V + 1, sizeof(int64_t));
+    s->perm = malloc(sizeof(int32_t) * (size_t)(s->N ? s->N : 1));
+    for (int64_t i = 0; i < s->N; i++) s->wptr[s->tokens[i] + 1]++;
+    for (int32_t w = 0; w < V; w++) s->wptr[w + 1] += s->wptr[w];
+    int64_t *cur = malloc(sizeof(int64_t) * (size_t)V);
+    memcpy(cur, s->wptr, sizeof(int64_t) * (size_t)V);
+    for (int64_t i = 0; i < s->N; i++) s->perm[cur[s->tokens[i]]++] = (int32_t)i;
+    free(cur);
+  }
+  for (int32_t it = 0; it < n_sweeps; it++) {
+    s->iteration++;
+    int err = ORC_OK;
+#pragma omp parallel num_threads(s->threads)
+    {
+#pragma omp for schedule(static)
+      for (int32_t v = 0; v < V; v++)                  /* phiT := transpose of the current Phi */
+        for (int32_t k = 0; k < K; k++) s->phiT[(size_t)v * K + k] = s->phi[(size_t)k * V + v];
+      int32_t *ltc = malloc(sizeof(int32_t) * K);
+      double *tp = malloc(sizeof(double) * K), *th = malloc(sizeof(double) * K);
+#pragma omp for schedule(dynamic, 100)
+      for (int64_t d = 0; d < s->D; d++) {
+        int e = tuned_doc_step(s, d, ltc, tp, th);
+        if (e) {
+#pragma omp atomic write
+          err = e;
+        }
+      }
+      free(ltc); free(tp); free(th);
+#pragma omp for schedule(dynamic, 64)
+      for (int32_t w = 0; w < V; w++) {                /* n_wk row of word w = histogram of its tokens' z */
+        int32_t *row = s->n_wk + (size_t)w * K;
+        memset(row, 0, sizeof(int32_t) * K);
+        for (int64_t j = s->wptr[w]; j < s->wptr[w + 1]; j++) row[s->z[s->perm[j]]]++;
+        for (int32_t k = 0; k < K; k++) s->n_kw[(size_t)k * V + w] = row[k];
+      }
+#pragma omp for schedule(static)
+      for (int32_t k = 0; k < K; k++) {
+        int32_t t = 0;
+        for (int32_t w = 0; w < V; w++) t += s->n_kw[(size_t)k * V + w];
+        s->n_k[k] = t;
+      }
+    }
+    if (err) return err;
+    int e = orc_sample_phi(s); if (e) return e;
   }
   return ORC_OK;
 }
@@ -1120,12 +1223,31 @@ void orc_add_delta(orc_state *s, const int32_t *d) {
     for (int32_t v = 0; v < s->V; v++) s->delta[(size_t)k * s->V + v] += d[(size_t)v * s->K + k];
 }
 void orc_get_phi(const orc_state *s, double *o) { memcpy(o, s->phi, sizeof(double) * (size_t)s->K * s->V); }
-void orc_set_phi(orc_state *s, const double *p) { memcpy(s->phi, p, sizeof(double) * (size_t)s->K * s->V); }
+/* UPLDA:1897-1902: this.phi = phi; if (savePhiMeans()) phiMean = new double[numTopics][numTypes] -- the running sum
+ * restarts at zero while noSampledPhi keeps counting */
+void orc_set_phi(orc_state *s, const double *p) {
+  memcpy(s->phi, p, sizeof(double) * (size_t)s->K * s->V);
+  if (s->save_phi_mean && s->phi_mean) memset(s->phi_mean, 0, sizeof(double) * (size_t)s->K * s->V);
+}
 int orc_get_phi_mean(const orc_state *s, double *o) {
   if (s->n_sampled_phi == 0 || !s->phi_mean) return 0;
   size_t kv = (size_t)s->K * s->V;
   for (size_t i = 0; i < kv; i++) o[i] = s->phi_mean[i] / s->n_sampled_phi; /* UPLDA:1959-1964 */
   return s->n_sampled_phi;
+}
+/* rows [k0, k1) of Phi as drawn elsewhere (another rank's topic batch); unlike setPhi this is not a caller's new
+ * matrix, so the running phi mean is left alone */
+void orc_set_phi_rows(orc_state *s, int32_t k0, int32_t k1, const double *rows) {
+  memcpy(s->phi + (size_t)k0 * s->V, rows, sizeof(double) * (size_t)(k1 - k0) * s->V);
+}
+/* all three count structures from a typeTopicCounts matrix [V][K] (the merged counts of a sharded run); deltas zeroed */
+void orc_set_counts(orc_state *s, const int32_t *n_wk) {
+  zero_counts(s);
+  for (int32_t v = 0; v < s->V; v++)
+    for (int32_t k = 0; k < s->K; k++) {
+      const int32_t c = n_wk[(size_t)v * s->K + k];
+      s->n_wk[(size_t)v * s->K + k] = c; s->n_kw[(size_t)k * s->V + v] = c; s->n_k[k] += c;
+    }
 }
 void orc_get_theta(const orc_state *s, double *o) { memcpy(o, s->theta, sizeof(double) * (size_t)s->D * s->K); }
 void orc_get_doc_topic_counts(const orc_state *s, int32_t *o) {

@@ -109,6 +109,12 @@ int32_t orc_get_iteration(const orc_state *s);
 
 /* one full sweep = z step for every doc + updateCounts + samplePhi */
 int orc_sweep(orc_state *s, int32_t n_sweeps);
+int orc_sample_phi_range(orc_state *s, int32_t k0, int32_t k1);   /* GGS:182-198 loopOverTopics for one topic batch */
+int orc_init_phi_range(orc_state *s, int32_t k0, int32_t k1);     /* UPLDA:1287-1294 for one topic batch */
+void orc_set_phi_rows(orc_state *s, int32_t k0, int32_t k1, const double *rows);
+void orc_set_counts(orc_state *s, const int32_t *n_wk /* [V][K] */);
+/* the same sweep, bit for bit, with CPU-friendly memory behaviour (transposed Phi, no atomics): bench.py's cpu_tuned_mt */
+int orc_sweep_tuned(orc_state *s, int32_t n_sweeps);
 /* pieces, for sharded / staged tests */
 int orc_z_step(orc_state *s);       /* GGS:47-132 for every local doc; leaves deltas */
 int orc_update_counts(orc_state *s);/* UPLDA:1107-1221 */

@@ -68,6 +68,11 @@ def lib():
         "orc_set_iteration": (None, [vp, C.c_int32]),
         "orc_get_iteration": (C.c_int32, [vp]),
         "orc_sweep": (C.c_int, [vp, C.c_int32]),
+        "orc_sweep_tuned": (C.c_int, [vp, C.c_int32]),
+        "orc_sample_phi_range": (C.c_int, [vp, C.c_int32, C.c_int32]),
+        "orc_init_phi_range": (C.c_int, [vp, C.c_int32, C.c_int32]),
+        "orc_set_phi_rows": (None, [vp, C.c_int32, C.c_int32, dp]),
+        "orc_set_counts": (None, [vp, ip]),
         "orc_z_step": (C.c_int, [vp]),
         "orc_update_counts": (C.c_int, [vp]),
         "orc_sample_phi": (C.c_int, [vp]),
@@ -270,6 +275,27 @@ class OracleSampler:
 
     def sweep(self, n=1):
         self._chk(lib().orc_sweep(self._h, n))
+
+    def sample_phi_range(self, k0, k1):
+        """loopOverTopics (GGS:182-198) for the topic batch [k0, k1)"""
+        self._chk(lib().orc_sample_phi_range(self._h, int(k0), int(k1)))
+
+    def init_phi_range(self, k0, k1):
+        self._chk(lib().orc_init_phi_range(self._h, int(k0), int(k1)))
+
+    def set_phi_rows(self, k0, rows):
+        rows = np.ascontiguousarray(rows, np.float64)
+        assert rows.ndim == 2 and rows.shape[1] == self.V and k0 + rows.shape[0] <= self.K
+        lib().orc_set_phi_rows(self._h, int(k0), int(k0 + rows.shape[0]), _dp(rows))
+
+    def set_counts(self, n_wk):
+        n_wk = np.ascontiguousarray(n_wk, np.int32)
+        assert n_wk.shape == (self.V, self.K)
+        lib().orc_set_counts(self._h, _ip(n_wk))
+
+    def sweep_tuned(self, n=1):
+        """orc_sweep with CPU-friendly memory behaviour; identical results (bench.py's cpu_tuned_mt)."""
+        self._chk(lib().orc_sweep_tuned(self._h, n))
 
     def z_step(self):
         self._chk(lib().orc_z_step(self._h))

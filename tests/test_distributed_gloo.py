@@ -206,3 +206,132 @@ def test_even_split_rule():
     b = even_split(157, 8)
     sizes = np.diff(b)
     assert sizes.max() - sizes.min() <= 1 and sizes.sum() == 157 and list(sizes) == sorted(sizes, reverse=True)
+
+
+def test_topic_slice_layout_rule():
+    """randomscan/topic/EvenSplitTopicBatchBuilder.java:28-39 with one batch per rank, and the slice-major pack/unpack
+    the native exchange uses for its reduce-scatter / all-gather buffers."""
+    from ldagroupedgibbssampler_amd.sharded import TopicSliceLayout
+    lay = TopicSliceLayout(100, 7, 8)
+    assert [lay.slice_of(r) for r in range(8)] == [(0, 13), (13, 26), (26, 39), (39, 52), (52, 64), (64, 76), (76, 88), (88, 100)]
+    assert lay.Ksm == 13
+    lay = TopicSliceLayout(2, 5, 3)
+    assert [lay.slice_of(r) for r in range(3)] == [(0, 1), (1, 2), (2, 2)] and lay.Ksm == 1
+    lay = TopicSliceLayout(10, 6, 3)
+    m = np.arange(60, dtype=np.int32).reshape(6, 10)
+    p = lay.pack(m)
+    assert p.shape == (3, 6, 4) and np.array_equal(p[0, :, :4], m[:, 0:4]) and np.array_equal(p[1, :, :3], m[:, 4:7]) and (p[1, :, 3] == 0).all()
+    assert np.array_equal(lay.unpack(p), m)
+
+
+class OracleSlicedEngine:
+    """The NATIVE exchange's protocol (include/ggs_hip.h, "multi-GPU") restated over the oracle: per sweep the ranks
+    reduce-scatter their local (word, topic) histograms by topic slice, each draws Phi for its own topic batch only
+    (loopOverTopics, GGS:182-198, on the batch EvenSplitTopicBatchBuilder would hand it) and the slices are
+    all-gathered.  `transport` supplies reduce_scatter / all_gather of numpy arrays (gloo here)."""
+
+    def __init__(self, oracle, K, V, alpha, beta, seed, rank, world, transport, scheme="ggs"):
+        from ldagroupedgibbssampler_amd.sharded import TopicSliceLayout
+        self.o = oracle.OracleSampler(K, V, alpha, beta, seed)
+        self.o.set_scheme(scheme)
+        self.K, self.V, self.rank = K, V, rank
+        self.lay, self.tr = TopicSliceLayout(K, V, world), transport
+        self.k0, self.k1 = self.lay.slice_of(rank)
+
+    def set_corpus(self, doc_ptr, tokens, doc_base=0, tok_base=0):
+        self.tokens = np.asarray(tokens)
+        self.o.set_corpus(doc_ptr, tokens, doc_base, tok_base)
+
+    def set_global_token_count(self, n):
+        self.global_tokens = n
+
+    def _local_histogram(self):
+        h = np.zeros((self.V, self.K), np.int32)
+        np.add.at(h, (self.tokens, self.o.get_z()), 1)
+        return h
+
+    def _exchange_counts(self):
+        own = self.tr.reduce_scatter(self.lay.pack(self._local_histogram()))          # [V][Ksm]: corpus-wide counts of my topics
+        self.o.set_counts(self.lay.unpack(self.tr.all_gather(own)))                  # (the product gathers these lazily)
+
+    def _exchange_phi(self):
+        mine = np.zeros((self.V, self.lay.Ksm))
+        mine[:, :self.k1 - self.k0] = self.o.get_phi()[self.k0:self.k1].T
+        self.o.set_phi_rows(0, np.ascontiguousarray(self.lay.unpack(self.tr.all_gather(mine)).T))
+
+    def set_z(self, z, redraw_phi=True):
+        assert not redraw_phi
+        self.o.set_z(z, False)
+
+    def init_phi(self):
+        self._exchange_counts()
+        self.o.init_phi_range(self.k0, self.k1)
+        self._exchange_phi()
+
+    def sweep_begin(self):
+        self.o.set_iteration(self.o.iteration + 1)
+        self.o.z_step()
+
+    def sweep_end(self):
+        self._exchange_counts()
+        self.o.sample_phi_range(self.k0, self.k1)
+        self._exchange_phi()
+
+    def set_test_corpus(self, doc_ptr, tokens, doc_base=0):
+        self._test = (doc_ptr, tokens, doc_base)
+
+    def heldout_log_likelihood(self, num_particles=100):
+        return self.o.heldout_log_likelihood(self._test[0], self._test[1], num_particles, self._test[2])
+
+
+def _worker_sliced(rank, world, port, out_dir, scheme, K):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from ldagroupedgibbssampler_amd.corpus import random_corpus
+    from ldagroupedgibbssampler_amd.sharded import GlooSliceTransport, NativeExchange, ShardedGGS, java_lcg_initial_z
+    from oracle import oracle as O
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    c = random_corpus(157, 120, 60, seed=17, empty_every=10)
+    eng = OracleSlicedEngine(O, K, c.num_types, 0.1, 0.01, 4242, rank, world, GlooSliceTransport(rank, world), scheme)
+    sh = ShardedGGS(eng, NativeExchange, c, rank, world)
+    sh.set_z_global(java_lcg_initial_z(c.num_tokens, K, 77))
+    sh.sweep(3)
+    sh.set_test_corpus(random_corpus(23, 120, 40, seed=5, empty_every=6))
+    ho_total, ho_docs = sh.heldout_log_likelihood(30)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), z=eng.o.get_z(), nwk=eng.o.get_type_topic_counts(), phi=eng.o.get_phi(),
+             theta=eng.o.get_theta(), ho_total=ho_total, ho_docs=ho_docs)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scheme,K", [("ggs", 9), ("pcgs", 9), ("ggs", 1)])
+def test_two_rank_topic_sliced_exchange_equals_unsharded(oracle, tmp_path, scheme, K):
+    """The topic-sliced exchange (reduce-scatter of counts, per-rank Phi batch, all-gather of Phi) over gloo, two real
+    processes: bit-identical to the unsharded oracle.  K = 9 over 2 ranks has unequal slices (5, 4); K = 1 leaves rank 1
+    without a topic."""
+    import torch.multiprocessing as mp
+    from ldagroupedgibbssampler_amd.corpus import random_corpus
+    from ldagroupedgibbssampler_amd.sharded import java_lcg_initial_z
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world = 2
+    mp.spawn(_worker_sliced, args=(world, port, str(tmp_path), scheme, K), nprocs=world, join=True)
+    c = random_corpus(157, 120, 60, seed=17, empty_every=10)
+    ref = oracle.OracleSampler(K, c.num_types, 0.1, 0.01, 4242)
+    ref.set_scheme(scheme)
+    ref.set_corpus(c.doc_ptr, c.tokens)
+    ref.set_z(java_lcg_initial_z(c.num_tokens, K, 77), redraw_phi=True)
+    ref.sweep(3)
+    t = random_corpus(23, 120, 40, seed=5, empty_every=6)
+    ho_total, ho_docs = ref.heldout_log_likelihood(t.doc_ptr, t.tokens, 30)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    assert np.array_equal(np.concatenate([p["z"] for p in parts]), ref.get_z())
+    if scheme == "ggs":
+        assert np.array_equal(np.concatenate([p["theta"] for p in parts]).view(np.int64), ref.get_theta().view(np.int64))
+    for p in parts:
+        assert np.array_equal(p["nwk"], ref.get_type_topic_counts())
+        assert np.array_equal(p["phi"].view(np.int64), ref.get_phi().view(np.int64))
+        assert float(p["ho_total"]) == ho_total and np.array_equal(p["ho_docs"], ho_docs)

@@ -1,0 +1,261 @@
+"""The NATIVE multi-GPU exchange of libggs_hip (include/ggs_hip.h, "multi-GPU"): reduce-scatter of the counts by topic
+slice, Phi drawn for the rank's own topics, all-gather of the fp64 slices -- the device form of the reference's merge
+(UPLDA:1107-1221) and topic-batched samplePhi (GGS:139-171, EvenSplitTopicBatchBuilder.java:28-39).
+
+One GPU is all these tests have, and RCCL refuses two ranks on one device, so the pieces are covered separately:
+  * one rank through the REAL RCCL provider (ncclCommInitRank / ncclReduceScatter / ncclAllGather on the handle's stream)
+  * several ranks with the callback provider: handles in threads of one process over an in-memory transport, and two
+    real processes over gloo -- the native sweep, its slice-major layout and its slice kernels are the product's
+  * the one-process group API (ncclCommInitAll) with one device
+Every case must reproduce the one-handle run / the oracle bit for bit."""
+import os
+import socket
+import sys
+import threading
+
+import numpy as np
+import pytest
+
+from ldagroupedgibbssampler_amd.corpus import Corpus, even_split, random_corpus
+from ldagroupedgibbssampler_amd.sharded import TopicSliceLayout, java_lcg_initial_z
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def assert_bit_equal(a, b, what):
+    a, b = np.ascontiguousarray(a), np.ascontiguousarray(b)
+    assert a.shape == b.shape, what
+    if a.dtype == np.float64:
+        a, b = a.view(np.int64), b.view(np.int64)
+    assert np.array_equal(a, b), "%s differs in %d of %d places" % (what, int((a != b).sum()), a.size)
+
+
+def reference_run(oracle, corpus, K, alpha, beta, seed, zseed, sweeps, scheme="ggs", save_mean=False):
+    o = oracle.OracleSampler(K, corpus.num_types, alpha, beta, seed, threads=4)
+    o.set_scheme(scheme)
+    o.set_phi_mean_gating(save_mean, 1, 1)
+    o.set_corpus(corpus.doc_ptr, corpus.tokens)
+    o.set_z(java_lcg_initial_z(corpus.num_tokens, K, zseed), redraw_phi=True)
+    o.sweep(sweeps)
+    return o
+
+
+@pytest.mark.parametrize("scheme,K", [("ggs", 20), ("ggs", 100), ("ggs", 200), ("pcgs", 24)])
+def test_one_rank_through_rccl(native, oracle, scheme, K):
+    """ncclCommInitRank with one rank: the whole exchange path (own stream, slice-major send buffer, reduce-scatter,
+    slice draw, all-gather, repack, lazily gathered counts) must not change a bit."""
+    c = random_corpus(240, 700, 140, seed=11 + K, empty_every=8)
+    flags = (native.FLAG_PCGS if scheme == "pcgs" else 0) | native.FLAG_SAVE_PHI_MEAN | native.FLAG_PARANOID
+    h = native.GGSHandle(K, c.num_types, 0.1, 0.01, 99, flags=flags, phi_burn_in=1, phi_mean_thin=1)
+    h.attach_rccl(0, 1, native.rccl_unique_id())
+    assert h.exchange_info() == {"rank": 0, "nranks": 1, "k_begin": 0, "k_end": K}
+    h.set_corpus(c.doc_ptr, c.tokens)
+    h.set_z(java_lcg_initial_z(c.num_tokens, K, 3), redraw_phi=True)
+    h.sweep(2)
+    h.sweep_begin()
+    h.sweep_end()
+    o = reference_run(oracle, c, K, 0.1, 0.01, 99, 3, 3, scheme, save_mean=True)
+    assert_bit_equal(h.get_z(), o.get_z(), "z")
+    assert_bit_equal(h.get_type_topic_counts(), o.get_type_topic_counts(), "n_wk")
+    assert_bit_equal(h.get_topic_totals(), o.get_topic_totals(), "n_k")
+    assert_bit_equal(h.get_phi(), o.get_phi(), "phi")
+    if scheme == "ggs":
+        assert_bit_equal(h.get_theta(), o.get_theta(), "theta")
+    gm, gn = h.get_phi_mean()
+    om, on = o.get_phi_mean()
+    assert gn == on == 2
+    assert_bit_equal(gm, om, "phi mean")
+    t = h.get_timings()
+    assert t["sweeps"] == 3 and t["exchange_ms"] > 0
+    with pytest.raises(native.GGSError):
+        h.counts_device_ptr()                      # the library merges the counts itself now
+    h.close()
+
+
+class ThreadTransport:
+    """In-memory collectives between handles driven by threads of one process."""
+
+    def __init__(self, n):
+        self.n, self.bar, self.box = n, threading.Barrier(n, timeout=300), [None] * n
+
+    def exchange(self, rank, payload):
+        self.box[rank] = payload
+        self.bar.wait()
+        got = list(self.box)
+        self.bar.wait()
+        return got
+
+
+def _thread_rank(native, tr, rank, world, whole, K, scheme, zseed, sweeps, out, errs):
+    import torch
+    from ldagroupedgibbssampler_amd.sharded import _DevPtr
+    try:
+        dev = torch.device("cuda", 0)
+
+        def view(ptr, n, typestr):
+            return torch.as_tensor(_DevPtr(ptr, n, typestr), device=dev)
+
+        def reduce_scatter_i32(send, recv, count, stream):
+            torch.cuda.synchronize()
+            mine = view(send, count * world, "<i4").cpu().numpy().reshape(world, count)
+            parts = tr.exchange(rank, mine)
+            own = np.sum([p[rank] for p in parts], axis=0, dtype=np.int32)
+            view(recv, count, "<i4").copy_(torch.from_numpy(own))
+            torch.cuda.synchronize()
+            return 0
+
+        def all_gather(typestr):
+            def cb(send, recv, count, stream):
+                torch.cuda.synchronize()
+                parts = tr.exchange(rank, view(send, count, typestr).cpu().numpy())
+                view(recv, count * world, typestr).copy_(torch.from_numpy(np.concatenate(parts)))
+                torch.cuda.synchronize()
+                return 0
+            return cb
+
+        bounds = even_split(whole.num_docs, world)
+        sub, doc_base, tok_base = whole.shard(bounds[rank], bounds[rank + 1])
+        flags = (native.FLAG_PCGS if scheme == "pcgs" else 0) | native.FLAG_SAVE_PHI_MEAN
+        h = native.GGSHandle(K, whole.num_types, 0.1, 0.01, 4242, flags=flags, phi_burn_in=1, phi_mean_thin=2)
+        h.attach_exchange(rank, world, reduce_scatter_i32, all_gather("<f8"), all_gather("<i4"))
+        h.set_corpus(sub.doc_ptr, sub.tokens, doc_base, tok_base)
+        h.set_global_token_count(whole.num_tokens)
+        z0 = java_lcg_initial_z(whole.num_tokens, K, zseed)
+        h.set_z(z0[tok_base:tok_base + sub.num_tokens], redraw_phi=True)
+        h.sweep(sweeps - 1)
+        h.sweep_begin()
+        h.sweep_end()
+        h.check_invariants()                       # collective: gathers the corpus-wide counts
+        doc_side, topic_side = h.model_log_likelihood()
+        out[rank] = dict(z=h.get_z(), nwk=h.get_type_topic_counts(), nk=h.get_topic_totals(), phi=h.get_phi(),
+                         theta=h.get_theta() if scheme == "ggs" else None, mean=h.get_phi_mean(), info=h.exchange_info(),
+                         ll=(doc_side, topic_side))
+        h.close()
+    except BaseException as e:                      # noqa: BLE001 -- re-raised by the test body
+        errs.append(e)
+        tr.bar.abort()
+
+
+@pytest.mark.parametrize("scheme,K,world", [("ggs", 100, 3), ("ggs", 7, 4), ("pcgs", 24, 2), ("ggs", 200, 3), ("ggs", 2, 3)])
+def test_topic_sliced_exchange_between_handles(native, oracle, scheme, K, world):
+    """`world` doc shards, each a handle with the callback exchange: z, theta per shard and counts, Phi, phi mean on
+    every rank equal the unsharded oracle.  K = 100 over 3 ranks has unequal slices (34, 33, 33); K = 2 over 3 leaves
+    rank 2 without a topic."""
+    whole = random_corpus(310, 900, 120, seed=5 + K, empty_every=9)
+    sweeps = 4
+    tr, out, errs = ThreadTransport(world), [None] * world, []
+    ts = [threading.Thread(target=_thread_rank, args=(native, tr, r, world, whole, K, scheme, 17, sweeps, out, errs)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
+    o = reference_run(oracle, whole, K, 0.1, 0.01, 4242, 17, sweeps, scheme, save_mean=False)
+    o2 = oracle.OracleSampler(K, whole.num_types, 0.1, 0.01, 4242, threads=4)
+    o2.set_scheme(scheme)
+    o2.set_phi_mean_gating(True, 1, 2)
+    o2.set_corpus(whole.doc_ptr, whole.tokens)
+    o2.set_z(java_lcg_initial_z(whole.num_tokens, K, 17), redraw_phi=True)
+    o2.sweep(sweeps)
+    om, on = o2.get_phi_mean()
+    lay = TopicSliceLayout(K, whole.num_types, world)
+    assert_bit_equal(np.concatenate([p["z"] for p in out]), o.get_z(), "z")
+    if scheme == "ggs":
+        assert_bit_equal(np.concatenate([p["theta"] for p in out]), o.get_theta(), "theta")
+    ll_docs = 0.0
+    for r, p in enumerate(out):
+        a, b = lay.slice_of(r)
+        assert p["info"] == {"rank": r, "nranks": world, "k_begin": a, "k_end": b}
+        assert_bit_equal(p["nwk"], o.get_type_topic_counts(), "n_wk on rank %d" % r)
+        assert_bit_equal(p["nk"], o.get_topic_totals(), "n_k on rank %d" % r)
+        assert_bit_equal(p["phi"], o.get_phi(), "phi on rank %d" % r)
+        assert p["mean"][1] == on
+        assert_bit_equal(p["mean"][0], om, "phi mean on rank %d" % r)
+        assert p["ll"][1] == out[0]["ll"][1]       # the topic side is computed from identical counts everywhere
+        ll_docs += p["ll"][0]
+    ref_ll = sum(o.model_log_likelihood())
+    assert abs((ll_docs + out[0]["ll"][1]) - ref_ll) <= 1e-9 * abs(ref_ll)
+
+
+def _process_rank(rank, world, port, out_dir, scheme, K):
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from ldagroupedgibbssampler_amd import native
+    from ldagroupedgibbssampler_amd.sharded import ShardedGGS, gloo_callback_exchange
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    whole = random_corpus(200, 400, 110, seed=77, empty_every=9)
+    h = native.GGSHandle(K, whole.num_types, 0.1, 0.01, 777, device_id=0, flags=native.FLAG_PCGS if scheme == "pcgs" else 0)
+    sh = ShardedGGS(h, gloo_callback_exchange(rank, world), whole, rank, world)
+    sh.set_z_global(java_lcg_initial_z(whole.num_tokens, K, 5))
+    sh.sweep(2)
+    sh.sweep(1)
+    sh.set_test_corpus(random_corpus(30, 400, 60, seed=6, empty_every=5))
+    ho_total, ho_docs = sh.heldout_log_likelihood(40)        # the estimator reads the (gathered) corpus-wide counts
+    h.check_invariants()
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), z=h.get_z(), nwk=h.get_type_topic_counts(), phi=h.get_phi(), ho_total=ho_total,
+             ho_docs=ho_docs)
+    h.close()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("scheme", ["ggs", "pcgs"])
+def test_two_processes_native_exchange_over_gloo(oracle, tmp_path, scheme):
+    """Two real processes, each with its own HIP handle, joined by the callback exchange over gloo: what bench.py runs
+    at --gpus 2 with the RCCL provider swapped for host staging."""
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    world, K = 2, 33
+    mp.spawn(_process_rank, args=(world, port, str(tmp_path), scheme, K), nprocs=world, join=True)
+    whole = random_corpus(200, 400, 110, seed=77, empty_every=9)
+    o = reference_run(oracle, whole, K, 0.1, 0.01, 777, 5, 3, scheme)
+    t = random_corpus(30, 400, 60, seed=6, empty_every=5)
+    ho_total, ho_docs = o.heldout_log_likelihood(t.doc_ptr, t.tokens, 40)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    assert_bit_equal(np.concatenate([p["z"] for p in parts]), o.get_z(), "z")
+    for p in parts:
+        assert_bit_equal(p["nwk"], o.get_type_topic_counts(), "n_wk")
+        assert_bit_equal(p["phi"], o.get_phi(), "phi")
+        assert float(p["ho_total"]) == ho_total
+        assert_bit_equal(p["ho_docs"], ho_docs, "held-out per document")
+
+
+def test_one_process_group_api(native, oracle):
+    """ggs_group_create / ggs_group_set_z / ggs_group_sweep with the one device there is (ncclCommInitAll, every
+    collective inside ncclGroupStart/End)."""
+    c = random_corpus(150, 300, 90, seed=3, empty_every=6)
+    K = 40
+    g = native.GGSGroup(K, c.num_types, 0.1, 0.01, 31337, device_ids=[0])
+    h = g.handles[0]
+    h.set_corpus(c.doc_ptr, c.tokens)
+    g.set_z([java_lcg_initial_z(c.num_tokens, K, 9)], redraw_phi=True)
+    g.sweep(3)
+    o = reference_run(oracle, c, K, 0.1, 0.01, 31337, 9, 3)
+    assert_bit_equal(h.get_z(), o.get_z(), "z")
+    assert_bit_equal(h.get_phi(), o.get_phi(), "phi")
+    assert_bit_equal(h.get_type_topic_counts(), o.get_type_topic_counts(), "n_wk")
+    assert h.get_timings()["sweeps"] == 3
+    g.close()
+
+
+def test_attach_order_and_errors(native):
+    c = random_corpus(20, 50, 30, seed=1)
+    h = native.GGSHandle(5, c.num_types, 0.1, 0.01, 1)
+    h.set_corpus(c.doc_ptr, c.tokens)
+    with pytest.raises(native.GGSError) as e:
+        h.attach_null_exchange(0, 2)               # after the corpus: refused
+    assert e.value.code == native.ERR_STATE
+    h.close()
+    h = native.GGSHandle(5, c.num_types, 0.1, 0.01, 1)
+    with pytest.raises(native.GGSError) as e:
+        h.attach_null_exchange(2, 2)
+    assert e.value.code == native.ERR_BAD_ARG
+    h.close()

@@ -273,3 +273,43 @@ def test_error_codes(oracle):
     with pytest.raises(oracle.OracleError) as e:
         o.sweep(1)
     assert e.value.code == oracle.ERR_INVALID_TOPIC and "Topic sampled is invalid" in str(e.value)
+
+
+def test_tuned_cpu_sweep_is_the_same_sweep(oracle):
+    """bench.py's cpu_tuned_mt (transposed Phi, counts rebuilt per word, no atomics) must be the SAME sampler as the
+    Java-layout port it is timed beside: identical z, counts, theta and Phi, alone and interleaved with it."""
+    c = random_corpus(90, 130, 70, seed=8, empty_every=7)
+    a = oracle.OracleSampler(11, c.num_types, 0.1, 0.01, 77, threads=3)
+    b = oracle.OracleSampler(11, c.num_types, 0.1, 0.01, 77, threads=2)
+    for o in (a, b):
+        o.set_corpus(c.doc_ptr, c.tokens)
+        o.init_z_java_lcg(5)
+        o.init_phi()
+    a.sweep(2)
+    b.sweep_tuned(2)
+    a.sweep(1)
+    b.sweep(1)                                               # the tuned sweep leaves every count structure in step
+    a.sweep(1)
+    b.sweep_tuned(1)
+    assert np.array_equal(a.get_z(), b.get_z())
+    assert np.array_equal(a.get_type_topic_counts(), b.get_type_topic_counts())
+    assert np.array_equal(a.get_topic_type_counts(), b.get_topic_type_counts())
+    assert np.array_equal(a.get_topic_totals(), b.get_topic_totals())
+    assert np.array_equal(a.get_phi().view(np.int64), b.get_phi().view(np.int64))
+    assert np.array_equal(a.get_theta().view(np.int64), b.get_theta().view(np.int64))
+
+
+def test_set_phi_restarts_the_phi_mean(oracle):
+    """UPLDA:1897-1902: setPhi allocates a fresh phiMean while noSampledPhi keeps counting."""
+    c = random_corpus(30, 40, 20, seed=2)
+    o = oracle.OracleSampler(3, c.num_types, 0.3, 0.1, 5)
+    o.set_phi_mean_gating(True, 1, 1)
+    o.set_corpus(c.doc_ptr, c.tokens)
+    o.init_z_java_lcg(1)
+    o.init_phi()
+    o.sweep(3)                                               # iterations 2, 3 accumulate
+    assert o.get_phi_mean()[1] == 2
+    o.set_phi(o.get_phi())
+    o.sweep(1)
+    m, n = o.get_phi_mean()
+    assert n == 3 and np.array_equal(m.view(np.int64), (o.get_phi() / 3).view(np.int64))

@@ -54,7 +54,10 @@ struct ggs_handle {
   bool have_corpus = false, have_phi = false, in_sweep = false;
   int32_t theta_docs_per_block = 0, theta_lds = 0, z_lds = 0, z_tile_tokens = 0, z_waves_per_cu = 0, num_cus = 0;
   bool z_sliced = false;   // scores-in-registers kernel (K <= kSlicedMaxTopics)
-  bool z_stream = false;   // two-pass streaming kernel (K > kSlicedMaxTopics)
+  bool z_stream = false;   // streaming kernel (K > kSlicedMaxTopics): rows once (z_stream1_kernel) ...
+  bool z_two_pass = false; // ... or twice (z_stream_kernel, GGS_DEBUG_ZKERNEL=3: the cross-check)
+  bool z_regck = false;    // z_stream1_kernel keeps its checkpoints in registers (K <= 1024)
+  double margin_scale = 1.0;   // GGS_DEBUG_MARGIN: scales z_stream1_kernel's certainty margin (tests force its exact replay)
 
   hipStream_t stream = nullptr;
   // device buffers
@@ -396,6 +399,7 @@ int launch_z(ggs_handle *h, bool force_fused = false) {
   zp.K = h->K; zp.Kp = h->Kp; zp.pitch16 = h->pitch16; zp.tile_tokens = h->z_tile_tokens;
   zp.num_chunks = h->C;
   zp.ablate = h->ablate;
+  zp.margin_scale = h->margin_scale;
   zp.ct_tok = h->d_ct_tok; zp.ct_idx = h->d_ct_idx; zp.ct_ip = h->d_ct_ip; zp.c_docs = h->d_c_docs; zp.num_cold = h->Cc;
   zp.hot_words = h->d_hot_words; zp.num_hot = h->num_hot; zp.hot_pitch = h->hot_pitch;
   zp.wave_lds = h->wave_lds; zp.hot_off = kSlicedWaves * h->wave_lds; zp.ring_base = h->ring_base;
@@ -425,7 +429,9 @@ int launch_z(ggs_handle *h, bool force_fused = false) {
       HIP_TRY(h, hipLaunchKernel(sliced_kernel_for(h->K), grid_of(std::max(h->Cc, h->Cs - h->Cc)), sblock, args,
                                  (size_t)(kSlicedWaves * h->wave_lds + h->num_hot * h->hot_pitch), h->stream));
     }
-  } else if (h->z_stream) hipLaunchKernelGGL(z_stream_kernel, grid, block, h->z_lds, h->stream, zp);
+  } else if (h->z_stream && h->z_two_pass) hipLaunchKernelGGL(z_stream_kernel, grid, block, h->z_lds, h->stream, zp);
+  else if (h->z_stream && h->z_regck) hipLaunchKernelGGL(z_stream1_kernel<true>, grid, block, h->z_lds, h->stream, zp);
+  else if (h->z_stream) hipLaunchKernelGGL(z_stream1_kernel<false>, grid, block, h->z_lds, h->stream, zp);
   else if (nt <= 1) hipLaunchKernelGGL(z_kernel<1>, grid, block, h->z_lds, h->stream, zp);
   else if (nt <= 2) hipLaunchKernelGGL(z_kernel<2>, grid, block, h->z_lds, h->stream, zp);
   else if (nt <= 4) hipLaunchKernelGGL(z_kernel<4>, grid, block, h->z_lds, h->stream, zp);
@@ -621,10 +627,17 @@ int setup_exchange(ggs_handle *h, Exchange *x) {
   HIP_TRY(h, hipMemset(h->d_phi_own, 0, slice * sizeof(double)));
   HIP_TRY(h, hipMemset(h->d_phi_all, 0, all * sizeof(double)));
   if (!h->stream) {
-    // collectives are ordered by THIS stream alone: not the legacy default stream, whose implicit synchronisation with
-    // other libraries' blocking streams is exactly the convention not to rely on
-    HIP_TRY(h, hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
-    h->stream = h->own_stream;
+    // Collectives are ordered by THIS stream alone: not the legacy default stream, whose implicit synchronisation with
+    // other libraries' blocking streams is exactly the convention not to rely on.  HIGH priority: measured with RCCL
+    // and a torch process group in the process, a normal-priority stream shares its hardware queue with theirs and the
+    // sweep's phases stretch (one rank: 2.59 ms per sweep against 1.93 on a high-priority stream or the null stream).
+    static const bool stay = std::getenv("GGS_DEBUG_OWN_STREAM") && std::atoi(std::getenv("GGS_DEBUG_OWN_STREAM")) == 0;   // experiments
+    if (!stay) {
+      int lo = 0, hi = 0;
+      (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+      HIP_TRY(h, hipStreamCreateWithPriority(&h->own_stream, hipStreamNonBlocking, hi));
+      h->stream = h->own_stream;
+    }
   }
   HIP_TRY(h, hipDeviceSynchronize());
   h->counts_global = false; h->cnt_own_valid = false; h->n_k_valid = false;
@@ -697,18 +710,28 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     // the sliced kernel tags chunk tokens (word ids) in bit 30
     h->z_sliced = h->K <= kSlicedMaxTopics && h->V < (1 << kSlotShift);
     h->z_stream = !h->z_sliced && h->K > 2 * kSliceTopics;
-    if (const char *e = std::getenv("GGS_DEBUG_ZKERNEL")) {          // 0: whole-row tile kernel, 2: streaming kernel where it applies
+    if (const char *e = std::getenv("GGS_DEBUG_ZKERNEL")) {          // 0: whole-row tile kernel, 2: streaming kernel where it applies, 3: its two-pass form
       const int mode = std::atoi(e);
       h->z_sliced = h->z_sliced && mode == 1;
-      h->z_stream = mode == 2 ? h->K > 2 * kSliceTopics : (h->z_stream && mode != 0);
+      h->z_stream = (mode == 2 || mode == 3) ? h->K > 2 * kSliceTopics : (h->z_stream && mode != 0);
+      h->z_two_pass = mode == 3;
     }
+    if (const char *e = std::getenv("GGS_DEBUG_MARGIN")) h->margin_scale = std::atof(e);
     if (h->z_stream) {
-      // 64-token chunks, a 2-slot slice ring + the theta row zero-padded to whole slices; no
-      // score registers, so 8 waves per CU fit the register file and LDS bounds the residency
+      // 64-token chunks, a 2-slot slice ring + the theta row zero-padded to whole slices (one-pass kernel: to whole
+      // checkpoint groups, plus a checkpoint per group and lane); no score registers, so 8 waves per CU fit the
+      // register file and LDS bounds the residency
       h->z_tile_tokens = 64;
-      h->z_lds = kStreamRingSlots * kSliceBytes + ((h->K + kSliceTopics - 1) / kSliceTopics) * kSliceTopics * 8;
+      const int ns = (h->K + kSliceTopics - 1) / kSliceTopics, ng = (ns + kGroupSlices - 1) / kGroupSlices;
+      h->z_regck = !h->z_two_pass && ng <= kRegCheckpoints;          // checkpoints in registers (K <= 1024) or in LDS
+      if (const char *e = std::getenv("GGS_DEBUG_REGCK")) h->z_regck = h->z_regck && std::atoi(e) != 0;
+      h->z_lds = h->z_two_pass ? kStreamRingSlots * kSliceBytes + ns * kSliceTopics * 8
+                               : kStream1RingSlots * kSliceBytes + ng * kGroupSlices * kSliceTopics * 8 + (h->z_regck ? 0 : ng * 64 * 8);
       if (h->z_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);   // K > ~16000: the theta row itself would need slicing
-      h->z_waves_per_cu = std::max(1, std::min(8, kMaxLdsBytes / alloc_of(h->z_lds)));
+      // the waves are persistent, so the grid must be what is truly co-resident -- and a CU's 160 KiB cannot be filled
+      // to the last granule: measured, 5 x 32 KiB and 4 x 40 KiB leave one workgroup waiting for a second round
+      // (z at K = 1024: 18.6 ms with 5 waves of 32 KiB requested, 12.7 ms with 4)
+      h->z_waves_per_cu = std::max(1, std::min(8, (kMaxLdsBytes - kGranule) / alloc_of(h->z_lds)));
       if (const char *e = std::getenv("GGS_DEBUG_WPC")) h->z_waves_per_cu = std::max(1, std::atoi(e));
     } else if (h->z_sliced) {
       // 64-token chunks, per wave the two theta rows and the slice ring, per workgroup (4 waves, one per SIMD) the hot-word table
@@ -737,7 +760,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     h->z_tile_tokens = T;
     h->z_lds = T * pitch + thbytes;
     if (h->z_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);   // K > ~2400 needs a K-sliced kernel (not in this round)
-    h->z_waves_per_cu = std::max(1, std::min(8, kMaxLdsBytes / alloc_of(h->z_lds)));
+    h->z_waves_per_cu = std::max(1, std::min(8, (kMaxLdsBytes - kGranule) / alloc_of(h->z_lds)));
     if (const char *e = std::getenv("GGS_DEBUG_WPC")) h->z_waves_per_cu = std::max(1, std::atoi(e));
     }
   }
@@ -750,7 +773,10 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     // It runs on the side stream beside the Phi phase, which is the critical path; stream priority orders dispatch,
     // not running waves, and measured with 5-6 resident workgroups theta finishes early (0.53 ms instead of 0.75)
     // while the Phi phase it starves gets longer (0.67 -> 0.72 ms).
-    h->theta_docs_per_block = B; h->theta_lds = std::max(lds_of(B), kMaxLdsBytes / 4 - 1024);
+    // ... and 24 KiB of every CU stay free for the main stream's own LDS users (the walk of the exact column sums,
+    // 14.5 KiB per workgroup: with the CU's LDS handed out to theta workgroups to the last granule it waited for the
+    // theta draw to END -- 5 ms at K = 1024).
+    h->theta_docs_per_block = B; h->theta_lds = std::max(lds_of(B), (kMaxLdsBytes - 24 * 1024) / 4);
   }
   if (h->z_sliced && (hipFuncSetAttribute(sliced_kernel_for(h->K), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess ||
                       hipFuncSetAttribute(hot_kernel_for(h->K), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess))
@@ -760,7 +786,9 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
                       reinterpret_cast<const void *>(z_kernel<16>), reinterpret_cast<const void *>(z_kernel<20>)};
   // The attribute is process-global per kernel, not per handle: always the hardware maximum, so that a later handle
   // with a smaller K never lowers the cap under a live one.
-  if (h->z_stream && hipFuncSetAttribute(reinterpret_cast<const void *>(z_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess)
+  if (h->z_stream && (hipFuncSetAttribute(reinterpret_cast<const void *>(z_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess ||
+                      hipFuncSetAttribute(reinterpret_cast<const void *>(z_stream1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess ||
+                      hipFuncSetAttribute(reinterpret_cast<const void *>(z_stream1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess))
     return bail(GGS_ERR_HIP);
   for (const void *f : zk)
     if (!h->z_sliced && !h->z_stream && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess) return bail(GGS_ERR_HIP);
@@ -795,7 +823,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       h->pcgs_lds = kPcgsRingSlots * kSliceBytes + kt * 8 + kt * 128;
     }
     if (h->pcgs_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);
-    h->pcgs_waves_per_cu = std::max(1, std::min(8, kMaxLdsBytes / ((h->pcgs_lds + 2047) / 2048 * 2048)));
+    h->pcgs_waves_per_cu = std::max(1, std::min(8, (kMaxLdsBytes - 2048) / ((h->pcgs_lds + 2047) / 2048 * 2048)));   // never a CU filled to the last granule (see z_waves_per_cu)
     if (hipFuncSetAttribute(h->pcgs_sliced ? pcgs_kernel_for(h->K) : reinterpret_cast<const void *>(pcgs_z_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             kMaxLdsBytes) != hipSuccess)
       return bail(GGS_ERR_HIP);

@@ -154,7 +154,7 @@ __global__ __launch_bounds__(kSumBlock) void sum_segfn_kernel(SumParams p) {
   fn[3] = (double)e;
 }
 
-// One wave per topic.  Segments are taken 1024 at a time (16 groups of 64, lane j of a group owns
+// One wave per topic.  Segments are taken 256 at a time (4 groups of 64, lane j of a group owns
 // segment j): all their segment functions and the raw rows of every segment already known to need
 // the element-by-element path are fetched up front, so memory latency is paid once, not per step.
 // Within a group the walk advances by RUNS: an inclusive wave scan of D1 over the consecutive clean,
@@ -163,12 +163,16 @@ __global__ __launch_bounds__(kSumBlock) void sum_segfn_kernel(SumParams p) {
 // upward of 2^(e+1), so its binade test still fails); the longest prefix whose s_out stays in the
 // binade is accepted in one step.  Whatever stops a run -- a tie, a dirty segment, a crossing -- is
 // then taken on its own.
-constexpr int kWalkSuper = 1024, kWalkRawSlots = 48;
+// LDS: 8 KiB of segment functions + 6 KiB of raw rows per (single-wave) workgroup.  Kept small on purpose: the walk
+// runs while the next theta draw fills the CUs from the side stream, and a workgroup that asks for more LDS than one
+// theta workgroup frees is starved until the theta draw ends (measured with 58 KiB: 80 us instead of 25 at K = 100,
+// 5 ms instead of 0.06 at K = 1024).
+constexpr int kWalkSuper = 256, kWalkGroups = kWalkSuper / 64, kWalkRawSlots = 12;
 
 template <typename T, bool MAGNITUDE>
 __global__ __launch_bounds__(64) void sum_walk_kernel(SumParams p) {
-  __shared__ double tup[kWalkSuper][4];                     // 32 KiB
-  __shared__ double raw[kWalkRawSlots][kSumSegRows];        // 24 KiB
+  __shared__ double tup[kWalkSuper][4];                     // 8 KiB
+  __shared__ double raw[kWalkRawSlots][kSumSegRows];        // 6 KiB
   __shared__ int16_t dirty_list[kWalkSuper];
   const int k = blockIdx.x, lane = threadIdx.x;
   const T *src = static_cast<const T *>(p.src);
@@ -183,16 +187,16 @@ __global__ __launch_bounds__(64) void sum_walk_kernel(SumParams p) {
     const int nhere = min(kWalkSuper, p.nseg - sg), groups = (nhere + 63) / 64;
     __syncthreads();
     {                                                       // all segment functions of the super-group -> LDS
-      double t[16][4];
+      double t[kWalkGroups][4];
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
+      for (int g = 0; g < kWalkGroups; ++g) {
         const int i = min(sg + g * 64 + lane, p.nseg - 1);
         const double *fn = p.fn + ((size_t)i * p.K + k) * 4;
 #pragma unroll
         for (int c = 0; c < 4; ++c) t[g][c] = fn[c];
       }
 #pragma unroll
-      for (int g = 0; g < 16; ++g) {
+      for (int g = 0; g < kWalkGroups; ++g) {
         const bool valid = g * 64 + lane < nhere;
 #pragma unroll
         for (int c = 0; c < 3; ++c) tup[g * 64 + lane][c] = t[g][c];

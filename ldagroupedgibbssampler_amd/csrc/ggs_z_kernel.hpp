@@ -50,6 +50,7 @@ struct ZParams {
   int32_t num_hot, hot_pitch;  // rows and row pitch (bytes) of the LDS table
   int32_t hot_off, wave_lds;   // LDS byte offset of the table; bytes of LDS per wave (theta rows + ring)
   int32_t ring_base;           // offset of the ring inside a wave's LDS
+  double margin_scale;         // z_stream1_kernel: 1.0; tests scale the certainty margin up to force its exact replay path
 };
 
 struct alignas(16) D2 { double a, b; };

@@ -181,4 +181,262 @@ __global__ __launch_bounds__(64) void z_stream_kernel(ZParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// z_stream1_kernel -- the same token loop with every phiT row streamed ONCE.
+//
+// The second pass of z_stream_kernel exists to replay the walk of GGS:108-113, sample -= score[k] until sample <= 0,
+// a rounding chain of its own.  But where that chain stops can almost always be decided from the chain the first pass
+// computes anyway, the running sum s_j = fl(s_{j-1} + p_j) of the scores p_j = theta[j]*phi[j][w] (GGS:96-101):
+//   * every step of either chain rounds a value of magnitude <= sum, so each is off by at most ulp(sum)/2, and after
+//     j steps  |t_j - (t_0 - s_j)| <= j * 2^-52 * sum,  with t_0 = fl(U*sum) and t_j the Java walk's `sample` after
+//     subtracting p_0..p_{j-1};
+//   * the walk returns the first topic r with t_{r+1} <= 0.  With d_j = t_0 - s_{j+1} and the margin
+//     delta = K * 2^-51 * sum (twice the bound):  d_j < -delta proves t_{j+1} < 0,  d_j > delta proves t_{j+1} > 0.
+//     Both chains are monotone, so if r is the first index with d_r < -delta and also d_{r-1} > delta (t_0 > delta for
+//     r = 0), the walk stops at r -- whatever its own roundings were.
+// A token is undecided only if U*sum falls within delta of one of K partial sums: probability ~ K^2 * 2^-50 (1e-9 at
+// K = 1024).  Such a token -- and any whose walk would not end inside [0, K) -- is replayed exactly as Java does it,
+// element by element from the raw row (the chunk's lanes wait for it; GGS_DEBUG_MARGIN scales delta up so that the
+// tests drive thousands of tokens through the replay).
+//
+// To find r without keeping K partial sums per token, pass 1 stores the chain at every 64th topic (a checkpoint per
+// group of 4 slices, [group][lane] in LDS); the first group whose checkpoint satisfies d < -delta contains r, and only
+// that group's 512 bytes of the row are streamed again (each lane its own group: the group offset rides on the per-lane
+// DMA source address), continuing the chain from the previous checkpoint -- the same additions in the same order, hence
+// the same s_j.  Row traffic per token: 8*K + 512 bytes instead of 16*K.
+// LDS per wave: the 2-slot ring, the theta row zero-padded to whole groups, the checkpoints.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int kGroupSlices = 4;                                    // slices per checkpoint group (64 topics, 512 B of a row)
+#ifndef GGS_STREAM1_RING
+#define GGS_STREAM1_RING 2
+#endif
+constexpr int kStream1RingSlots = GGS_STREAM1_RING;                // measured at K = 1024 with 4 waves per CU: 2 slots 12.7 ms, 3 slots 12.9; waves per CU matter more
+constexpr int kRegCheckpoints = 16;                                // REGCK: checkpoints in registers for up to 16 groups (K <= 1024): 8 KiB less LDS per wave at K = 1024
+
+template <bool REGCK>
+__global__ __launch_bounds__(64) void z_stream1_kernel(ZParams p) {
+  constexpr int R = kStream1RingSlots, kAhead = R - 1;
+  static_assert(kAhead >= 1 && kAhead <= 3, "wait_younger covers up to 3 slices in flight behind the current one");
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x;
+  const int K = p.K, Kp = p.Kp;
+  const int NS = (K + kSliceTopics - 1) / kSliceTopics;            // slices of pass 1
+  const int NG = (NS + kGroupSlices - 1) / kGroupSlices;           // checkpoint groups
+  const int KTG = NG * kGroupSlices * kSliceTopics;                // theta row in LDS, zero padded to whole groups
+  double *thb = reinterpret_cast<double *>(smem + R * kSliceBytes);
+  double *ckb = thb + KTG;                                         // [NG][64] (!REGCK)
+  double ck[REGCK ? kRegCheckpoints : 1];                           // REGCK: the lane's checkpoints
+  const unsigned char *phib = reinterpret_cast<const unsigned char *>(p.phiT);
+  const size_t rowbytes = (size_t)Kp * 8;
+  const const_i64_t *cstart = (const const_i64_t *)p.chunk_start;
+  const const_i32_t *clen = (const const_i32_t *)p.chunk_len;
+  const const_i32_t *cdoc = (const const_i32_t *)p.chunk_doc;
+  const int64_t C = p.num_chunks;
+
+  const int lrow = lane >> 3, lslot = lane & 7;
+  const unsigned char *my_row = smem + lane * 128;
+  const int rot = lane >> 1;
+
+  auto row_addresses = [&](const int w, const unsigned char *(&ra)[8]) {
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+      const int row = 8 * m + lrow;
+      const int wm = __shfl(w, row);                               // 0 for rows past the chunk
+      ra[m] = phib + (size_t)wm * rowbytes + (size_t)(((lslot - (row >> 1)) & 7) << 4);
+    }
+  };
+  auto issue_slice = [&](const int s, const int slot, const unsigned char *const (&ra)[8]) {
+    const size_t off = (size_t)s * 128;
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+      __builtin_amdgcn_global_load_lds((glb_cvoid_t *)(ra[m] + off), (lds_void_t *)(smem + slot * kSliceBytes + m * 1024), 16, 0, 0);
+  };
+
+  const int64_t cend = C * (int64_t)(blockIdx.x + 1) / (int64_t)gridDim.x;
+  int64_t c = C * (int64_t)blockIdx.x / (int64_t)gridDim.x;
+  if (c >= cend) return;
+  int doc_in_lds = -1;
+  int64_t start0 = cstart[c], start1 = 0;
+  int len0 = clen[c], len1 = 0, doc0 = cdoc[c], doc1 = 0;
+  if (c + 1 < cend) { start1 = cstart[c + 1]; len1 = clen[c + 1]; doc1 = cdoc[c + 1]; }
+  int w0 = (lane < len0) ? p.tok[start0 + lane] : 0;
+  int ip0 = (lane < len0) ? p.inv_perm[start0 + lane] : 0;
+  const unsigned char *ra[8], *ran[8], *rr[8];
+  row_addresses(w0, ra);
+  // all but the youngest n slices (8 DMA instructions each) have landed
+  auto wait_younger = [](const int n) {
+    if (n >= 3) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  int g = 0;                                                       // ring slot of this chunk's first slice
+#pragma unroll
+  for (int s = 0; s < kAhead; ++s) issue_slice(s, (g + s) % R, ra);
+
+  for (;;) {
+    const bool has1 = c + 1 < cend;
+    if (doc0 != doc_in_lds) {                                      // wave-uniform: consecutive chunks share the document
+      const double *thg = p.theta + (size_t)doc0 * K;
+      for (int base = 0; base < KTG; base += 1024) {               // 16 loads in flight per lane, one round trip per 1024 topics
+        double t[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int k = base + i * 64 + lane;
+          t[i] = thg[k < K ? k : K - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int k = base + i * 64 + lane;
+          if (k < KTG) thb[k] = (k < K) ? t[i] : 0.0;
+        }
+      }
+      doc_in_lds = doc0;
+    }
+    int w1 = 0, ip1 = 0;
+    int64_t start2 = 0;
+    int len2 = 0, doc2 = 0;
+    if (has1) {
+      w1 = (lane < len1) ? p.tok[start1 + lane] : 0;
+      ip1 = (lane < len1) ? p.inv_perm[start1 + lane] : 0;
+      if (c + 2 < cend) { start2 = cstart[c + 2]; len2 = clen[c + 2]; doc2 = cdoc[c + 2]; }
+      row_addresses(w1, ran);
+    }
+    asm volatile("" ::: "memory");
+
+    // ---- pass 1: the sum chain (GGS:96-101), checkpointed every kGroupSlices slices
+    double sum = 0.0;
+    auto pass1_slice = [&](const int j) {
+      const int cur = (g + j) % R;
+      if (j + kAhead < NS) issue_slice(j + kAhead, (g + j + kAhead) % R, ra);
+      wait_younger(min(kAhead, NS - 1 - j));                       // the pipeline drains at the end: which group to stream next is not known yet
+      if (lane < len0) {
+        const unsigned char *rb = my_row + cur * kSliceBytes;
+        const unsigned char *tb = reinterpret_cast<const unsigned char *>(thb) + j * kSliceTopics * 8;
+        D2 ph[kSliceUnits], th[kSliceUnits];
+#pragma unroll
+        for (int u = 0; u < kSliceUnits; ++u) {
+          ph[u] = lds_d2(rb + (((u + rot) & 7) << 4));
+          th[u] = lds_d2(tb + u * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < kSliceUnits; ++u) {
+          sum += th[u].a * ph[u].a;
+          sum += th[u].b * ph[u].b;
+        }
+      }
+      asm volatile("" ::: "memory");                               // every read of this ring slot is issued before it is refilled
+    };
+    if constexpr (REGCK) {
+#pragma unroll
+      for (int q = 0; q < kRegCheckpoints; ++q)
+        if (q < NG) {                                              // wave-uniform
+#pragma unroll 1
+          for (int j = q * kGroupSlices; j < min((q + 1) * kGroupSlices, NS); ++j) pass1_slice(j);
+          ck[q] = sum;
+        }
+    } else {
+      for (int j = 0; j < NS; ++j) {
+        pass1_slice(j);
+        if (lane < len0 && ((j & (kGroupSlices - 1)) == kGroupSlices - 1 || j == NS - 1)) ckb[(j / kGroupSlices) * 64 + lane] = sum;
+      }
+    }
+
+    // ---- the threshold and the group it falls into
+    double t0 = 0.0, delta = 0.0, s = 0.0;
+    int gsel = 0;
+    bool undecided = true;
+    if (lane < len0) {
+      const uint64_t gtok = (uint64_t)(p.tok_base + start0 + lane);
+      const U4 o = philox4x32_10((uint32_t)gtok, (uint32_t)(gtok >> 32), (uint32_t)GGS_PURPOSE_Z << 24, p.iteration,
+                                 (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
+      t0 = u53(o.x, o.y) * sum;                                    // GGS:107-108
+      delta = (sum * (double)K) * 0x1p-51 * p.margin_scale;
+      int gi = NG;
+      if constexpr (REGCK) {
+#pragma unroll
+        for (int q = kRegCheckpoints - 1; q >= 0; --q)
+          if (q < NG && t0 - ck[q] < -delta) gi = q;               // d is monotone: ends at the first group that satisfies it
+      } else {
+        for (int q = NG - 1; q >= 0; --q)
+          if (t0 - ckb[q * 64 + lane] < -delta) gi = q;
+      }
+      undecided = gi == NG;                                        // the walk would not end inside the row (or too close to call)
+      gsel = undecided ? 0 : gi;
+      if constexpr (REGCK) {                                       // the chain as it stood when pass 1 entered the group
+#pragma unroll
+        for (int q = 0; q < kRegCheckpoints - 1; ++q)
+          if (gsel == q + 1) s = ck[q];
+      } else {
+        s = gsel > 0 ? ckb[(gsel - 1) * 64 + lane] : 0.0;
+      }
+    }
+    // ---- refinement: the 4 slices of each lane's own group
+#pragma unroll
+    for (int m = 0; m < 8; ++m) rr[m] = ra[m] + (size_t)__shfl(gsel, 8 * m + lrow) * (kGroupSlices * 128);
+    const int gr = (g + NS) % R;                                   // ring slot of the first refinement slice
+#pragma unroll
+    for (int i = 0; i < kAhead; ++i) issue_slice(i, (gr + i) % R, rr);
+    int found = -1;
+    double dprev = 0.0;
+#pragma unroll 1
+    for (int i = 0; i < kGroupSlices; ++i) {
+      const int cur = (gr + i) % R;
+      const int ia = i + kAhead;
+      if (ia < kGroupSlices) issue_slice(ia, (gr + ia) % R, rr);
+      else if (has1) issue_slice(ia - kGroupSlices, (gr + ia) % R, ran);   // the next chunk's first slices
+      wait_younger(has1 ? kAhead : min(kAhead, kGroupSlices - 1 - i));
+      if (lane < len0) {
+        const unsigned char *rb = my_row + cur * kSliceBytes;
+        const unsigned char *tb = reinterpret_cast<const unsigned char *>(thb) + ((size_t)gsel * kGroupSlices + i) * kSliceTopics * 8;
+        D2 ph[kSliceUnits], th[kSliceUnits];
+#pragma unroll
+        for (int u = 0; u < kSliceUnits; ++u) {
+          ph[u] = lds_d2(rb + (((u + rot) & 7) << 4));
+          th[u] = lds_d2(tb + u * 16);
+        }
+#pragma unroll
+        for (int u = 0; u < kSliceUnits; ++u) {
+          const int kk = (gsel * kGroupSlices + i) * kSliceTopics + 2 * u;
+          double sp = s;
+          s += th[u].a * ph[u].a;
+          if (found < 0 && t0 - s < -delta) { found = kk; dprev = t0 - sp; }
+          sp = s;
+          s += th[u].b * ph[u].b;
+          if (found < 0 && t0 - s < -delta) { found = kk + 1; dprev = t0 - sp; }
+        }
+      }
+      asm volatile("" ::: "memory");
+    }
+    g = (g + NS + kGroupSlices) % R;
+
+    if (lane < len0) {
+      int new_topic = found;
+      if (undecided || found < 0 || found >= K || !(dprev > delta)) {
+        // the exact replay: GGS:108-113 element by element from the raw row (rare; see the header)
+        const double *row = p.phiT + (size_t)w0 * Kp;
+        double sample = t0;
+        new_topic = -1;
+        while (sample > 0.0) {
+          ++new_topic;
+          if (new_topic >= K) break;
+          sample -= thb[new_topic] * row[new_topic];
+        }
+        if (new_topic < 0 || new_topic >= K) {                     // GGS:116-118 (and the index past K Java would throw on)
+          atomicOr(p.status, ST_INVALID_TOPIC);
+          new_topic = new_topic < 0 ? 0 : K - 1;
+        }
+      }
+      p.z[start0 + lane] = new_topic;
+      p.zw[ip0] = new_topic;
+    }
+    if (!has1) break;
+    c += 1;
+    start0 = start1; len0 = len1; doc0 = doc1; w0 = w1; ip0 = ip1;
+    start1 = start2; len1 = len2; doc1 = doc2;
+#pragma unroll
+    for (int m = 0; m < 8; ++m) ra[m] = ran[m];
+  }
+}
+
 }  // namespace ggs

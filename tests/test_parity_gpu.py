@@ -137,30 +137,38 @@ def test_ragged_corpus_with_empty_documents(native, oracle, K, alpha, beta):
 
 @pytest.mark.parametrize("K", [193, 200, 257, 1024, 1100, 2049])
 def test_wide_topic_rows_use_the_streaming_kernel(native, oracle, K):
-    """K > 192: scores no longer fit the register file; z_stream_kernel streams the phiT rows
-    through the slice ring twice (BASELINE config 3 is K = 1024; > 1024 topics take a second
-    round of theta staging)."""
+    """K > 192: scores no longer fit the register file; z_stream1_kernel streams the phiT rows through the slice ring
+    once, checkpointing the sum chain every 64 topics, plus the 64-topic group the draw falls into (BASELINE config 3
+    is K = 1024; > 1024 topics take a second round of theta staging)."""
     c = random_corpus(120, 300, 150, seed=K, empty_every=9)
     g, o = make_pair(native, oracle, c, K, 0.1, 0.01, 7 + K, flags=native.FLAG_PARANOID, zseed=K)
-    assert g.launch_info()["lds_bytes_z"] == 2 * 8192 + (K + 15) // 16 * 128
+    groups = ((K + 15) // 16 + 3) // 4
+    assert g.launch_info()["lds_bytes_z"] == 2 * 8192 + groups * 512 + (groups * 512 if groups > 16 else 0)   # ring, theta row, checkpoints (in registers up to 16 groups)
     g.sweep(2)
     o.sweep(2)
     compare_state(g, o, "wide K=%d" % K)
 
 
-@pytest.mark.parametrize("mode,K", [(2, 33), (2, 48), (2, 100), (2, 192), (0, 5), (0, 100), (0, 257), ("fused", 20), ("fused", 100), ("chain", 9), ("nohot", 20), ("hot3", 100)])
+@pytest.mark.parametrize("mode,K", [(2, 33), (2, 48), (2, 100), (2, 192), (3, 48), (3, 257), (3, 1024), ("margin9", 257), ("margin9", 1024), ("margin13", 64),
+                                    ("margin13", 300), ("ldsck", 300), ("ldsck", 1024), (0, 5), (0, 100), (0, 257), ("fused", 20), ("fused", 100), ("chain", 9), ("nohot", 20), ("hot3", 100)])
 def test_alternate_z_kernels_agree(native, oracle, K, mode, monkeypatch):
-    """The z kernels are interchangeable: GGS_DEBUG_ZKERNEL=2 forces the streaming kernel below 193 topics,
+    """The z kernels are interchangeable: GGS_DEBUG_ZKERNEL=2 forces the (one-pass) streaming kernel below 193 topics,
+    =3 its two-pass form (every row streamed twice, the walk replayed in full: the cross-check of the one-pass kernel's
+    certainty argument), GGS_DEBUG_MARGIN scales that kernel's margin by 1e9 / 1e13 so that a good share of / nearly all
+    tokens take its exact-replay path,
     =0 the whole-row LDS tile kernel (first-generation, kept as a cross-check); GGS_DEBUG_SPLIT=0 ("fused")
     lets one sliced kernel take cold and hot chunks in turn instead of running z_hot_kernel beside it;
     GGS_DEBUG_CHAIN=1 ("chain") walks the Phi normalisers element by element instead of the exact parallel sums;
     GGS_DEBUG_HOT caps the hot-word table (0: every chunk is a cold chunk; 3: three hot words)."""
     env = {"fused": ("GGS_DEBUG_SPLIT", "0"), "chain": ("GGS_DEBUG_CHAIN", "1"), "nohot": ("GGS_DEBUG_HOT", "0"),
-           "hot3": ("GGS_DEBUG_HOT", "3")}.get(mode, ("GGS_DEBUG_ZKERNEL", str(mode)))
+           "hot3": ("GGS_DEBUG_HOT", "3"), "margin9": ("GGS_DEBUG_MARGIN", "1e9"), "margin13": ("GGS_DEBUG_MARGIN", "1e13"), "ldsck": ("GGS_DEBUG_REGCK", "0")}.get(mode, ("GGS_DEBUG_ZKERNEL", str(mode)))
     monkeypatch.setenv(*env)
+    if str(mode).startswith("margin") or mode == "ldsck":
+        monkeypatch.setenv("GGS_DEBUG_ZKERNEL", "2")
     c = random_corpus(150, 400, 140, seed=K + (mode if isinstance(mode, int) else 7), empty_every=11)
     g, o = make_pair(native, oracle, c, K, 0.1, 0.01, 70 + K, flags=native.FLAG_PARANOID, zseed=K)
     monkeypatch.delenv(env[0])
+    monkeypatch.delenv("GGS_DEBUG_ZKERNEL", raising=False)
     g.sweep(3)
     o.sweep(3)
     compare_state(g, o, "z kernel mode %s K=%d" % (mode, K))

@@ -101,6 +101,30 @@ def synthetic_lda_corpus(num_docs, num_types, mean_doc_len, true_topics=100, see
     return Corpus(doc_ptr, tokens, V)
 
 
+def zipf_unigram_corpus(num_docs, num_types, mean_doc_len, seed=2019, zipf_s=1.07):
+    """Cheap corpus for Wikipedia-scale shapes (BASELINE config 5; SURVEY.md 8d allows unigram words there for the
+    generation cost): len_d = max(1, Poisson(mean)), every token an independent draw from a Zipf(zipf_s) law over a
+    random permutation of the vocabulary.  Generated in slabs so that the 1e8-token case stays within a few GB."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    D, V = int(num_docs), int(num_types)
+    lens = np.maximum(1, rng.poisson(mean_doc_len, D)).astype(np.int64)
+    doc_ptr = np.zeros(D + 1, np.int64)
+    np.cumsum(lens, out=doc_ptr[1:])
+    N = int(doc_ptr[-1])
+    p = 1.0 / np.arange(1, V + 1, dtype=np.float64) ** zipf_s
+    cdf = np.cumsum(p)
+    cdf /= cdf[-1]
+    perm = rng.permutation(V).astype(np.int32)
+    tokens = np.empty(N, np.int32)
+    slab = 1 << 24
+    for b in range(0, N, slab):
+        e = min(N, b + slab)
+        r = np.searchsorted(cdf, rng.random(e - b), side="right")
+        np.minimum(r, V - 1, out=r)
+        tokens[b:e] = perm[r]
+    return Corpus(doc_ptr, tokens, V)
+
+
 def random_corpus(num_docs, num_types, max_len, seed=0, empty_every=0):
     """Small ragged test corpus: uniform lengths in [0, max_len], Zipf-ish words."""
     rng = np.random.default_rng(seed)

@@ -1,0 +1,167 @@
+"""BASELINE.json's larger configurations through the HIP path, at their real dimensions:
+  config 3   the benchmark corpus (D=100k, V=50k, 20.0 M tokens) at K=1024 -- two sweeps, bit for bit against the oracle
+  config 4   stand-in for 20-Newsgroups (the file is not in the image: D=18 846, V=60 000, mean 150 tokens), K=200,
+             three doc shards joined by the native exchange against one handle against the oracle
+  config 5   ONE of its eight shards: D=625 000 documents over V=1 000 000 types, K=500, ~125 M tokens -- offsets
+             beyond 2^31 (phiT is 4.0 GB, theta 2.5 GB), size-independent properties, and exact checks against the
+             oracle on a sample (the first documents' z and theta; three Phi rows)
+The oracle legs use orc_sweep_tuned where a whole-corpus sweep is needed: tests/test_oracle_cpu.py proves it the same
+sampler as the Java-layout orc_sweep, and it is what fits the time budget at K=1024."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from ldagroupedgibbssampler_amd.corpus import even_split, synthetic_lda_corpus, zipf_unigram_corpus
+from ldagroupedgibbssampler_amd.sharded import java_lcg_initial_z
+from tests.test_native_exchange_gpu import ThreadTransport, assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+CORES = min(64, os.cpu_count() or 4)
+
+
+def test_config3_full_size_k1024(native, oracle):
+    c = synthetic_lda_corpus(100000, 50000, 200, true_topics=100, seed=2019)
+    K = 1024
+    g = native.GGSHandle(K, c.num_types, 0.1, 0.01, 2019, flags=native.FLAG_PARANOID)
+    g.set_corpus(c.doc_ptr, c.tokens)
+    g.init_z_java_lcg(2019)
+    g.init_phi()
+    g.sweep(2)
+    z, nk, th, phi = g.get_z(), g.get_topic_totals(), g.get_theta(0, 1000), g.get_phi()
+    g.close()
+    assert z.min() >= 0 and z.max() < K and nk.sum() == c.num_tokens
+    assert np.array_equal(np.bincount(z, minlength=K), nk)
+    o = oracle.OracleSampler(K, c.num_types, 0.1, 0.01, 2019, threads=CORES)
+    o.set_corpus(c.doc_ptr, c.tokens)
+    o.init_z_java_lcg(2019)
+    o.init_phi()
+    o.sweep_tuned(2)
+    assert_bit_equal(z, o.get_z(), "K=1024 full size z")
+    assert_bit_equal(nk, o.get_topic_totals(), "K=1024 full size n_k")
+    assert_bit_equal(phi, o.get_phi(), "K=1024 full size phi")
+    assert_bit_equal(th, o.get_theta()[:1000], "K=1024 full size theta (first 1000 documents)")
+
+
+def _c4_rank(native, tr, rank, world, whole, K, z0, sweeps, out, errs):
+    import torch
+    from ldagroupedgibbssampler_amd.sharded import _DevPtr
+    try:
+        dev = torch.device("cuda", 0)
+
+        def view(ptr, n, typestr):
+            return torch.as_tensor(_DevPtr(ptr, n, typestr), device=dev)
+
+        def reduce_scatter_i32(send, recv, count, stream):
+            torch.cuda.synchronize()
+            parts = tr.exchange(rank, view(send, count * world, "<i4").cpu().numpy().reshape(world, count))
+            view(recv, count, "<i4").copy_(torch.from_numpy(np.sum([p[rank] for p in parts], axis=0, dtype=np.int32)))
+            torch.cuda.synchronize()
+            return 0
+
+        def all_gather(typestr):
+            def cb(send, recv, count, stream):
+                torch.cuda.synchronize()
+                parts = tr.exchange(rank, view(send, count, typestr).cpu().numpy())
+                view(recv, count * world, typestr).copy_(torch.from_numpy(np.concatenate(parts)))
+                torch.cuda.synchronize()
+                return 0
+            return cb
+
+        b = even_split(whole.num_docs, world)
+        sub, doc_base, tok_base = whole.shard(b[rank], b[rank + 1])
+        h = native.GGSHandle(K, whole.num_types, 0.1, 0.01, 2019)
+        h.attach_exchange(rank, world, reduce_scatter_i32, all_gather("<f8"), all_gather("<i4"))
+        h.set_corpus(sub.doc_ptr, sub.tokens, doc_base, tok_base)
+        h.set_global_token_count(whole.num_tokens)
+        h.set_z(z0[tok_base:tok_base + sub.num_tokens], redraw_phi=True)
+        h.sweep(sweeps)
+        h.check_invariants()
+        out[rank] = dict(z=h.get_z(), theta=h.get_theta(), phi=h.get_phi(), nwk=h.get_type_topic_counts())
+        h.close()
+    except BaseException as e:  # noqa: BLE001
+        errs.append(e)
+        tr.bar.abort()
+
+
+def test_config4_standin_three_shards_one_handle_oracle(native, oracle):
+    whole = synthetic_lda_corpus(18846, 60000, 150, true_topics=100, seed=2019)
+    K, sweeps, world = 200, 3, 3
+    z0 = java_lcg_initial_z(whole.num_tokens, K, 2019)
+    one = native.GGSHandle(K, whole.num_types, 0.1, 0.01, 2019, flags=native.FLAG_PARANOID)
+    one.set_corpus(whole.doc_ptr, whole.tokens)
+    one.set_z(z0, redraw_phi=True)
+    one.sweep(sweeps)
+    ref = dict(z=one.get_z(), theta=one.get_theta(), phi=one.get_phi(), nwk=one.get_type_topic_counts())
+    one.close()
+    tr, out, errs = ThreadTransport(world), [None] * world, []
+    ts = [threading.Thread(target=_c4_rank, args=(native, tr, r, world, whole, K, z0, sweeps, out, errs)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
+    assert_bit_equal(np.concatenate([p["z"] for p in out]), ref["z"], "3 shards vs one handle: z")
+    assert_bit_equal(np.concatenate([p["theta"] for p in out]), ref["theta"], "3 shards vs one handle: theta")
+    for p in out:
+        assert_bit_equal(p["phi"], ref["phi"], "3 shards vs one handle: phi")
+        assert_bit_equal(p["nwk"], ref["nwk"], "3 shards vs one handle: n_wk")
+    o = oracle.OracleSampler(K, whole.num_types, 0.1, 0.01, 2019, threads=CORES)
+    o.set_corpus(whole.doc_ptr, whole.tokens)
+    o.set_z(z0, redraw_phi=True)
+    o.sweep(sweeps)
+    assert_bit_equal(ref["z"], o.get_z(), "one handle vs oracle: z")
+    assert_bit_equal(ref["theta"], o.get_theta(), "one handle vs oracle: theta")
+    assert_bit_equal(ref["phi"], o.get_phi(), "one handle vs oracle: phi")
+    assert_bit_equal(ref["nwk"], o.get_type_topic_counts(), "one handle vs oracle: n_wk")
+
+
+def test_config5_one_shard(native, oracle):
+    D, V, K = 625000, 1000000, 500
+    c = zipf_unigram_corpus(D, V, 200, seed=2019)
+    N = c.num_tokens
+    assert N > 120e6 and V * (K + (K & 1)) * 8 > 2 ** 31 and D * K * 8 > 2 ** 31     # the offsets this test exists for
+    g = native.GGSHandle(K, V, 0.1, 0.01, 2019)
+    # shard 3 of 8: non-zero bases, so the RNG element ids (global token / document*K + k) pass 2^32 as well
+    doc_base, tok_base = 3 * D, 3 * N
+    g.set_corpus(c.doc_ptr, c.tokens, doc_base, tok_base)
+    rng = np.random.default_rng(1)
+    z0 = rng.integers(0, K, N, dtype=np.int32)
+    g.set_z(z0, redraw_phi=True)
+    g.sweep(1)
+    z1, phi1 = g.get_z(), g.get_phi()
+    g.sweep(1)
+    g.check_invariants()
+    z2, nk = g.get_z(), g.get_topic_totals()
+    nwk = g.get_type_topic_counts()
+    # size-independent properties
+    assert z2.min() >= 0 and z2.max() < K and nk.sum() == N
+    assert np.array_equal(np.bincount(z2, minlength=K), nk)
+    key = c.tokens.astype(np.int64) * K + z2
+    assert np.array_equal(np.bincount(key, minlength=V * K).astype(np.int32).reshape(V, K), nwk), "n_wk is not the (word, z) histogram"
+    del key
+    for a, b in ((0, 3), (D - 3, D)):                                # first and last documents: theta rows sum to one
+        th = g.get_theta(a, b)
+        assert np.allclose(th.sum(1), 1.0, atol=1e-12) and (th > 0).all()
+    # exact: the first 3000 and the last 2000 documents' sweep 2, replayed by the oracle from the device's own state
+    # after sweep 1 (z, Phi): the RNG is keyed by global indices, so a sub-corpus with the right bases draws the same
+    o = oracle.OracleSampler(K, V, 0.1, 0.01, 2019, threads=CORES)
+    o.set_phi(phi1)
+    for a, b in ((0, 3000), (D - 2000, D)):
+        sub, _, tb = c.shard(a, b)
+        o.set_corpus(sub.doc_ptr, sub.tokens, doc_base + a, tok_base + tb)
+        o.set_z(z1[tb:tb + sub.num_tokens], redraw_phi=False)
+        o.set_iteration(2)
+        o.z_step()
+        assert_bit_equal(z2[tb:tb + sub.num_tokens], o.get_z(), "c5 shard: z of documents [%d, %d)" % (a, b))
+        assert_bit_equal(g.get_theta(a, b), o.get_theta(), "c5 shard: theta of documents [%d, %d)" % (a, b))
+    # exact: three Phi rows of sweep 2 from the device's counts (loopOverTopics on one-topic batches)
+    o.set_counts(nwk)
+    phi2 = g.get_phi()
+    for k in (0, 257, K - 1):
+        o.sample_phi_range(k, k + 1)
+        assert_bit_equal(phi2[k], o.get_phi()[k], "c5 shard: phi row %d" % k)
+    assert np.allclose(phi2.sum(1), 1.0, atol=1e-9)
+    g.close()

@@ -90,8 +90,10 @@ def measured_traffic(kernel_prefixes, workload, sha):
 
 def z_kernels(K, scheme):
     kmax = 8 * ((K + 7) // 8)
+    if scheme == "collapsed":
+        return ["pcgs_z_kernel<true>"]
     if scheme == "pcgs":
-        return ["pcgs_sliced_kernel<%d>" % kmax] if K <= 192 else ["pcgs_z_kernel"]
+        return ["pcgs_sliced_kernel<%d>" % kmax] if K <= 192 else ["pcgs_z_kernel<false>"]
     return ["z_sliced_kernel<%d>" % kmax, "z_hot_kernel<%d>" % kmax] if K <= 192 else ["z_stream_kernel"]
 
 
@@ -196,7 +198,7 @@ def cpu_baseline(corpus, K, alpha, beta, seed, z0, sample_docs):
 
 def make_handle(native, K, V, args, local_rank):
     return native.GGSHandle(K, V, args.alpha, args.beta, args.seed, device_id=local_rank,
-                            flags=native.FLAG_PCGS if args.scheme == "pcgs" else 0)
+                            flags={"ggs": 0, "pcgs": native.FLAG_PCGS, "collapsed": native.FLAG_COLLAPSED}[args.scheme])
 
 
 def phases(tm):
@@ -273,7 +275,8 @@ def main():
     ap.add_argument("--cpu-sample-docs", type=int, default=100000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true", help="skip the extra_configs legs (configs 3 and 4 stand-in) of the default N=1 run")
-    ap.add_argument("--scheme", default="ggs", choices=["ggs", "pcgs"], help="ggs = the headline path; pcgs = the partially collapsed z loop (SURVEY 8f-1), for comparison")
+    ap.add_argument("--scheme", default="ggs", choices=["ggs", "pcgs", "collapsed"],
+                    help="ggs = the headline path; pcgs = the partially collapsed z loop (SURVEY 8f-1); collapsed = the count-form conditional, parallel schedule (SURVEY 8f-4)")
     ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
                     help="N>1: strong = the N=1 corpus split across the ranks (default, BASELINE.json), weak = D documents PER RANK")
     ap.add_argument("--exchange", default="native", choices=["native", "torch"],

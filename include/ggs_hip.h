@@ -59,6 +59,14 @@ enum {
   GGS_FLAG_PARANOID = 1 << 0,     /* run ggs_check_invariants after every sweep
                                      (ParanoidUncollapsedParallelLDA.java:14-55)   */
   GGS_FLAG_SAVE_PHI_MEAN = 1 << 1,/* cfg key save_phi_mean, UPLDA:205,1331-1335    */
+  GGS_FLAG_COLLAPSED = 1 << 3,    /* scheme=collapsed (SerialCollapsedLDA; the conditional is MSLDA:158-226): no theta, no Phi:
+                                     score = (alpha_k + n_dk)*((beta + n_wk)/(betaSum + n_k)).  ggs_sweep runs the PARALLEL
+                                     schedule -- documents side by side against the sweep-start counts minus the token
+                                     itself, merged after the sweep (AD-LDA semantics, ADLDA.java:176-332; approximate as
+                                     ADLDA is, and what a doc-sharded run exchanges is again the count buffer);
+                                     ggs_collapsed_serial_sweep runs the reference's own serial chain.  ggs_get_phi returns
+                                     the point estimate (beta + n_wk)/(betaSum + n_k); ggs_get_theta, ggs_log_posterior and
+                                     ggs_sample_z_given_phi do not apply.  Same K and document-length limits as pcgs. */
   GGS_FLAG_PCGS = 1 << 2          /* scheme=pcgs (LDAPartiallyCollapsedGibbsSampler): the z step is UPLDA:1466-1544,
                                      score = (n_dk + alpha_k)*phi[k][w], sequential inside a document; no theta draw;
                                      counts, Phi draw and exchange exactly as for ggs.  Any K up to
@@ -155,6 +163,14 @@ int ggs_sweep_end(ggs_handle *h);
  * device (they are sticky) and its phase times surface at the next ggs_sweep_end / ggs_sweep / ggs_synchronize-
  * then-getter.  For a doc-sharded loop that exchanges counts every sweep but looks at the result every n. */
 int ggs_sweep_end_async(ggs_handle *h);
+/* replaces: SerialCollapsedLDA.sample's loop over documents (SerialCollapsedLDA.java:159-172 -> sampleTopicsForOneDoc,
+ * MSLDA:158-226) n_sweeps times, in the reference's own SERIAL schedule: one chain over all tokens, counts moved in
+ * place, uniforms from the sampler's ONE java.util.Random: after ggs_init_z_java_lcg(h, seed) the stream simply
+ * continues where the initial topics left it -- SerialCollapsedLDA draws both from the same Randoms(seed) object
+ * (SerialCollapsedLDA.java:60-65,789; MSLDA:206) -- and java_seed is not looked at; after ggs_set_z a new
+ * Random(java_seed) is created at the first call and carried on.  Needs GGS_FLAG_COLLAPSED, an unsharded corpus and no exchange.  One wave does it all: for parity on small
+ * corpora (BASELINE config 1), not for throughput. */
+int ggs_collapsed_serial_sweep(ggs_handle *h, int32_t java_seed, int32_t n_sweeps);
 /* replaces: sampleZGivenPhi (UPLDA:975-1014): z step + updateCounts, Phi kept */
 int ggs_sample_z_given_phi(ggs_handle *h, int32_t n_sweeps);
 /* Device pointer / element count of the int32 [V][K] type-topic counts

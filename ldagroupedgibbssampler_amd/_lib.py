@@ -86,6 +86,7 @@ SIGNATURES = {
     "ggs_sweep_end": (C.c_int, [_vp]),
     "ggs_sweep_end_async": (C.c_int, [_vp]),
     "ggs_sample_z_given_phi": (C.c_int, [_vp, C.c_int32]),
+    "ggs_collapsed_serial_sweep": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "ggs_counts_device_ptr": (C.c_int, [_vp, C.POINTER(_vp), _lp]),
     "ggs_set_global_token_count": (C.c_int, [_vp, C.c_int64]),
     "ggs_synchronize": (C.c_int, [_vp]),

@@ -17,6 +17,7 @@
 #include "ggs_z_stream.hpp"
 #include "ggs_exact_sum.hpp"
 #include "ggs_z_pcgs.hpp"
+#include "ggs_z_collapsed.hpp"
 #include "ggs_loglik.hpp"
 #include "ggs_heldout.hpp"
 #include "ggs_exchange.hpp"
@@ -69,6 +70,9 @@ struct ggs_handle {
   int32_t *d_order = nullptr;                          // scheme=pcgs: local documents, longest first
   int32_t pcgs_lds = 0, pcgs_waves_per_cu = 0, max_doc_len = 0;
   bool pcgs_sliced = false;                            // K <= 192: scores in registers, one pass over the rows per step
+  bool collapsed = false;                              // scheme=collapsed: the pcgs machinery over psi = (beta + n_wk)/(betaSum + n_k)
+  uint64_t *d_lcg = nullptr;                           // ggs_collapsed_serial_sweep: the java.util.Random state
+  bool lcg_ready = false;
   int32_t hot_cap = 0, num_hot = 0, hot_pitch = 0, wave_lds = 0, ring_base = 0;
   int32_t *d_perm = nullptr, *d_inv_perm = nullptr, *d_zw = nullptr, *d_seg_word = nullptr, *d_seg_begin = nullptr;
   // theta of the current / last z step, and the buffer the next iteration's theta is drawn into
@@ -165,7 +169,8 @@ int check_status(ggs_handle *h) {
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   if (!st) return GGS_OK;
   HIP_TRY(h, hipMemsetAsync(h->d_status, 0, sizeof(uint32_t), h->stream));
-  if (st & ST_INVALID_TOPIC) return set_err(h, GGS_ERR_INVALID_TOPIC, "LDAGroupedGibbsSampler: Topic sampled is invalid!");
+  if (st & ST_INVALID_TOPIC)
+    return set_err(h, GGS_ERR_INVALID_TOPIC, h->collapsed ? "SimpleLDA: New topic not sampled." /* MSLDA:216-218 */ : "LDAGroupedGibbsSampler: Topic sampled is invalid!");
   if (st & ST_NEGATIVE_COUNT) return set_err(h, GGS_ERR_NEGATIVE_COUNT, "Negative count for topic (Invalid count!)");
   if (st & ST_BAD_SHAPE) return set_err(h, GGS_ERR_BAD_ARG, "alpha and beta must be strictly positive (gamma shape <= 0)");
   return set_err(h, GGS_ERR_RNG_EXHAUSTED, "a gamma rejection loop exceeded GGS_MAX_BLOCKS Philox blocks");
@@ -380,11 +385,19 @@ int launch_pcgs_z(ggs_handle *h) {
   pp.K = h->K; pp.Kp = h->Kp;
   const int64_t groups = (h->D + 63) / 64;
   const dim3 grid((unsigned)std::min<int64_t>(groups, (int64_t)h->num_cus * h->pcgs_waves_per_cu)), block(64);
-  if (h->pcgs_sliced) {
+  if (h->collapsed) {
+    // the sweep-start ratios (beta + n_wk)/(betaSum + n_k) of the corpus-wide counts, then the pcgs loop over them
+    int rc = launch_magnitude(h);
+    if (rc) return rc;
+    pp.n_wk = h->d_n_wk; pp.n_k = h->d_n_k; pp.beta = h->beta; pp.beta_sum = h->beta * (double)h->V;   // betaSum = beta * numTypes, MSLDA:136
+    hipLaunchKernelGGL(psi_kernel, dim3(grid_for((int64_t)h->K * h->V, 256, 2)), dim3(256), 0, h->stream, h->d_n_wk, h->d_n_k, pp.beta, pp.beta_sum, h->d_phiT,
+                       h->K, h->Kp, h->V);
+    hipLaunchKernelGGL(pcgs_z_kernel<true>, grid, block, (size_t)h->pcgs_lds, h->stream, pp);
+  } else if (h->pcgs_sliced) {
     void *args[] = {&pp};
     HIP_TRY(h, hipLaunchKernel(pcgs_kernel_for(h->K), grid, block, args, (size_t)h->pcgs_lds, h->stream));
   } else {
-    hipLaunchKernelGGL(pcgs_z_kernel, grid, block, (size_t)h->pcgs_lds, h->stream, pp);
+    hipLaunchKernelGGL(pcgs_z_kernel<false>, grid, block, (size_t)h->pcgs_lds, h->stream, pp);
   }
   HIP_TRY(h, hipGetLastError());
   return GGS_OK;
@@ -448,7 +461,7 @@ bool sample_phi_this_iteration(const ggs_handle *h) {  // UPLDA:1350-1352
 
 // java.util.Random(seed).nextInt(bound), n times (JDK 8 javadoc algorithm: 48-bit LCG,
 // next(31), power-of-two shortcut, modulo rejection loop otherwise).
-void java_lcg_next_ints(int32_t seed, int32_t bound, int64_t n, int32_t *out) {
+uint64_t java_lcg_next_ints(int32_t seed, int32_t bound, int64_t n, int32_t *out) {   // returns the generator's state after the n draws
   constexpr uint64_t kMult = 0x5DEECE66DULL, kMask = (1ULL << 48) - 1;
   uint64_t s = ((uint64_t)(int64_t)seed ^ kMult) & kMask;
   auto next31 = [&]() { s = (s * kMult + 0xBULL) & kMask; return (int32_t)(s >> 17); };
@@ -463,6 +476,7 @@ void java_lcg_next_ints(int32_t seed, int32_t bound, int64_t n, int32_t *out) {
       }
     out[i] = r;
   }
+  return s;
 }
 
 int require_ready(ggs_handle *h, bool need_phi) {
@@ -581,8 +595,13 @@ int finish_sweep_enqueue(ggs_handle *h, bool with_phi) {
   E.exchanged = false;
   if (with_phi) {
     acc = (h->flags & GGS_FLAG_SAVE_PHI_MEAN) && sample_phi_this_iteration(h);
-    E.exchanged = h->xg != nullptr;
-    if ((rc = launch_phi(h, false, acc, &E))) return rc;
+    if (h->collapsed) {                    // no Phi in the count form: the merge (with an exchange: the gather of the count slices) and tokensPerTopic
+      acc = false;
+      if ((rc = launch_magnitude(h))) return rc;
+    } else {
+      E.exchanged = h->xg != nullptr;
+      if ((rc = launch_phi(h, false, acc, &E))) return rc;
+    }
   }
   HIP_TRY(h, hipEventRecord(E.e[5], h->stream));
   if (acc) h->n_sampled_phi++;             // GGS:168-170
@@ -681,6 +700,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
   h->Kp = (h->K + 1) & ~1;
   h->pitch16 = (h->Kp / 2) | 1;             // odd number of 16-byte units per LDS row
   h->beta = cfg->beta; h->seed = cfg->seed; h->flags = cfg->flags;
+  if (h->flags & GGS_FLAG_COLLAPSED) { h->collapsed = true; h->flags |= GGS_FLAG_PCGS; }   // the lane-per-document z loop, a different matrix
   h->phi_burn_in = cfg->phi_burn_in; h->phi_thin = cfg->phi_mean_thin > 0 ? cfg->phi_mean_thin : 1;
   if (const char *ab = std::getenv("GGS_DEBUG_ABLATE")) h->ablate = std::atoi(ab);
   h->alpha.assign(h->K, cfg->alpha_scalar);
@@ -814,7 +834,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
   if (h->flags & GGS_FLAG_PCGS) {
     // pcgs_z_kernel: slice ring + alpha row + int16 [KT][64] document counts per single-wave workgroup
     const int ns = std::max(kPcgsRingSlots - 1, (h->K + kSliceTopics - 1) / kSliceTopics), kt = ns * kSliceTopics;
-    h->pcgs_sliced = h->K <= kSlicedMaxTopics;
+    h->pcgs_sliced = h->K <= kSlicedMaxTopics && !h->collapsed;   // the count form runs in the two-pass kernel
     if (const char *e = std::getenv("GGS_DEBUG_PCGS_STREAM")) h->pcgs_sliced = h->pcgs_sliced && std::atoi(e) == 0;
     if (h->pcgs_sliced) {
       const int kmax = ((h->K + 7) / 8) * 8;                       // alpha row + counts below the ring (pcgs_sliced_kernel's kHead)
@@ -824,9 +844,13 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     }
     if (h->pcgs_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);
     h->pcgs_waves_per_cu = std::max(1, std::min(8, (kMaxLdsBytes - 2048) / ((h->pcgs_lds + 2047) / 2048 * 2048)));   // never a CU filled to the last granule (see z_waves_per_cu)
-    if (hipFuncSetAttribute(h->pcgs_sliced ? pcgs_kernel_for(h->K) : reinterpret_cast<const void *>(pcgs_z_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            kMaxLdsBytes) != hipSuccess)
+    if (hipFuncSetAttribute(h->pcgs_sliced ? pcgs_kernel_for(h->K) : h->collapsed ? reinterpret_cast<const void *>(pcgs_z_kernel<true>)
+                                                                                   : reinterpret_cast<const void *>(pcgs_z_kernel<false>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess)
       return bail(GGS_ERR_HIP);
+    if (h->collapsed && ((rc = dev_alloc(h, &h->d_lcg, 2)) ||
+                         hipFuncSetAttribute(reinterpret_cast<const void *>(collapsed_serial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess))
+      return bail(rc ? rc : GGS_ERR_HIP);
   }
   for (auto &E : h->evs) {
     for (auto &e : E.e)
@@ -860,7 +884,7 @@ void ggs_destroy(ggs_handle *h) {
                   h->d_phiT, h->d_mag, h->d_tot, h->d_phi_mean, h->d_n_wk, h->d_n_k, h->d_perm, h->d_inv_perm, h->d_zw, h->d_seg_word, h->d_seg_begin,
                   h->d_status, h->d_scratch, h->d_sum_pref, h->d_sum_fn, h->d_ct_tok, h->d_ct_idx, h->d_ct_ip, h->d_c_docs, h->d_hot_words, h->d_order,
                   h->d_test_ptr, h->d_test_tok, h->d_test_ll, h->d_test_docs, h->d_koff, h->d_cnt_send, h->d_cnt_own, h->d_cnt_all, h->d_n_k_own,
-                  h->d_phi_own, h->d_phi_all, h->d_mag_own, h->d_tot_own};
+                  h->d_phi_own, h->d_phi_all, h->d_mag_own, h->d_tot_own, h->d_lcg};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (h->xg) {
@@ -1049,7 +1073,7 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
     HIP_TRY(h, hipMemcpy(h->d_chunk_len, clen.data(), sizeof(int32_t) * clen.size(), hipMemcpyHostToDevice));
   }
   HIP_TRY(h, hipDeviceSynchronize());   // the uploads and memsets above ran on the null stream; the handle's stream may not synchronise with it
-  h->have_corpus = true; h->have_phi = false; h->in_sweep = false; h->global_tokens = -1;
+  h->have_corpus = true; h->have_phi = false; h->in_sweep = false; h->global_tokens = -1; h->lcg_ready = false;
   h->z_split = h->z_split_allowed; h->z_split_tried = false;
   h->counts_global = h->xg == nullptr; h->cnt_own_valid = false; h->n_k_valid = false;
   return GGS_OK;
@@ -1062,7 +1086,13 @@ int ggs_init_z_java_lcg(ggs_handle *h, int32_t seed) {
   if ((rc = drop_theta_ahead(h))) return rc;
   // One sequential stream, so it runs on the host exactly once at start-up.
   std::vector<int32_t> z((size_t)h->N);
-  java_lcg_next_ints(seed, h->K, h->N, z.data());
+  const uint64_t lcg_state = java_lcg_next_ints(seed, h->K, h->N, z.data());
+  if (h->collapsed) {
+    // SerialCollapsedLDA owns ONE Randoms(seed) (SerialCollapsedLDA.java:60-65): addInstances draws the initial topics
+    // from it (:789) and the sampling loop goes on with the same object (MSLDA:206): the serial sweep continues this stream
+    HIP_TRY(h, hipMemcpyAsync(h->d_lcg, &lcg_state, sizeof lcg_state, hipMemcpyHostToDevice, h->stream));
+    h->lcg_ready = true;
+  }
   if (h->N) HIP_TRY(h, hipMemcpyAsync(h->d_z, z.data(), sizeof(int32_t) * (size_t)h->N, hipMemcpyHostToDevice, h->stream));
   if ((rc = launch_permute_z(h))) return rc;
   if ((rc = launch_count_rebuild(h))) return rc;
@@ -1088,6 +1118,11 @@ int ggs_set_z(ggs_handle *h, const int32_t *z, int32_t redraw_phi) {
 int ggs_init_phi(ggs_handle *h) {
   int rc = require_ready(h, false);
   if (rc) return rc;
+  if (h->collapsed) {                                  // nothing to draw: corpus-wide counts and tokensPerTopic are the whole model
+    if ((rc = launch_magnitude(h))) return rc;
+    h->have_phi = true;
+    return check_status(h);
+  }
   if ((rc = launch_phi(h, true, false))) return rc;   // with an exchange: the start-up count reduce-scatter, the slice, the all-gather
   return check_status(h);
 }
@@ -1131,10 +1166,37 @@ int ggs_sweep(ggs_handle *h, int32_t n_sweeps) {
   return GGS_OK;
 }
 
+int ggs_collapsed_serial_sweep(ggs_handle *h, int32_t java_seed, int32_t n_sweeps) {
+  int rc = require_ready(h, false);
+  if (rc) return rc;
+  if (!h->collapsed) return set_err(h, GGS_ERR_STATE, "ggs_collapsed_serial_sweep needs GGS_FLAG_COLLAPSED");
+  if (h->xg || h->tok_base != 0) return set_err(h, GGS_ERR_STATE, "the serial chain runs over ONE unsharded corpus");
+  if (h->in_sweep) return set_err(h, GGS_ERR_STATE, "inside a split sweep");
+  if ((size_t)h->K * 16 > (size_t)kMaxLdsBytes) return set_err(h, GGS_ERR_UNSUPPORTED, "num_topics too large for the serial kernel's LDS");
+  if ((rc = launch_magnitude(h))) return rc;           // tokensPerTopic in step with the counts
+  if (!h->lcg_ready) {                                 // new java.util.Random(seed): the scrambled initial state
+    const uint64_t st = ((uint64_t)(int64_t)java_seed ^ 0x5DEECE66DULL) & ((1ULL << 48) - 1);
+    HIP_TRY(h, hipMemcpyAsync(h->d_lcg, &st, sizeof st, hipMemcpyHostToDevice, h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    h->lcg_ready = true;
+  }
+  CollapsedSerialParams cp{};
+  cp.doc_ptr = h->d_doc_ptr; cp.tok = h->d_tok; cp.inv_perm = h->d_inv_perm; cp.z = h->d_z; cp.zw = h->d_zw; cp.n_wk = h->d_n_wk; cp.n_k = h->d_n_k;
+  cp.alpha = h->d_alpha; cp.lcg = h->d_lcg; cp.status = h->d_status; cp.num_docs = h->D; cp.beta = h->beta; cp.beta_sum = h->beta * (double)h->V; cp.K = h->K;
+  for (int32_t i = 0; i < n_sweeps; ++i) {
+    h->iteration += 1;
+    hipLaunchKernelGGL(collapsed_serial_kernel, dim3(1), dim3(64), (size_t)h->K * 16, h->stream, cp);
+  }
+  HIP_TRY(h, hipGetLastError());
+  h->have_phi = true;
+  return check_status(h);
+}
+
 int ggs_sample_z_given_phi(ggs_handle *h, int32_t n_sweeps) {
   int rc = require_ready(h, true);
   if (rc) return rc;
   if (h->in_sweep) return set_err(h, GGS_ERR_STATE, "inside a split sweep");
+  if (h->collapsed) return set_err(h, GGS_ERR_UNSUPPORTED, "scheme=collapsed has no Phi to condition on");
   for (int32_t i = 0; i < n_sweeps; ++i) {
     h->iteration += 1;                                 // UPLDA:980
     if ((rc = z_phase(h))) return rc;
@@ -1404,6 +1466,12 @@ int ggs_get_phi(ggs_handle *h, double *phi) {
   if (!h || !phi) return GGS_ERR_BAD_ARG;
   int rc = bind_device(h);
   if (rc) return rc;
+  if (h->collapsed) {                                  // the point estimate from the current counts
+    if ((rc = launch_magnitude(h))) return rc;
+    hipLaunchKernelGGL(psi_kernel, dim3(grid_for((int64_t)h->K * h->V, 256, 2)), dim3(256), 0, h->stream, h->d_n_wk, h->d_n_k, h->beta, h->beta * (double)h->V,
+                       h->d_phiT, h->K, h->Kp, h->V);
+    HIP_TRY(h, hipGetLastError());
+  }
   return phi_out(h, h->d_phiT, h->Kp, phi, 1.0);
 }
 int ggs_set_phi(ggs_handle *h, const double *phi) {

@@ -32,11 +32,17 @@ struct PcgsParams {
   uint64_t seed;
   uint32_t iteration;
   int32_t K, Kp;
+  // scheme=collapsed (pcgs_z_kernel<true>, ggs_z_collapsed.hpp): phiT holds psi[w][k] = (beta + n_wk)/(betaSum + n_k) of the
+  // sweep-start counts; the entry of the token's own old topic is recomputed with the token removed
+  const int32_t *n_wk;         // [V][K] sweep-start counts
+  const int32_t *n_k;          // [K]
+  double beta, beta_sum;
 };
 
 constexpr int kPcgsMaxDocLen = 32767;  // counts are int16
 constexpr int kPcgsRingSlots = 3;      // two slices ahead: 24 KiB of ring, so that four waves fit a CU at K = 100
 
+template <bool COLLAPSED>
 __global__ __launch_bounds__(64) void pcgs_z_kernel(PcgsParams p) {
   constexpr int kAhead = kPcgsRingSlots - 1;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -95,6 +101,9 @@ __global__ __launch_bounds__(64) void pcgs_z_kernel(PcgsParams p) {
       const int w1 = (t + 1 < len) ? p.tok[beg + t + 1] : 0;
       if (has1) row_addresses(w1, ran);
       if (active) cnt[zold * 64 + lane] -= 1;                      // UPLDA:1494 (a count below zero cannot arise: it was built from z above)
+      double own = 0.0;                                            // COLLAPSED: psi of the old topic with this token removed (MSLDA:185-190)
+      if (COLLAPSED && active)
+        own = (p.beta + (double)(p.n_wk[(size_t)w * K + zold] - 1)) / (p.beta_sum + (double)(p.n_k[zold] - 1));
       asm volatile("" ::: "memory");
 
       double sum = 0.0, tt = 0.0;
@@ -123,7 +132,15 @@ __global__ __launch_bounds__(64) void pcgs_z_kernel(PcgsParams p) {
             n[2 * u] = cb[(2 * u) * 64];
             n[2 * u + 1] = cb[(2 * u + 1) * 64];
           }
-          if (j < NS) {                                            // UPLDA:1509-1513
+          if (COLLAPSED) {
+            const int rel = zold - s * kSliceTopics;               // position of the old topic inside this slice, if any
+#pragma unroll
+            for (int u = 0; u < kSliceUnits; ++u) {
+              if (rel == 2 * u) ph[u].a = own;
+              if (rel == 2 * u + 1) ph[u].b = own;
+            }
+          }
+          if (j < NS) {                                            // UPLDA:1509-1513 / MSLDA:196-203
 #pragma unroll
             for (int u = 0; u < kSliceUnits; ++u) {
               sum += ((double)n[2 * u] + al[u].a) * ph[u].a;

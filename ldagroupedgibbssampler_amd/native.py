@@ -8,7 +8,7 @@ from . import _lib
 OK = 0
 ERR_NEGATIVE_COUNT, ERR_INVALID_TOPIC, ERR_RNG_EXHAUSTED, ERR_BAD_ARG = 1, 2, 3, 4
 ERR_HIP, ERR_STATE, ERR_UNSUPPORTED, ERR_INVARIANT = 5, 6, 7, 8
-FLAG_PARANOID, FLAG_SAVE_PHI_MEAN, FLAG_PCGS = 1, 2, 4
+FLAG_PARANOID, FLAG_SAVE_PHI_MEAN, FLAG_PCGS, FLAG_COLLAPSED = 1, 2, 4, 8
 PURPOSE_Z, PURPOSE_THETA, PURPOSE_PHI, PURPOSE_INIT_PHI = 1, 2, 3, 4
 
 
@@ -165,6 +165,10 @@ class GGSHandle:
     # ---- sweeps ----
     def sweep(self, n=1):
         self._chk(self._L.ggs_sweep(self._h, int(n)))
+
+    def collapsed_serial_sweep(self, java_seed, n=1):
+        """SerialCollapsedLDA's own schedule (MSLDA:158-226, one chain, java.util.Random(java_seed)); needs FLAG_COLLAPSED."""
+        self._chk(self._L.ggs_collapsed_serial_sweep(self._h, int(java_seed), int(n)))
 
     def sweep_begin(self):
         self._chk(self._L.ggs_sweep_begin(self._h))

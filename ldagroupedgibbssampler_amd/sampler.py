@@ -183,10 +183,10 @@ class LDAGroupedGibbsSampler:
             self.preIteration()
             self.preZ()
             t0 = self._h.get_timings()
-            self._h.sweep_begin()                        # loopOverBatches + the local half of updateCounts
+            self._z_half()                               # loopOverBatches + the local half of updateCounts
             self.postZ()
             self.prePhi()
-            self._h.sweep_end()                          # samplePhi
+            self._phi_half()                             # samplePhi
             self.postPhi()
             self.currentIteration = self._h.iteration
             t1 = self._h.get_timings()
@@ -200,13 +200,19 @@ class LDAGroupedGibbsSampler:
                 break
         self.postSample()
 
+    def _z_half(self):
+        self._h.sweep_begin()
+
+    def _phi_half(self):
+        self._h.sweep_end()
+
     def _diagnostics(self, iteration):
         """The per-iteration diagnostics of UPLDA:695-905 that have a device implementation, in the Java order: log
         posterior (ggs, from start_diagnostic on), held-out and model log likelihood (compute_likelihood), topic
         indicators; each value is kept in the Java-named list and, with a log_dir, appended in the Java file format."""
         cfg = self.config
         from . import formats as F
-        if cfg.start_diagnostic > 0 and iteration >= cfg.start_diagnostic and not (self._scheme_flags & native.FLAG_PCGS):
+        if cfg.start_diagnostic > 0 and iteration >= cfg.start_diagnostic and not (self._scheme_flags & (native.FLAG_PCGS | native.FLAG_COLLAPSED)):
             lp = self.computeLogPosterior()                               # UPLDA:818-821
             self.logPosterior.append(lp)
             if cfg.log_dir:
@@ -384,11 +390,47 @@ class LDAPartiallyCollapsedGibbsSampler(LDAGroupedGibbsSampler):
         raise NotImplementedError("scheme=pcgs never draws theta; use getThetaEstimate() (UPLDA:716-720 does the same)")
 
 
+class SerialCollapsedLDA(LDAGroupedGibbsSampler):
+    """scheme=collapsed (topics/SerialCollapsedLDA.java; the conditional it samples from is sampleTopicsForOneDoc,
+    MSLDA:158-226).  `schedule`:
+      "serial"    the reference's own chain -- one pass over all tokens, counts moved in place, initial topics and
+                  sampling uniforms from the ONE Randoms(seed) the Java class owns (SerialCollapsedLDA.java:60-65,789):
+                  bit-identical to the restated Java loop, no parallelism across tokens (BASELINE config 1)
+      "parallel"  documents side by side on the sweep-start counts, merged after the sweep (the AD-LDA decomposition):
+                  the device-speed variant, approximate as ADLDA is
+    No theta and no Phi are drawn: getPhi() is the point estimate (beta + n_wk)/(betaSum + n_k)."""
+    _scheme_flags = native.FLAG_COLLAPSED
+
+    def __init__(self, config, schedule="serial"):
+        super().__init__(config)
+        if schedule not in ("serial", "parallel"):
+            raise ValueError("schedule must be 'serial' or 'parallel'")
+        self.schedule = schedule
+
+    def _z_half(self):
+        if self.schedule == "serial":
+            self._h.collapsed_serial_sweep(self.startSeed, 1)
+        else:
+            self._h.sweep_begin()
+
+    def _phi_half(self):
+        if self.schedule == "parallel":
+            self._h.sweep_end()
+
+    def getTheta(self):
+        raise NotImplementedError("scheme=collapsed never draws theta; use getThetaEstimate()")
+
+    def sampleZGivenPhi(self, iterations):
+        raise NotImplementedError("scheme=collapsed has no Phi to condition on")
+
+
 def create_model(config, scheme=None):
-    """The `case "ggs"` / `case "pcgs"` of tui/ParallelLDA.createModel (ParallelLDA.java:401-490)."""
+    """The `case "ggs"` / `case "pcgs"` / `case "collapsed"` of tui/ParallelLDA.createModel (ParallelLDA.java:401-490)."""
     scheme = scheme or config.scheme
     if scheme == "ggs":
         return LDAGroupedGibbsSampler(config)
     if scheme == "pcgs":
         return LDAPartiallyCollapsedGibbsSampler(config)
-    raise ValueError("scheme %r is not provided by this build (only the ggs and pcgs z loops are in scope)" % scheme)
+    if scheme == "collapsed":
+        return SerialCollapsedLDA(config)
+    raise ValueError("scheme %r is not provided by this build (only the ggs, pcgs and collapsed z loops are in scope)" % scheme)

@@ -610,6 +610,10 @@ int orc_init_z_java_lcg(orc_state *s, int32_t seed) {
       int e = update_type_topic_count(s, s->tokens[i], topic, 1);
       if (e) return e;
     }
+  /* SerialCollapsedLDA owns ONE Randoms(seed) (SerialCollapsedLDA.java:60-65): its addInstances draws the initial
+   * topics from it (:789) and the sampling loop goes on drawing from the same object (MSLDA:206) -- so the stream of
+   * orc_collapsed_sweep continues where this initialisation stopped */
+  s->collapsed_rng = r; s->collapsed_rng_ready = 1;
   return ORC_OK;
 }
 /* UPLDA:1797-1843 setZIndicators */
@@ -933,7 +937,9 @@ int orc_sweep_tuned(orc_state *s, int32_t n_sweeps) {
 /* MSLDA:158-226 sampleTopicsForOneDoc, looped as SerialCollapsedLDA.sample does
  * (SerialCollapsedLDA.java:159-172): strictly serial, one java.util.Random
  * stream (MALLET Randoms.nextUniform() is restated as nextDouble(): ASSUMPTION
- * flagged in SURVEY 8c). */
+ * flagged in SURVEY 8c).  The stream is the one orc_init_z_java_lcg left behind
+ * (the sampler's single Randoms object); only a state initialised another way
+ * (orc_set_z) starts a new Random(seed_if_first). */
 int orc_collapsed_sweep(orc_state *s, int32_t seed_if_first, int32_t n_sweeps) {
   s->err[0] = 0;
   const int32_t K = s->K, V = s->V;
@@ -976,6 +982,72 @@ int orc_collapsed_sweep(orc_state *s, int32_t seed_if_first, int32_t n_sweeps) {
   }
   free(localTopicCounts); free(topicTermScores);
   return err;
+}
+
+/* The count-form conditional of MSLDA:196-203 in the PARALLEL schedule the device runs (scheme=collapsed with
+ * documents side by side; the AD-LDA decomposition of ADLDA.java:176-332 with one worker per document): every
+ * document is sampled against the type-topic counts and topic totals AS THEY STOOD AT THE START OF THE SWEEP, minus
+ * the token being resampled (each AD-LDA worker removes the current token from its copy, MSLDA:186-189), while the
+ * document's own topic counts run along its positions exactly as in the serial loop; the merged counts of the sweep
+ * are the (word, z) histogram of the new assignments (sum of the workers' deltas, ADLDA.java:302).  Uniform: Philox,
+ * purpose Z, element = global token index, like the other schemes.  Not the serial chain of orc_collapsed_sweep --
+ * a different (approximate, like ADLDA) sampler that the device kernel must reproduce bit for bit. */
+int orc_collapsed_parallel_sweep(orc_state *s, int32_t n_sweeps) {
+  s->err[0] = 0;
+  const int32_t K = s->K, V = s->V;
+  const double betaSum = s->beta * V;
+  int32_t *stale_wk = malloc(sizeof(int32_t) * (size_t)K * V), *stale_k = malloc(sizeof(int32_t) * K);
+  int err = ORC_OK;
+  for (int32_t it = 0; it < n_sweeps && !err; it++) {
+    s->iteration++;
+    memcpy(stale_wk, s->n_wk, sizeof(int32_t) * (size_t)K * V);
+    memcpy(stale_k, s->n_k, sizeof(int32_t) * K);
+#pragma omp parallel num_threads(s->threads)
+    {
+      int32_t *localTopicCounts = malloc(sizeof(int32_t) * K);
+      double *topicTermScores = malloc(sizeof(double) * K);
+#pragma omp for schedule(dynamic, 100)
+      for (int64_t d = 0; d < s->D; d++) {
+        const int64_t b = s->doc_ptr[d], docLength = s->doc_ptr[d + 1] - b;
+        memset(localTopicCounts, 0, sizeof(int32_t) * K);
+        for (int64_t p = 0; p < docLength; p++) localTopicCounts[s->z[b + p]]++;
+        for (int64_t p = 0; p < docLength; p++) {
+          const int32_t type = s->tokens[b + p], oldTopic = s->z[b + p];
+          const int32_t *currentTypeTopicCounts = stale_wk + (size_t)type * K;
+          localTopicCounts[oldTopic]--;
+          double sum = 0.0;
+          for (int32_t topic = 0; topic < K; topic++) {
+            const int32_t own = topic == oldTopic;                 /* "Remove this token from all counts", MSLDA:185-190 */
+            double score = (s->alpha[topic] + localTopicCounts[topic]) *
+                           ((s->beta + (currentTypeTopicCounts[topic] - own)) / (betaSum + (stale_k[topic] - own)));
+            sum += score;
+            topicTermScores[topic] = score;
+          }
+          draw_rng r; draw_init(&r, s->seed, (uint32_t)s->iteration, ORC_PURPOSE_Z, (uint64_t)(s->tok_base + b + p));
+          double sample = draw_next_double(&r) * sum;
+          int32_t newTopic = -1;
+          while (sample > 0.0) { newTopic++; if (newTopic >= K) break; sample -= topicTermScores[newTopic]; }
+          if (newTopic < 0 || newTopic >= K) {
+            newTopic = newTopic < 0 ? 0 : K - 1;
+#pragma omp atomic write
+            err = ORC_ERR_INVALID_TOPIC;
+          }
+          s->z[b + p] = newTopic;
+          localTopicCounts[newTopic]++;
+        }
+      }
+      free(localTopicCounts); free(topicTermScores);
+    }
+    /* the merge: counts := histogram of the new assignments */
+    zero_counts(s);
+    for (int64_t i = 0; i < s->N; i++) {
+      const int32_t w = s->tokens[i], k = s->z[i];
+      s->n_wk[(size_t)w * K + k]++; s->n_kw[(size_t)k * V + w]++; s->n_k[k]++;
+    }
+  }
+  free(stale_wk); free(stale_k);
+  if (err) return fail(s, err, "SimpleLDA: New topic not sampled.");
+  return ORC_OK;
 }
 
 /* ------------------------------------------------------------------------ */

@@ -120,6 +120,7 @@ int orc_z_step(orc_state *s);       /* GGS:47-132 for every local doc; leaves de
 int orc_update_counts(orc_state *s);/* UPLDA:1107-1221 */
 int orc_sample_phi(orc_state *s);   /* GGS:139-198 */
 int orc_collapsed_sweep(orc_state *s, int32_t seed_if_first, int32_t n_sweeps); /* MSLDA:158-226 */
+int orc_collapsed_parallel_sweep(orc_state *s, int32_t n_sweeps);   /* the same conditional, documents side by side on sweep-start counts (AD-LDA) */
 
 int64_t orc_num_tokens(const orc_state *s);
 void orc_get_z(const orc_state *s, int32_t *z);

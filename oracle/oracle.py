@@ -77,6 +77,7 @@ def lib():
         "orc_update_counts": (C.c_int, [vp]),
         "orc_sample_phi": (C.c_int, [vp]),
         "orc_collapsed_sweep": (C.c_int, [vp, C.c_int32, C.c_int32]),
+        "orc_collapsed_parallel_sweep": (C.c_int, [vp, C.c_int32]),
         "orc_num_tokens": (C.c_int64, [vp]),
         "orc_get_z": (None, [vp, ip]),
         "orc_get_type_topic_counts": (None, [vp, ip]),
@@ -308,6 +309,10 @@ class OracleSampler:
 
     def collapsed_sweep(self, seed, n=1):
         self._chk(lib().orc_collapsed_sweep(self._h, seed, n))
+
+    def collapsed_parallel_sweep(self, n=1):
+        """MSLDA:196-203 with documents side by side on the sweep-start counts (the device's scheme=collapsed schedule)."""
+        self._chk(lib().orc_collapsed_parallel_sweep(self._h, n))
 
     def get_z(self):
         out = np.empty(self.N, np.int32)

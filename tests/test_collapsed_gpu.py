@@ -1,0 +1,200 @@
+"""scheme=collapsed on the device: the count-form conditional of ModifiedSimpleLDA.sampleTopicsForOneDoc (MSLDA:158-226,
+the in-tree twin of what SerialCollapsedLDA runs), SURVEY.md 8(a) row 9 / 8(f) item 4.
+
+  serial schedule     ggs_collapsed_serial_sweep == orc_collapsed_sweep bit for bit: the reference's own chain (counts in
+                      place, the sampler's one java.util.Random stream continuing from the seeded initial topics) --
+                      BASELINE config 1 (the bundled cats corpus, K = 20) among the cases
+  parallel schedule   ggs_sweep with GGS_FLAG_COLLAPSED == orc_collapsed_parallel_sweep bit for bit: the SAME schedule
+                      restated on the CPU (documents side by side on sweep-start counts, AD-LDA style).  Against the
+                      serial chain that schedule is a different, approximate sampler: the north_star's "otherwise"
+                      clause applies, held-out log likelihood within +-1 %.
+Parity against a JVM run: unpinned, as for every path (no JVM, no fixture in the reference; tests/test_oracle_cpu.py)."""
+import threading
+
+import numpy as np
+import pytest
+
+from ldagroupedgibbssampler_amd.corpus import even_split, random_corpus, synthetic_lda_corpus
+from tests.test_native_exchange_gpu import ThreadTransport, assert_bit_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def pair(native, oracle, c, K, alpha, beta, seed, zseed):
+    g = native.GGSHandle(K, c.num_types, alpha, beta, seed, flags=native.FLAG_COLLAPSED | native.FLAG_PARANOID)
+    o = oracle.OracleSampler(K, c.num_types, alpha, beta, seed, threads=4)
+    for s in (g, o):
+        s.set_corpus(c.doc_ptr, c.tokens)
+        s.init_z_java_lcg(zseed)
+        s.init_phi()
+    return g, o
+
+
+def same_counts(g, o, tag):
+    assert_bit_equal(g.get_z(), o.get_z(), tag + " z")
+    assert_bit_equal(g.get_type_topic_counts(), o.get_type_topic_counts(), tag + " n_wk")
+    assert_bit_equal(g.get_topic_totals(), o.get_topic_totals(), tag + " n_k")
+    assert_bit_equal(g.get_doc_topic_counts(), o.get_doc_topic_counts(), tag + " n_dk")
+
+
+@pytest.mark.parametrize("K", [3, 20])
+def test_serial_chain_on_cats_is_the_java_loop(native, oracle, cats, K):
+    """plda-cats-test.cfg:18-25 (alpha 5, beta 7, seed 2019) with K = 3 as in the file and K = 20 as BASELINE config 1 asks."""
+    g, o = pair(native, oracle, cats, K, 5.0, 7.0, 2019, 2019)
+    for it in range(3):
+        g.collapsed_serial_sweep(2019, 1)
+        o.collapsed_sweep(2019, 1)
+        same_counts(g, o, "cats K=%d serial sweep %d" % (K, it + 1))
+    g.collapsed_serial_sweep(2019, 4)                       # several sweeps in one call carry the stream on
+    o.collapsed_sweep(2019, 4)
+    same_counts(g, o, "cats K=%d serial sweep 7" % K)
+    g.check_invariants()
+    phi = g.get_phi()                                       # the point estimate (beta + n_wk)/(betaSum + n_k)
+    nwk, nk = o.get_type_topic_counts().astype(np.float64), o.get_topic_totals().astype(np.float64)
+    assert_bit_equal(phi, ((7.0 + nwk) / (7.0 * cats.num_types + nk)).T, "phi point estimate")
+
+
+@pytest.mark.parametrize("K,alpha,beta", [(1, 0.5, 0.1), (7, 0.1, 0.01), (64, 0.05, 0.01), (100, 0.1, 0.01), (130, 1.5, 0.5)])
+def test_serial_chain_on_ragged_corpora(native, oracle, K, alpha, beta):
+    c = random_corpus(60, 200, 50, seed=K, empty_every=7)
+    g, o = pair(native, oracle, c, K, alpha, beta, 11, K)
+    g.collapsed_serial_sweep(0, 3)
+    o.collapsed_sweep(0, 3)
+    same_counts(g, o, "ragged K=%d serial" % K)
+    # a state set with set_z starts a NEW Random(seed) at the first serial sweep
+    z = g.get_z()
+    g2 = native.GGSHandle(K, c.num_types, alpha, beta, 11, flags=native.FLAG_COLLAPSED)
+    o2 = oracle.OracleSampler(K, c.num_types, alpha, beta, 11)
+    for s in (g2, o2):
+        s.set_corpus(c.doc_ptr, c.tokens)
+        s.set_z(z, redraw_phi=True)
+    g2.collapsed_serial_sweep(77, 2)
+    o2.collapsed_sweep(77, 2)
+    same_counts(g2, o2, "ragged K=%d serial after set_z" % K)
+
+
+@pytest.mark.parametrize("K,alpha,beta", [(3, 5.0, 7.0), (7, 0.1, 0.01), (20, 5.0, 7.0), (64, 0.05, 0.01), (100, 0.1, 0.01), (200, 0.1, 0.01), (333, 0.1, 0.01)])
+def test_parallel_schedule_matches_its_restatement(native, oracle, cats, K, alpha, beta):
+    c = cats if K in (3, 20) else random_corpus(301, 500, 150, seed=K, empty_every=7)
+    g, o = pair(native, oracle, c, K, alpha, beta, 42 + K, K)
+    for it in range(3):
+        g.sweep(1)
+        o.collapsed_parallel_sweep(1)
+        same_counts(g, o, "parallel K=%d sweep %d" % (K, it + 1))
+    g.sweep_begin()
+    g.sweep_end()
+    o.collapsed_parallel_sweep(1)
+    same_counts(g, o, "parallel K=%d split sweep" % K)
+    with pytest.raises(native.GGSError) as e:
+        g._chk(g._L.ggs_sample_z_given_phi(g._h, 1))
+    assert e.value.code == native.ERR_UNSUPPORTED
+
+
+def _shard_rank(native, tr, rank, world, whole, K, zseed, sweeps, out, errs):
+    import torch
+    from ldagroupedgibbssampler_amd.sharded import _DevPtr, java_lcg_initial_z
+    try:
+        dev = torch.device("cuda", 0)
+
+        def view(ptr, n, typestr):
+            return torch.as_tensor(_DevPtr(ptr, n, typestr), device=dev)
+
+        def reduce_scatter_i32(send, recv, count, stream):
+            torch.cuda.synchronize()
+            parts = tr.exchange(rank, view(send, count * world, "<i4").cpu().numpy().reshape(world, count))
+            view(recv, count, "<i4").copy_(torch.from_numpy(np.sum([p[rank] for p in parts], axis=0, dtype=np.int32)))
+            torch.cuda.synchronize()
+            return 0
+
+        def all_gather(typestr):
+            def cb(send, recv, count, stream):
+                torch.cuda.synchronize()
+                parts = tr.exchange(rank, view(send, count, typestr).cpu().numpy())
+                view(recv, count * world, typestr).copy_(torch.from_numpy(np.concatenate(parts)))
+                torch.cuda.synchronize()
+                return 0
+            return cb
+
+        b = even_split(whole.num_docs, world)
+        sub, doc_base, tok_base = whole.shard(b[rank], b[rank + 1])
+        h = native.GGSHandle(K, whole.num_types, 0.1, 0.01, 5, flags=native.FLAG_COLLAPSED)
+        h.attach_exchange(rank, world, reduce_scatter_i32, all_gather("<f8"), all_gather("<i4"))
+        h.set_corpus(sub.doc_ptr, sub.tokens, doc_base, tok_base)
+        h.set_global_token_count(whole.num_tokens)
+        h.set_z(java_lcg_initial_z(whole.num_tokens, K, zseed)[tok_base:tok_base + sub.num_tokens], redraw_phi=True)
+        h.sweep(sweeps)
+        h.check_invariants()
+        out[rank] = dict(z=h.get_z(), nwk=h.get_type_topic_counts(), nk=h.get_topic_totals())
+        h.close()
+    except BaseException as e:  # noqa: BLE001
+        errs.append(e)
+        tr.bar.abort()
+
+
+def test_parallel_schedule_doc_sharded_is_ad_lda_with_a_merge_per_sweep(native, oracle):
+    """Two doc shards joined by the exchange (the count slices are reduce-scattered and gathered: the AD-LDA merge,
+    ADLDA.java:302-332) sample exactly what one handle samples: the schedule already conditions on sweep-start counts."""
+    from ldagroupedgibbssampler_amd.sharded import java_lcg_initial_z
+    whole = random_corpus(260, 400, 120, seed=9, empty_every=8)
+    K, world, sweeps = 24, 2, 3
+    tr, out, errs = ThreadTransport(world), [None] * world, []
+    ts = [threading.Thread(target=_shard_rank, args=(native, tr, r, world, whole, K, 3, sweeps, out, errs)) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    if errs:
+        raise errs[0]
+    o = oracle.OracleSampler(K, whole.num_types, 0.1, 0.01, 5, threads=4)
+    o.set_corpus(whole.doc_ptr, whole.tokens)
+    o.set_z(java_lcg_initial_z(whole.num_tokens, K, 3), redraw_phi=True)
+    o.collapsed_parallel_sweep(sweeps)
+    assert_bit_equal(np.concatenate([p["z"] for p in out]), o.get_z(), "sharded collapsed z")
+    for p in out:
+        assert_bit_equal(p["nwk"], o.get_type_topic_counts(), "sharded collapsed n_wk")
+        assert_bit_equal(p["nk"], o.get_topic_totals(), "sharded collapsed n_k")
+
+
+def test_parallel_schedule_heldout_within_one_percent_of_the_serial_chain(native, oracle):
+    """The north_star's "otherwise" clause: the device's parallel collapsed chain against the reference's serial chain
+    (restated), different random streams, on the 1 000-document K=100 slice of the benchmark corpus with 100 held-out
+    documents: left-to-right held-out log likelihood (MarginalProbEstimatorPlain, 100 particles) within +-1 %."""
+    full = synthetic_lda_corpus(1100, 50000, 200, true_topics=100, seed=2019)
+    train, _, _ = full.shard(0, 1000)
+    test, _, _ = full.shard(1000, 1100)
+    K, sweeps = 100, 60
+    g = native.GGSHandle(K, train.num_types, 0.1, 0.01, 2019, flags=native.FLAG_COLLAPSED)
+    g.set_corpus(train.doc_ptr, train.tokens)
+    g.init_z_java_lcg(2019)
+    g.init_phi()
+    g.sweep(sweeps)
+    g.set_test_corpus(test.doc_ptr, test.tokens)
+    ll_dev = g.heldout_log_likelihood(100)[0]
+    o = oracle.OracleSampler(K, train.num_types, 0.1, 0.01, 2019, threads=8)
+    o.set_corpus(train.doc_ptr, train.tokens)
+    o.init_z_java_lcg(2019)
+    o.collapsed_sweep(2019, sweeps)
+    ll_ref = o.heldout_log_likelihood(test.doc_ptr, test.tokens, 100)[0]
+    assert ll_dev < 0 and ll_ref < 0
+    assert abs(ll_dev - ll_ref) <= 0.01 * abs(ll_ref), (ll_dev, ll_ref)
+
+
+def test_python_mirror_serial_collapsed_lda(native, oracle, cats):
+    """create_model(config, "collapsed") -> SerialCollapsedLDA mirror: setRandomSeed / addInstances / sample as
+    tui/ParallelLDA drives them (ParallelLDA.java:173-202); the serial schedule is the restated Java chain."""
+    from ldagroupedgibbssampler_amd.sampler import SimpleLDAConfiguration, create_model
+    cfg = SimpleLDAConfiguration(scheme="collapsed", topics=20, alpha=5.0, beta=7.0, seed=2019, iterations=5, exec_time=1800, start_diagnostic=1,
+                                 compute_likelihood=True)
+    m = create_model(cfg)
+    m.setRandomSeed(2019)
+    m.addInstances(cats)
+    m.sample(5)
+    o = oracle.OracleSampler(20, cats.num_types, 5.0, 7.0, 2019)
+    o.set_corpus(cats.doc_ptr, cats.tokens)
+    o.init_z_java_lcg(2019)
+    o.collapsed_sweep(2019, 5)
+    assert_bit_equal(np.concatenate(m.getZIndicators()), o.get_z(), "mirror z")
+    assert_bit_equal(np.asarray(m.getTypeTopicMatrix()), o.get_type_topic_counts(), "mirror n_wk")
+    assert len(m.loglikelihood) == 5 and m.logPosterior == []
+    ref = sum(o.model_log_likelihood())
+    assert abs(m.loglikelihood[-1] - ref) <= 1e-9 * abs(ref)

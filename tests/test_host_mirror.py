@@ -67,7 +67,8 @@ def test_configuration_defaults_and_registry():
     m = create_model(SimpleLDAConfiguration(topics=3, seed=5))
     assert isinstance(m, LDAGroupedGibbsSampler) and m.getNoTopics() == 3 and m.getStartSeed() == 5
     with pytest.raises(ValueError):
-        create_model(SimpleLDAConfiguration(), "collapsed")
+        create_model(SimpleLDAConfiguration(), "adlda")
+    assert type(create_model(SimpleLDAConfiguration(), "collapsed")).__name__ == "SerialCollapsedLDA"   # ParallelLDA.java:424-428
     with pytest.raises(RuntimeError):
         m.sample(1)                                      # before addInstances
 

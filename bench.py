@@ -94,7 +94,7 @@ def z_kernels(K, scheme):
         return ["pcgs_z_kernel<true>"]
     if scheme == "pcgs":
         return ["pcgs_sliced_kernel<%d>" % kmax] if K <= 192 else ["pcgs_z_kernel<false>"]
-    return ["z_sliced_kernel<%d>" % kmax, "z_hot_kernel<%d>" % kmax] if K <= 192 else ["z_stream_kernel"]
+    return ["z_sliced_kernel<%d>" % kmax, "z_hot_kernel<%d>" % kmax] if K <= 192 else ["z_stream1_kernel"]
 
 
 def row_stats(corpus, K, num_hot):

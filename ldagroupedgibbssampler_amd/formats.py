@@ -17,7 +17,7 @@ output file) -- parity unpinned:
     most three fraction digits, HALF_EVEN on the exact binary value, exponent without a plus sign.
 """
 import os
-from decimal import ROUND_HALF_EVEN, ROUND_HALF_UP, Decimal
+from decimal import ROUND_HALF_EVEN, ROUND_HALF_UP, Decimal, localcontext
 
 import numpy as np
 
@@ -124,7 +124,9 @@ def java_format_fixed(d, digits):
         return "NaN"
     if d in (float("inf"), float("-inf")):
         return "Infinity" if d > 0 else "-Infinity"
-    q = Decimal(repr(d)).quantize(Decimal(1).scaleb(-digits), rounding=ROUND_HALF_UP)
+    with localcontext() as ctx:
+        ctx.prec = 400                                 # 1e300 with six decimals has 307 digits
+        q = Decimal(repr(d)).quantize(Decimal(1).scaleb(-digits), rounding=ROUND_HALF_UP)
     out = format(q, "f")
     if q == 0 and str(d).startswith("-"):
         out = "-" + out.lstrip("-")                    # Java keeps the sign of a negative value that rounds to zero

@@ -9,6 +9,7 @@ import os
 import struct
 
 import numpy as np
+import pytest
 
 from ldagroupedgibbssampler_amd import formats as F
 
@@ -91,3 +92,59 @@ def test_text_logs_and_double_csv(tmp_path):
     assert os.path.basename(fn) == "Phi_KxV_2_3_00005.csv"
     F.write_ascii_double_matrix(np.array([[0.5, 0.25, 0.25], [0.99995, 2e-5, 3e-5]]), fn)
     assert open(fn, newline="").read() == "0.5000,0.2500,0.2500" + os.linesep + "1.0000,20E-6,30E-6" + os.linesep
+
+
+# ---------------------------------------------------------------- the C++ writers (include/ggs_formats.hpp) against the Python ones
+@pytest.fixture(scope="module")
+def formats_demo(tmp_path_factory):
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path_factory.mktemp("fmt") / "ggs_formats_demo")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-Wall", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "examples", "ggs_formats_demo.cpp"), "-o", exe])
+    return exe
+
+
+def test_cpp_text_rules_equal_the_python_ones(formats_demo):
+    """Double.toString, %.4f, %.6f and LDAUtils.formatDouble from C++ on 6 000 values: log-likelihood-sized numbers, probabilities,
+    magnitudes around the 1e-4 / 1e-3 / 1e7 switches, exact decimal ties, denormals, infinities, both zeros."""
+    import subprocess
+    rng = np.random.default_rng(5)
+    vals = np.concatenate([
+        -np.exp(rng.uniform(0, 25, 1500)), rng.random(1500), np.exp(rng.uniform(-30, -5, 1000)), rng.normal(0, 1e7, 500),
+        np.exp(rng.uniform(np.log(5e-5), np.log(2e-4), 300)), np.exp(rng.uniform(np.log(5e-4), np.log(2e-3), 300)),
+        np.exp(rng.uniform(np.log(5e6), np.log(2e7), 300)), (rng.integers(0, 100000, 300) + 0.5) / 10000.0, -(rng.integers(0, 100000, 200) + 0.5) / 1e6,
+        [0.0, -0.0, 1.0, -1.0, 0.1, 0.5, 0.00005, 0.99995, 9.99995, 99.99995, 1e-4, 1e-3, 1e7, 9999999.999999998, 1e22, 1e23, 4.9e-324, 2.2250738585072014e-308,
+         1.7976931348623157e308, float("inf"), float("-inf"), float("nan"), 123456789.0, 0.001, 0.0009999999999999998, -7.0e-5, 12345.678949999999]])
+    inp = "\n".join("%016x" % int(b) for b in vals.view(np.uint64)) + "\n"
+    out = subprocess.run([formats_demo, "text"], input=inp, capture_output=True, text=True, check=True).stdout.splitlines()
+    assert len(out) == vals.size
+    for v, line in zip(vals.tolist(), out):
+        ts, f4, f6, fd = line.split("\t")
+        assert ts == F.java_double_to_string(v), (v, ts)
+        assert f4 == F.java_format_fixed(v, 4), (v, f4)
+        assert f6 == F.java_format_fixed(v, 6), (v, f6)
+        if v == v and v not in (0.0, float("inf"), float("-inf")):
+            assert fd == F.format_double(v), (v, fd)
+
+
+def test_cpp_files_equal_the_python_files(formats_demo, tmp_path):
+    import subprocess
+    cdir, pdir = tmp_path / "c", tmp_path / "p"
+    cdir.mkdir()
+    pdir.mkdir()
+    subprocess.check_call([formats_demo, "files", str(cdir)])
+    im = np.array([[1, -2, 300000], [0, 2147483647, -2147483648]], np.int32)
+    dm = np.array([[0.25, -1.5e-7], [3.14159265358979, 0.0], [1e300, 4.9e-324]])
+    F.write_binary_int_matrix(im, str(pdir / F.binary_matrix_name("N", 2, 3, 12)))
+    F.write_binary_double_matrix(dm, str(pdir / F.binary_matrix_name("phi", 3, 2, 12)))
+    F.write_ascii_int_matrix(im, str(pdir / "ints.csv"))
+    F.write_ascii_double_matrix(dm, F.ascii_matrix_name(str(pdir), "Phi_KxV", 3, 2, 12))
+    F.write_topic_indicators(np.array([0, 2, 2, 5]), np.array([4, 0, 1, 1, 9]), str(pdir), 7)
+    F.append_log_likelihood(str(pdir), 3, -123456.789)
+    F.append_heldout_log_likelihood(str(pdir), 3, -1.0e-5)
+    F.append_log_posterior(str(pdir), 3, -98765.4321987, 1700000000000)
+    names = sorted(os.listdir(pdir))
+    assert names == sorted(os.listdir(cdir)) and len(names) == 8
+    for n in names:
+        assert (cdir / n).read_bytes() == (pdir / n).read_bytes(), n

@@ -7,8 +7,9 @@
 //   cc.mallet.topics.LDASamplerWithPhi (topics/LDASamplerWithPhi.java:5-12)
 //   driver call order                  (topics/tui/ParallelLDA.java:173-296):
 //     ctor(config) -> setRandomSeed -> addInstances -> sample(iterations) -> getters
-// sample() is the per-iteration loop of UncollapsedParallelLDA.sample (UPLDA:645-930) minus the
-// host diagnostics: abort flag, exec_time budget on cumulative z+Phi time, the eight hooks.
+// sample() is the per-iteration loop of UncollapsedParallelLDA.sample (UPLDA:645-930): abort flag, exec_time budget
+// on cumulative z+Phi time, the eight hooks, and the diagnostics that have a device implementation (log posterior,
+// held-out and model log likelihood, topic indicators), written in the Java driver's file formats by ggs_formats.hpp.
 // Errors: the Java code throws IllegalStateException / IllegalArgumentException; here a
 // non-zero C-ABI return becomes ggs::SamplerError carrying the code and ggs_last_error().
 #pragma once
@@ -20,6 +21,9 @@
 #include <string>
 #include <vector>
 
+#include <chrono>
+
+#include "ggs_formats.hpp"
 #include "ggs_hip.h"
 
 namespace ggs {
@@ -43,7 +47,13 @@ struct LDAConfiguration {
   int phi_mean_thin = 1;
   bool paranoid = false;
   bool pcgs = false;              // scheme=pcgs instead of ggs (ParallelLDA.java:414-416): the z step of UPLDA:1466-1544
+  bool collapsed = false;         // scheme=collapsed (ParallelLDA.java:424-428, SerialCollapsedLDA): the serial chain of MSLDA:158-226
   int device_id = 0;
+  // the diagnostics of the sampling loop (UPLDA:695-905), computed on the device, written as the Java driver writes them
+  bool compute_likelihood = false;   // model LL (+ held-out LL with a test set) every iteration, UPLDA:838-850
+  int start_diagnostic = 500;        // START_DIAG_DEFAULT; log posterior from this iteration on, UPLDA:706,818-821
+  bool log_topic_indicators = false; // z_<iteration>.csv, UPLDA:637-638,871-872
+  std::string log_dir;               // where the files go (LoggingUtils' run directory in Java); empty = no files
 };
 
 // integer CSR of the training InstanceList: FeatureSequence.getFeatures() in instance order
@@ -72,7 +82,7 @@ class LDAGroupedGibbsSampler {
     c.alpha = nullptr; c.alpha_scalar = config_.alpha; c.beta = config_.beta;
     c.seed = (uint64_t)(int64_t)startSeed_;
     c.flags = (config_.paranoid ? GGS_FLAG_PARANOID : 0) | (config_.save_phi_mean ? GGS_FLAG_SAVE_PHI_MEAN : 0) |
-              (config_.pcgs ? GGS_FLAG_PCGS : 0);
+              (config_.pcgs ? GGS_FLAG_PCGS : 0) | (config_.collapsed ? GGS_FLAG_COLLAPSED : 0);
     c.phi_burn_in = (int32_t)(((double)config_.phi_mean_burnin / 100) * config_.iterations);   // UPLDA:206-207
     c.phi_mean_thin = config_.phi_mean_thin;
     int rc = ggs_create(&c, &h_);
@@ -94,15 +104,17 @@ class LDAGroupedGibbsSampler {
       ggs_timings t0{}, t1{};
       chk(ggs_get_timings(h_, &t0));
       preZ();
-      chk(ggs_sweep_begin(h_));                                             // loopOverBatches (+ this device's counts)
+      if (config_.collapsed) chk(ggs_collapsed_serial_sweep(h_, startSeed_, 1));   // SerialCollapsedLDA.java:159-172
+      else chk(ggs_sweep_begin(h_));                                        // loopOverBatches (+ this device's counts)
       postZ();
       prePhi();
-      chk(ggs_sweep_end(h_));                                               // samplePhi
+      if (!config_.collapsed) chk(ggs_sweep_end(h_));                       // samplePhi
       postPhi();
       chk(ggs_get_iteration(h_, &currentIteration_));
       chk(ggs_get_timings(h_, &t1));
       zSamplingTimeCum += (t1.theta_ms - t0.theta_ms) + (t1.z_ms - t0.z_ms) + (t1.merge_ms - t0.merge_ms);
       phiSamplingTimeCum += t1.phi_ms - t0.phi_ms;
+      diagnostics(iteration);
       postIteration();
       if (std::ifstream("abort").good()) abort();                           // the sentinel file of UPLDA:131,908-910
       if (zSamplingTimeCum + phiSamplingTimeCum >= maxExecMs) break;        // UPLDA:926-928
@@ -234,6 +246,35 @@ class LDAGroupedGibbsSampler {
     double total = 0;
     chk(ggs_heldout_log_likelihood(h_, numParticles, nullptr, &total));
     return total;
+  }
+
+  // The per-iteration diagnostics of UPLDA:695-905 that have a device implementation, in the Java order; each value is
+  // kept in the Java-named list and, with a log_dir, appended in the Java file format.
+  std::vector<double> loglikelihood, heldOutLoglikelihood, logPosterior;    // MSLDA:114-115; UPLDA:591,843,849
+  void diagnostics(int iteration) {
+    const bool files = !config_.log_dir.empty();
+    if (config_.start_diagnostic > 0 && iteration >= config_.start_diagnostic && !config_.pcgs && !config_.collapsed) {
+      const double lp = computeLogPosterior();                              // UPLDA:818-821
+      logPosterior.push_back(lp);
+      if (files)
+        formats::append_log_posterior(config_.log_dir, iteration, lp,
+                                      std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::system_clock::now().time_since_epoch()).count());
+    }
+    if (config_.compute_likelihood) {
+      if (haveTestSet_) {                                                   // UPLDA:840-844
+        const double ho = heldOutLogLikelihood(100);
+        heldOutLoglikelihood.push_back(ho);
+        if (files) formats::append_heldout_log_likelihood(config_.log_dir, iteration, ho);
+      }
+      const double ll = modelLogLikelihood();                               // UPLDA:846-850
+      loglikelihood.push_back(ll);
+      if (files) formats::append_log_likelihood(config_.log_dir, iteration, ll);
+      if (config_.log_topic_indicators && files) {                          // UPLDA:871-872
+        std::vector<int32_t> z((size_t)N_);
+        chk(ggs_get_z(h_, z.data()));
+        formats::write_topic_indicators(doc_ptr_.data(), D_, z.data(), config_.log_dir, iteration);
+      }
+    }
   }
 
   void abort() { abort_.store(true); }                                      // MSLDA:601-603; may come from another thread

@@ -160,6 +160,42 @@ def test_cpp_mirror_matches_python_path(native, tmp_path):
     assert float(lines["logposterior"]) == sum(g.log_posterior())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("scheme", ["ggs", "collapsed"])
+def test_cpp_mirror_writes_the_java_drivers_files(native, tmp_path, scheme):
+    """The C++ mirror with a log_dir (include/ggs_sampler.hpp + ggs_formats.hpp) leaves the same files as the Python
+    mirror: log-likelihood.txt, test_held_out_log_likelihood.txt, z_<iteration>.csv byte for byte, log-posterior.txt
+    up to its wall-clock column (LDAUtils.java:928-979; UPLDA:945-968)."""
+    exe = os.path.join(ROOT, "examples", "ggs_host_demo")
+    c = random_corpus(40, 70, 50, seed=3, empty_every=6)
+    path = os.path.join(str(tmp_path), "corpus.txt")
+    with open(path, "w") as f:
+        f.write("%d %d\n" % (c.num_docs, c.num_types))
+        for d in range(c.num_docs):
+            t = c.tokens[c.doc_ptr[d]:c.doc_ptr[d + 1]]
+            f.write(" ".join([str(len(t))] + [str(int(x)) for x in t]) + "\n")
+    cdir, pdir = tmp_path / "cpp", tmp_path / "py"
+    cdir.mkdir()
+    pdir.mkdir()
+    K, alpha, beta, seed, its = 5, 0.5, 0.1, 7, 3
+    out = subprocess.run([exe, path, str(K), str(alpha), str(beta), str(seed), str(its), str(cdir), scheme], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    m = create_model(SimpleLDAConfiguration(scheme=scheme, topics=K, alpha=alpha, beta=beta, seed=seed, iterations=its, exec_time=1800, paranoid=True,
+                                            compute_likelihood=True, start_diagnostic=1, log_topic_indicators=True, log_dir=str(pdir)))
+    m.setRandomSeed(seed)
+    m.addInstances(c)
+    m.addTestInstances(c)
+    m.sample(its)
+    names = sorted(os.listdir(pdir))
+    assert names == sorted(os.listdir(cdir))
+    assert ("log-posterior.txt" in names) == (scheme == "ggs") and "z_3.csv" in names and "log-likelihood.txt" in names
+    for n in names:
+        a, b = (cdir / n).read_text(), (pdir / n).read_text()
+        if n == "log-posterior.txt":
+            a, b = ["\t".join(l.split("\t")[:2]) for l in a.splitlines()], ["\t".join(l.split("\t")[:2]) for l in b.splitlines()]
+        assert a == b, n
+
+
 def test_model_log_likelihood_formula():
     """UPLDA:1644-1758 against a direct evaluation of the Dirichlet-multinomial formula
     (UPLDA:1653-1659) on a tiny hand-made state."""

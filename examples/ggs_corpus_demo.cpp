@@ -1,0 +1,38 @@
+// ggs_corpus_demo -- loads a dataset with include/ggs_corpus.hpp and prints it for tests/test_frontend.py:
+//   usage: ggs_corpus_demo dataset.txt stoplist|- rare_threshold keep_numbers(0|1) max_doc_buf_size keep_connectors(0|1)
+//   output: "D V N", then the doc_ptr, the token ids, the label ids (one line each), then V vocabulary lines,
+//           then D name lines.  Exit code 3 + "overflow" on stderr for the tokenizer's ArrayIndexOutOfBoundsException.
+#include <cstdio>
+#include <cstdlib>
+#include <string>
+
+#include "ggs_corpus.hpp"
+
+int main(int argc, char **argv) {
+  if (argc != 7) { std::fprintf(stderr, "usage: %s dataset stoplist|- rare_threshold keep_numbers buf keep_connectors\n", argv[0]); return 2; }
+  ggs::corpus::LoadOptions opt;
+  if (std::string(argv[2]) != "-") opt.stoplist_file = argv[2];
+  opt.prune_count = std::atoi(argv[3]);
+  opt.keep_numbers = std::atoi(argv[4]) != 0;
+  opt.buffer_size = std::atoi(argv[5]);
+  opt.keep_connectors = std::atoi(argv[6]) != 0;
+  try {
+    const ggs::corpus::Dataset ds = ggs::corpus::load_instances_prune(argv[1], opt);
+    std::printf("%lld %zu %zu\n", (long long)ds.size(), ds.vocab.size(), ds.tokens.size());
+    for (int64_t p : ds.doc_ptr) std::printf("%lld ", (long long)p);
+    std::printf("\n");
+    for (int32_t t : ds.tokens) std::printf("%d ", t);
+    std::printf("\n");
+    for (int32_t l : ds.labels) std::printf("%d ", l);
+    std::printf("\n");
+    for (const auto &w : ds.vocab) std::printf("%s\n", w.c_str());
+    for (const auto &n : ds.names) std::printf("%s\n", n.c_str());
+  } catch (const ggs::corpus::TokenBufferOverflow &e) {
+    std::fprintf(stderr, "overflow: %s\n", e.what());
+    return 3;
+  } catch (const std::exception &e) {
+    std::fprintf(stderr, "error: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

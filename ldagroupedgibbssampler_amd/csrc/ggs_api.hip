@@ -86,6 +86,12 @@ struct ggs_handle {
   bool z_split_allowed = true, z_split_tried = false;  // the first z step of a corpus times both forms and keeps the faster
   int32_t hot_wave_lds = 0;
   bool overlap_theta = true;
+  // K > 192: the z step is cut into parts of consecutive documents and the NEXT iteration's theta of a part is drawn
+  // (side stream) while the following parts are still being sampled: the streaming z kernel waits on memory, the theta
+  // draw on the VALU.  The last part's theta runs beside the Phi phase as before.
+  int32_t z_parts = 1, theta_lds_beside_z = 0;
+  std::vector<int64_t> part_doc, part_chunk;           // [z_parts + 1] boundaries
+  hipEvent_t ev_part[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int64_t theta_ahead_iter = INT64_MIN;     // iteration the side-stream theta was drawn for, or none
   double *d_alpha = nullptr, *d_theta = nullptr, *d_phiT = nullptr, *d_mag = nullptr, *d_tot = nullptr, *d_phi_mean = nullptr;
   int32_t *d_n_wk = nullptr, *d_n_k = nullptr;
@@ -344,14 +350,15 @@ int launch_phi(ggs_handle *h, bool initial, bool accumulate_mean, Events *E = nu
   return GGS_OK;
 }
 
-int launch_theta(ggs_handle *h, hipStream_t stream, double *dst, int32_t iteration) {
-  if (h->D == 0) return GGS_OK;
+int launch_theta(ggs_handle *h, hipStream_t stream, double *dst, int32_t iteration, int64_t d0 = 0, int64_t d1 = -1, int32_t lds = 0) {
+  if (d1 < 0) d1 = h->D;
+  if (d1 <= d0) return GGS_OK;
   ThetaParams tp{};
-  tp.doc_ptr = h->d_doc_ptr; tp.z = h->d_z; tp.alpha = h->d_alpha; tp.theta = dst; tp.status = h->d_status;
-  tp.num_docs = h->D; tp.doc_base = h->doc_base; tp.seed = h->seed; tp.iteration = (uint32_t)iteration;
+  tp.doc_ptr = h->d_doc_ptr + d0; tp.z = h->d_z; tp.alpha = h->d_alpha; tp.theta = dst + (size_t)d0 * h->K; tp.status = h->d_status;
+  tp.num_docs = d1 - d0; tp.doc_base = h->doc_base + d0; tp.seed = h->seed; tp.iteration = (uint32_t)iteration;
   tp.K = h->K; tp.docs_per_block = h->theta_docs_per_block;
-  const int64_t grid = (h->D + h->theta_docs_per_block - 1) / h->theta_docs_per_block;
-  hipLaunchKernelGGL(theta_kernel<kThetaBlock>, dim3((unsigned)grid), dim3(kThetaBlock), h->theta_lds, stream, tp);
+  const int64_t grid = (d1 - d0 + h->theta_docs_per_block - 1) / h->theta_docs_per_block;
+  hipLaunchKernelGGL(theta_kernel<kThetaBlock>, dim3((unsigned)grid), dim3(kThetaBlock), lds ? lds : h->theta_lds, stream, tp);
   HIP_TRY(h, hipGetLastError());
   return GGS_OK;
 }
@@ -403,8 +410,10 @@ int launch_pcgs_z(ggs_handle *h) {
   return GGS_OK;
 }
 
-int launch_z(ggs_handle *h, bool force_fused = false) {
+int launch_z(ggs_handle *h, bool force_fused = false, int64_t c0 = 0, int64_t c1 = -1) {
   if (h->C == 0) return GGS_OK;
+  if (c1 < 0) c1 = h->C;
+  if (c1 <= c0) return GGS_OK;
   ZParams zp{};
   zp.tok = h->d_tok; zp.inv_perm = h->d_inv_perm; zp.z = h->d_z; zp.zw = h->d_zw; zp.chunk_start = h->d_chunk_start; zp.chunk_doc = h->d_chunk_doc; zp.chunk_len = h->d_chunk_len;
   zp.theta = h->d_theta; zp.phiT = h->d_phiT; zp.status = h->d_status;
@@ -416,8 +425,11 @@ int launch_z(ggs_handle *h, bool force_fused = false) {
   zp.ct_tok = h->d_ct_tok; zp.ct_idx = h->d_ct_idx; zp.ct_ip = h->d_ct_ip; zp.c_docs = h->d_c_docs; zp.num_cold = h->Cc;
   zp.hot_words = h->d_hot_words; zp.num_hot = h->num_hot; zp.hot_pitch = h->hot_pitch;
   zp.wave_lds = h->wave_lds; zp.hot_off = kSlicedWaves * h->wave_lds; zp.ring_base = h->ring_base;
+  if (!h->z_sliced) {                                  // a range of the chunk table (the one-document chunks are in document order)
+    zp.chunk_start += c0; zp.chunk_doc += c0; zp.chunk_len += c0; zp.num_chunks = c1 - c0;
+  }
   // persistent waves: as many single-wave workgroups as stay resident, each strides the chunk table
-  const dim3 grid((unsigned)std::min<int64_t>(h->C, (int64_t)h->num_cus * h->z_waves_per_cu)), block(64);
+  const dim3 grid((unsigned)std::min<int64_t>(zp.num_chunks, (int64_t)h->num_cus * h->z_waves_per_cu)), block(64);
   const int nt = (h->K + 63) / 64;
   if (h->z_sliced) {
     // one 4-wave workgroup per CU (a wave per SIMD), persistent; the hot-word table fills the LDS the rings leave
@@ -567,17 +579,37 @@ int z_phase(ggs_handle *h) {
     if (t_fused < t_split) h->z_split = false;
     HIP_TRY(h, hipEventRecord(E.e[1], h->stream));          // this sweep's z time: one launch of the form kept
   }
-  if ((rc = launch_z(h))) return rc;
-  HIP_TRY(h, hipEventRecord(E.e[2], h->stream));
   h->theta_ahead_iter = INT64_MIN;
-  if (h->overlap_theta && h->side && h->D > 0) {
-    // theta of iteration t+1 from the z just drawn, concurrent with the counts and the Phi draw
+  const bool ahead = h->overlap_theta && h->side && h->D > 0;
+  const int32_t P = (int32_t)h->part_doc.size() - 1;   // 1 for a small corpus
+  if (ahead && P > 1 && h->z_stream) {
+    // part by part: z of part p on the main stream, then -- beside z of part p + 1 -- theta of iteration t+1 for the
+    // documents of part p on the side stream; the last part's theta runs beside the counts and the Phi draw
     Events &N = h->evs[(h->ev_head + 1) % kEvRing];
-    HIP_TRY(h, hipStreamWaitEvent(h->side, E.e[2], 0));
-    HIP_TRY(h, hipEventRecord(N.th0, h->side));
-    if ((rc = launch_theta(h, h->side, h->d_theta_next, h->iteration + 1))) return rc;
+    for (int32_t p = 0; p < P; ++p) {
+      if ((rc = launch_z(h, false, h->part_chunk[(size_t)p], h->part_chunk[(size_t)p + 1]))) return rc;
+      HIP_TRY(h, hipEventRecord(h->ev_part[p], h->stream));
+      HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_part[p], 0));
+      if (p == 0) HIP_TRY(h, hipEventRecord(N.th0, h->side));
+      if ((rc = launch_theta(h, h->side, h->d_theta_next, h->iteration + 1, h->part_doc[(size_t)p], h->part_doc[(size_t)p + 1],
+                             p + 1 < P ? h->theta_lds_beside_z : 0)))
+        return rc;
+    }
     HIP_TRY(h, hipEventRecord(N.th1, h->side));
+    HIP_TRY(h, hipEventRecord(E.e[2], h->stream));
     h->theta_ahead_iter = (int64_t)h->iteration + 1;
+  } else {
+    if ((rc = launch_z(h))) return rc;
+    HIP_TRY(h, hipEventRecord(E.e[2], h->stream));
+    if (ahead) {
+      // theta of iteration t+1 from the z just drawn, concurrent with the counts and the Phi draw
+      Events &N = h->evs[(h->ev_head + 1) % kEvRing];
+      HIP_TRY(h, hipStreamWaitEvent(h->side, E.e[2], 0));
+      HIP_TRY(h, hipEventRecord(N.th0, h->side));
+      if ((rc = launch_theta(h, h->side, h->d_theta_next, h->iteration + 1))) return rc;
+      HIP_TRY(h, hipEventRecord(N.th1, h->side));
+      h->theta_ahead_iter = (int64_t)h->iteration + 1;
+    }
   }
   if ((rc = launch_count_rebuild(h))) return rc;   // this shard's counts; summed across shards by the caller
   HIP_TRY(h, hipEventRecord(E.e[3], h->stream));
@@ -797,6 +829,27 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     // 14.5 KiB per workgroup: with the CU's LDS handed out to theta workgroups to the last granule it waited for the
     // theta draw to END -- 5 ms at K = 1024).
     h->theta_docs_per_block = B; h->theta_lds = std::max(lds_of(B), (kMaxLdsBytes - 24 * 1024) / 4);
+    // K > 192 (one-pass streaming z kernel): theta workgroups small enough to sit BESIDE the z waves -- three of
+    // them, on the LDS the z waves give up -- so that the next theta of a part of the documents is drawn while the
+    // following parts are sampled (z_phase).  The padded request caps them at three per CU while z runs.
+    if (const char *e = std::getenv("GGS_DEBUG_ZPARTS")) h->z_parts = std::max(1, std::min(8, std::atoi(e)));
+    else h->z_parts = (h->z_stream && !h->z_two_pass && !(h->flags & GGS_FLAG_PCGS)) ? 8 : 1;   // measured at K = 1024: 1 part 18.4 ms per sweep, 2: 18.1, 4: 16.5, 8: 15.9
+    if (h->z_parts > 1 && h->z_stream && !h->z_two_pass) {
+      constexpr int kGranule = 2048;
+      const int kBeside = std::getenv("GGS_DEBUG_BESIDE") ? std::max(1, std::atoi(std::getenv("GGS_DEBUG_BESIDE"))) : 4;   // measured at K = 1024 (sweep): 2 -> 16.9 ms, 3 -> 16.1, 4 -> 15.0, 5 -> 15.0
+      auto alloc_of = [&](int bytes) { return (bytes + kGranule - 1) / kGranule * kGranule; };
+      int Bt = 64;
+      while (Bt > 1 && lds_of(Bt) > 10 * 1024) Bt >>= 1;
+      const int z_alloc = alloc_of(h->z_lds), zw = std::min(h->z_waves_per_cu, (kMaxLdsBytes - kGranule - kBeside * alloc_of(lds_of(Bt))) / z_alloc);
+      if (lds_of(Bt) <= 12 * 1024 && zw >= 2) {
+        h->z_waves_per_cu = zw;
+        h->theta_docs_per_block = Bt;
+        h->theta_lds_beside_z = std::max(lds_of(Bt), (kMaxLdsBytes - kGranule - zw * z_alloc) / kBeside / kGranule * kGranule);
+        h->theta_lds = std::max(lds_of(Bt), (kMaxLdsBytes - 24 * 1024) / 4);
+      } else {
+        h->z_parts = 1;
+      }
+    }
   }
   if (h->z_sliced && (hipFuncSetAttribute(sliced_kernel_for(h->K), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess ||
                       hipFuncSetAttribute(hot_kernel_for(h->K), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess))
@@ -852,6 +905,8 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
                          hipFuncSetAttribute(reinterpret_cast<const void *>(collapsed_serial_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess))
       return bail(rc ? rc : GGS_ERR_HIP);
   }
+  for (auto &e : h->ev_part)
+    if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return bail(GGS_ERR_HIP);
   for (auto &E : h->evs) {
     for (auto &e : E.e)
       if (hipEventCreate(&e) != hipSuccess) return bail(GGS_ERR_HIP);
@@ -892,6 +947,8 @@ void ggs_destroy(ggs_handle *h) {
     delete h->xg;
   }
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  for (auto &e : h->ev_part)
+    if (e) (void)hipEventDestroy(e);
   for (auto &E : h->evs) {
     for (auto &e : E.e)
       if (e) (void)hipEventDestroy(e);
@@ -983,6 +1040,21 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
     if (D) HIP_TRY(h, hipMemcpy(h->d_order, order.data(), sizeof(int32_t) * (size_t)D, hipMemcpyHostToDevice));
   }
   h->D = D; h->N = N; h->C = (int64_t)cstart.size(); h->S = (int64_t)seg_word.size(); h->doc_base = doc_base; h->tok_base = tok_base;
+  {
+    // the parts of the z step (z_phase): consecutive documents with about equal token counts, and their chunk ranges
+    const int32_t P = (h->z_parts > 1 && D >= 64 * h->z_parts) ? h->z_parts : 1;
+    h->part_doc.assign((size_t)P + 1, D); h->part_chunk.assign((size_t)P + 1, (int64_t)cstart.size());
+    h->part_doc[0] = 0; h->part_chunk[0] = 0;
+    int64_t d = 0;
+    size_t c = 0;
+    for (int32_t p = 1; p < P; ++p) {
+      const int64_t want = N * p / P;
+      while (d < D && doc_ptr[d] < want) ++d;
+      while (c < cdoc.size() && cdoc[c] < d) ++c;
+      h->part_doc[(size_t)p] = d; h->part_chunk[(size_t)p] = (int64_t)c;
+    }
+    if (P != h->z_parts) { h->part_doc.resize(2); h->part_chunk.resize(2); h->part_doc[1] = D; h->part_chunk[1] = (int64_t)cstart.size(); }
+  }
   if ((rc = dev_alloc(h, &h->d_doc_ptr, (size_t)D + 1)) || (rc = dev_alloc(h, &h->d_tok, (size_t)N)) || (rc = dev_alloc(h, &h->d_z, (size_t)N)) ||
       (rc = dev_alloc(h, &h->d_theta, (size_t)D * h->K)) || (rc = dev_alloc(h, &h->d_theta_next, (size_t)D * h->K)) || (rc = dev_alloc(h, &h->d_chunk_start, (size_t)h->C)) ||
       (rc = dev_alloc(h, &h->d_chunk_doc, (size_t)h->C)) || (rc = dev_alloc(h, &h->d_chunk_len, (size_t)h->C)) ||

@@ -34,7 +34,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
-MALL_GATHER_PEAK_GBS = 8600.0  # measured Infinity-Cache random-row gather ceiling, same guide
+MALL_GATHER_PEAK_GBS = 8600.0  # measured Infinity-Cache random-row gather ceiling, same guide ("Indexed rows: gather into LDS")
+L2_GATHER_PEAK_GBS = 17800.0   # measured L2-resident row gather, same table (16.8-18.8 TB/s)
 
 
 def algorithmic_bytes_per_token(K):
@@ -108,14 +109,15 @@ def row_stats(corpus, K, num_hot):
     freq = np.bincount(corpus.tokens, minlength=V)
     hot_tokens = int(np.sort(freq)[::-1][:num_hot].sum()) if num_hot > 0 else 0
     row = 8 * (K + (K & 1))
+    gathered = row + (512 if K > 192 else 0)             # the one-pass kernel streams the row once plus one 64-topic group again
     return {
         "compulsory_bytes": int(N * (3 * 4 + 4 + 2 * 4) + D * K * 8 + V * row),
-        "cold_row_bytes": int((N - hot_tokens) * row),
+        "cold_row_bytes": int((N - hot_tokens) * gathered),
         "hot_token_frac": round(hot_tokens / max(N, 1), 4),
     }
 
 
-def roofline_block(corpus, K, scheme, n_local, z_ms, workload, sha, num_hot):
+def roofline_block(corpus, K, scheme, n_local, z_ms, workload, sha, num_hot, z_parts=1):
     """What bounds the dominant kernel (the z step), in three consistent readings:
       achieved / frac    HBM bytes per launch over the launch time against the HBM peak -- from the PMC counters when a
                          profile of this very workload and build is committed (`traffic`), else from the compulsory
@@ -123,12 +125,18 @@ def roofline_block(corpus, K, scheme, n_local, z_ms, workload, sha, num_hot):
       algorithmic        SURVEY 8(d)'s per-token figure x tokens: what a kernel without on-chip reuse would move.  The
                          phiT rows are served from the LDS hot-word table and L2 / Infinity Cache, so this exceeds the
                          HBM peak at K=100 -- it is a statement about reuse, not a fraction of a roofline.
-      cache_gather       cold-row bytes over the launch time against the guide's measured Infinity-Cache random-row
-                         ceiling: the memory-side limit that actually applies to the row gather."""
+      row_gather         phiT row bytes the kernels actually pull into LDS over the launch time, beside the guide's two
+                         measured ceilings for exactly this access pattern (indexed rows gathered into LDS): rows
+                         served by the XCD's L2 and rows served by the Infinity Cache.  The Zipfian head of the
+                         vocabulary hits L2, the tail goes to the Infinity Cache (K=100: phiT is 40 MB) or HBM
+                         (K=1024: 410 MB), so the rate sits between the two: this is the memory-side limit that
+                         applies, and the PMC profile's L2 hit rate says where between."""
     btok = algorithmic_bytes_per_token(K)
     zk = z_kernels(K, scheme)
     rs = row_stats(corpus, K, num_hot)
     traffic, src = measured_traffic(["ggs::" + k.split("<")[0] for k in zk], workload, sha)
+    if traffic is not None:
+        traffic *= z_parts                                   # the profile's counters are per launch; the step is z_parts launches
     secs = z_ms * 1e-3
 
     def gbs(b):
@@ -142,18 +150,21 @@ def roofline_block(corpus, K, scheme, n_local, z_ms, workload, sha, num_hot):
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
         "frac": round(gbs(hbm_bytes) / HBM_PEAK_GBS, 4),
-        "basis": "measured HBM traffic (PMC)" if traffic is not None else "compulsory bytes (lower bound of the HBM traffic; no matching PMC profile)",
+        "basis": ("PMC FETCH_SIZE/WRITE_SIZE of the committed profile of this workload and build: the L2's memory-side traffic, Infinity-Cache hits "
+                  "included (an upper bound of the HBM bytes)") if traffic is not None else "compulsory bytes (lower bound of the HBM traffic; no matching PMC profile)",
         "traffic": traffic,
         "traffic_source": src,
         "compulsory_bytes": rs["compulsory_bytes"],
-        "limiter": ("instruction issue + L2/Infinity-Cache row gather (the sweep is far from the HBM roofline: see cache_gather and profiles/)"
-                    if K <= 192 else "L2/Infinity-Cache/HBM row gather: phiT exceeds the 256 MB Infinity Cache"),
-        "cache_gather": {"cold_row_bytes": rs["cold_row_bytes"], "GBps": gbs(rs["cold_row_bytes"]), "ceiling_GBps": MALL_GATHER_PEAK_GBS,
-                         "frac": round(gbs(rs["cold_row_bytes"]) / MALL_GATHER_PEAK_GBS, 4), "hot_token_frac_in_lds": rs["hot_token_frac"]},
+        "limiter": ("instruction issue + L2/Infinity-Cache row gather (far from the HBM roofline: see row_gather and profiles/)"
+                    if K <= 192 else "L2/Infinity-Cache/HBM row gather latency (one pass over the rows; see row_gather and profiles/)"),
+        "row_gather": {"row_bytes": rs["cold_row_bytes"], "GBps": gbs(rs["cold_row_bytes"]), "l2_ceiling_GBps": L2_GATHER_PEAK_GBS,
+                       "infinity_cache_ceiling_GBps": MALL_GATHER_PEAK_GBS, "frac_of_l2_ceiling": round(gbs(rs["cold_row_bytes"]) / L2_GATHER_PEAK_GBS, 4),
+                       "hot_token_frac_in_lds": rs["hot_token_frac"]},
         "algorithmic": {"bytes_per_token": btok, "bytes_per_launch": alg, "GBps": gbs(alg), "over_hbm_peak": round(gbs(alg) / HBM_PEAK_GBS, 4),
                         "note": "SURVEY 8(d) figure; rows served from LDS/L2/MALL make it exceed the HBM peak -- not a roofline fraction"},
-        "tokens_per_launch": n_local,
-        "avg_launch_ms": round(z_ms, 4),
+        "tokens_per_z_step": n_local,
+        "launches_per_z_step": z_parts,
+        "avg_z_step_ms": round(z_ms, 4),
     }
 
 
@@ -256,7 +267,7 @@ def extra_configs(native, corpus2, args, local_rank, fence, sha):
         workload = workload_string(corpus.num_docs, corpus.num_types, corpus.num_tokens, K, args)
         out[tag] = {"workload": workload, "value": round(corpus.num_tokens * steps / dt / 1e6, 3), "unit": "M tokens/s", "steps": steps,
                     "ms_per_step": round(dt / steps * 1e3, 4), "phase_ms_per_sweep": ph,
-                    "roofline": roofline_block(corpus, K, "ggs", corpus.num_tokens, ph["z_ms"], workload, sha, info.get("num_hot", 0))}
+                    "roofline": roofline_block(corpus, K, "ggs", corpus.num_tokens, ph["z_ms"], workload, sha, info.get("num_hot", 0), info.get("z_parts", 1))}
     return out
 
 
@@ -425,7 +436,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": workload, "parallelism": par},
-            "roofline": roofline_block(r["local"], K, args.scheme, r["n_local"], r["phases"]["z_ms"], workload, sha, r["info"].get("num_hot", 0)),
+            "roofline": roofline_block(r["local"], K, args.scheme, r["n_local"], r["phases"]["z_ms"], workload, sha, r["info"].get("num_hot", 0), r["info"].get("z_parts", 1)),
             "phase_ms_per_sweep": r["phases"],
             "build": {"csrc_sha16": sha},
         }

@@ -259,6 +259,10 @@ int ggs_get_launch_info(ggs_handle *h, int64_t *num_chunks, int32_t *lds_bytes_z
 /* Rows of the z kernels' LDS hot-word table for the current corpus (0 for K > 192 and scheme pcgs): tokens of these
  * words read no phiT row from memory -- bench.py's cold-row byte accounting. */
 int ggs_get_num_hot_words(ggs_handle *h, int32_t *num_hot);
+/* Launches of the z kernel per sweep for the current corpus: 1, or the number of document parts the streaming kernel's
+ * step is cut into (K > 192; the next theta of a part is drawn beside the following parts) -- bench.py scales the
+ * per-launch PMC counters of a profile by it. */
+int ggs_get_z_parts(ggs_handle *h, int32_t *parts);
 /* ---- primitives, exported so the parity tests can pin each layer ----------- */
 int ggs_debug_philox(int32_t device_id, int64_t n, const uint32_t *ctr /*n*4*/, const uint32_t *key /*n*2*/, uint32_t *out /*n*4*/);
 int ggs_debug_math(int32_t device_id, int32_t op /*0 log,1 pow,2 sqrt,3 div*/, int64_t n, const double *x, const double *y, double *out);

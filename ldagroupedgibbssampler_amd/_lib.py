@@ -103,6 +103,7 @@ SIGNATURES = {
     "ggs_check_invariants": (C.c_int, [_vp]),
     "ggs_get_launch_info": (C.c_int, [_vp, _lp, _ip, _ip]),
     "ggs_get_num_hot_words": (C.c_int, [_vp, _ip]),
+    "ggs_get_z_parts": (C.c_int, [_vp, _ip]),
     "ggs_attach_exchange": (C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(GGSExchangeOps)]),
     "ggs_rccl_unique_id": (C.c_int, [_vp]),
     "ggs_attach_rccl": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),

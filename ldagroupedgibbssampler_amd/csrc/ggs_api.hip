@@ -1818,6 +1818,13 @@ int ggs_get_num_hot_words(ggs_handle *h, int32_t *num_hot) {
   return GGS_OK;
 }
 
+int ggs_get_z_parts(ggs_handle *h, int32_t *parts) {
+  if (!h || !parts) return GGS_ERR_BAD_ARG;
+  const int32_t P = (int32_t)h->part_doc.size() - 1;
+  *parts = (h->z_stream && h->overlap_theta && P > 1 && !(h->flags & GGS_FLAG_PCGS)) ? P : 1;
+  return GGS_OK;
+}
+
 int ggs_java_lcg_next_ints(int32_t seed, int32_t bound, int64_t n, int32_t *out) {
   if (bound <= 0 || n < 0 || (n > 0 && !out)) return GGS_ERR_BAD_ARG;
   java_lcg_next_ints(seed, bound, n, out);

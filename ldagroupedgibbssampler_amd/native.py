@@ -278,10 +278,11 @@ class GGSHandle:
         return tot.value, doc_ll
 
     def launch_info(self):
-        c, l, b, nh = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32()
+        c, l, b, nh, zp = C.c_int64(), C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         self._chk(self._L.ggs_get_launch_info(self._h, C.byref(c), C.byref(l), C.byref(b)))
         self._chk(self._L.ggs_get_num_hot_words(self._h, C.byref(nh)))
-        return {"num_chunks": c.value, "lds_bytes_z": l.value, "docs_per_block_theta": b.value, "num_hot": nh.value}
+        self._chk(self._L.ggs_get_z_parts(self._h, C.byref(zp)))
+        return {"num_chunks": c.value, "lds_bytes_z": l.value, "docs_per_block_theta": b.value, "num_hot": nh.value, "z_parts": zp.value}
 
 
 class GGSGroup:

@@ -92,7 +92,7 @@ def measured_traffic(kernel_prefixes, workload, sha):
 def z_kernels(K, scheme):
     kmax = 8 * ((K + 7) // 8)
     if scheme == "collapsed":
-        return ["pcgs_z_kernel<true>"]
+        return ["pcgs_sliced_kernel<%d, true>" % kmax] if K <= 192 else ["pcgs_z_kernel<true>"]
     if scheme == "pcgs":
         return ["pcgs_sliced_kernel<%d>" % kmax] if K <= 192 else ["pcgs_z_kernel<false>"]
     return ["z_sliced_kernel<%d>" % kmax, "z_hot_kernel<%d>" % kmax] if K <= 192 else ["z_stream1_kernel"]

@@ -382,6 +382,15 @@ int launch_theta(ggs_handle *h, hipStream_t stream, double *dst, int32_t iterati
 const void *sliced_kernel_for(int K) { GGS_KMAX_SWITCH(z_sliced_kernel) }
 const void *hot_kernel_for(int K) { GGS_KMAX_SWITCH(z_hot_kernel) }
 const void *pcgs_kernel_for(int K) { GGS_KMAX_SWITCH(pcgs_sliced_kernel) }
+const void *collapsed_kernel_for(int K) {
+  switch ((K + 7) / 8) {
+#define GGS_CK(N) case N: return reinterpret_cast<const void *>(pcgs_sliced_kernel<8 * N, true>);
+    GGS_CK(1) GGS_CK(2) GGS_CK(3) GGS_CK(4) GGS_CK(5) GGS_CK(6) GGS_CK(7) GGS_CK(8) GGS_CK(9) GGS_CK(10) GGS_CK(11) GGS_CK(12)
+    GGS_CK(13) GGS_CK(14) GGS_CK(15) GGS_CK(16) GGS_CK(17) GGS_CK(18) GGS_CK(19) GGS_CK(20) GGS_CK(21) GGS_CK(22) GGS_CK(23)
+#undef GGS_CK
+    default: return reinterpret_cast<const void *>(pcgs_sliced_kernel<192, true>);
+  }
+}
 
 int launch_pcgs_z(ggs_handle *h) {
   if (h->N == 0) return GGS_OK;
@@ -399,7 +408,12 @@ int launch_pcgs_z(ggs_handle *h) {
     pp.n_wk = h->d_n_wk; pp.n_k = h->d_n_k; pp.beta = h->beta; pp.beta_sum = h->beta * (double)h->V;   // betaSum = beta * numTypes, MSLDA:136
     hipLaunchKernelGGL(psi_kernel, dim3(grid_for((int64_t)h->K * h->V, 256, 2)), dim3(256), 0, h->stream, h->d_n_wk, h->d_n_k, pp.beta, pp.beta_sum, h->d_phiT,
                        h->K, h->Kp, h->V);
-    hipLaunchKernelGGL(pcgs_z_kernel<true>, grid, block, (size_t)h->pcgs_lds, h->stream, pp);
+    if (h->pcgs_sliced) {
+      void *args[] = {&pp};
+      HIP_TRY(h, hipLaunchKernel(collapsed_kernel_for(h->K), grid, block, args, (size_t)h->pcgs_lds, h->stream));
+    } else {
+      hipLaunchKernelGGL(pcgs_z_kernel<true>, grid, block, (size_t)h->pcgs_lds, h->stream, pp);
+    }
   } else if (h->pcgs_sliced) {
     void *args[] = {&pp};
     HIP_TRY(h, hipLaunchKernel(pcgs_kernel_for(h->K), grid, block, args, (size_t)h->pcgs_lds, h->stream));
@@ -887,7 +901,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
   if (h->flags & GGS_FLAG_PCGS) {
     // pcgs_z_kernel: slice ring + alpha row + int16 [KT][64] document counts per single-wave workgroup
     const int ns = std::max(kPcgsRingSlots - 1, (h->K + kSliceTopics - 1) / kSliceTopics), kt = ns * kSliceTopics;
-    h->pcgs_sliced = h->K <= kSlicedMaxTopics && !h->collapsed;   // the count form runs in the two-pass kernel
+    h->pcgs_sliced = h->K <= kSlicedMaxTopics;
     if (const char *e = std::getenv("GGS_DEBUG_PCGS_STREAM")) h->pcgs_sliced = h->pcgs_sliced && std::atoi(e) == 0;
     if (h->pcgs_sliced) {
       const int kmax = ((h->K + 7) / 8) * 8;                       // alpha row + counts below the ring (pcgs_sliced_kernel's kHead)
@@ -897,8 +911,8 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     }
     if (h->pcgs_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);
     h->pcgs_waves_per_cu = std::max(1, std::min(8, (kMaxLdsBytes - 2048) / ((h->pcgs_lds + 2047) / 2048 * 2048)));   // never a CU filled to the last granule (see z_waves_per_cu)
-    if (hipFuncSetAttribute(h->pcgs_sliced ? pcgs_kernel_for(h->K) : h->collapsed ? reinterpret_cast<const void *>(pcgs_z_kernel<true>)
-                                                                                   : reinterpret_cast<const void *>(pcgs_z_kernel<false>),
+    if (hipFuncSetAttribute(h->pcgs_sliced ? (h->collapsed ? collapsed_kernel_for(h->K) : pcgs_kernel_for(h->K))
+                                           : h->collapsed ? reinterpret_cast<const void *>(pcgs_z_kernel<true>) : reinterpret_cast<const void *>(pcgs_z_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess)
       return bail(GGS_ERR_HIP);
     if (h->collapsed && ((rc = dev_alloc(h, &h->d_lcg, 2)) ||

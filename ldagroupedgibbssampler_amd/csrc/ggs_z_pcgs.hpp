@@ -93,17 +93,24 @@ __global__ __launch_bounds__(64) void pcgs_z_kernel(PcgsParams p) {
     int gs = 0;                                                    // ring slot of this step's first slice
 #pragma unroll
     for (int s = 0; s < kAhead; ++s) issue_slice(s, s, ra);
+    // the token's old topic and (COLLAPSED) psi of that topic with the token itself removed (MSLDA:185-190), both
+    // fetched one step ahead: z[beg + t + 1] is not written before step t + 1, the counts are the sweep-start ones
+    int znext = len > 0 ? p.z[beg] : 0;
+    auto own_of = [&](const int word, const int topic) {
+      return (p.beta + (double)(p.n_wk[(size_t)word * K + topic] - 1)) / (p.beta_sum + (double)(p.n_k[topic] - 1));
+    };
+    double own_next = (COLLAPSED && len > 0) ? own_of(w, znext) : 0.0;
 
     for (int t = 0; t < steps; ++t) {
       const bool active = t < len, has1 = t + 1 < steps;
-      const int zold = active ? p.z[beg + t] : 0;
+      const int zold = znext;
+      const double own = own_next;
       const int ip = active ? p.inv_perm[beg + t] : 0;
       const int w1 = (t + 1 < len) ? p.tok[beg + t + 1] : 0;
+      znext = (t + 1 < len) ? p.z[beg + t + 1] : 0;
+      if (COLLAPSED && t + 1 < len) own_next = own_of(w1, znext);
       if (has1) row_addresses(w1, ran);
       if (active) cnt[zold * 64 + lane] -= 1;                      // UPLDA:1494 (a count below zero cannot arise: it was built from z above)
-      double own = 0.0;                                            // COLLAPSED: psi of the old topic with this token removed (MSLDA:185-190)
-      if (COLLAPSED && active)
-        own = (p.beta + (double)(p.n_wk[(size_t)w * K + zold] - 1)) / (p.beta_sum + (double)(p.n_k[zold] - 1));
       asm volatile("" ::: "memory");
 
       double sum = 0.0, tt = 0.0;
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(64) void pcgs_z_kernel(PcgsParams p) {
 // offset as the DMA immediate (the ring therefore starts above the alpha row and the counts).
 namespace ggs {
 
-template <int KMAX>
+template <int KMAX, bool COLLAPSED = false>
 __global__ __launch_bounds__(64) void pcgs_sliced_kernel(PcgsParams p) {
   constexpr int NS = (KMAX + kSliceTopics - 1) / kSliceTopics;
   constexpr int kAhead = NS < kPcgsRingSlots - 1 ? NS : kPcgsRingSlots - 1;
@@ -247,13 +254,21 @@ __global__ __launch_bounds__(64) void pcgs_sliced_kernel(PcgsParams p) {
     row_addresses(w, ra);
     int gs = 0;
     static_for<0, kAhead>([&](auto sc) { issue_slice(sc, decltype(sc)::value % kPcgsRingSlots, ra); });
+    int znext = len > 0 ? p.z[beg] : 0;                            // old topic and (COLLAPSED) its own-token psi, one step ahead (see pcgs_z_kernel)
+    auto own_of = [&](const int word, const int topic) {
+      return (p.beta + (double)(p.n_wk[(size_t)word * K + topic] - 1)) / (p.beta_sum + (double)(p.n_k[topic] - 1));
+    };
+    double own_next = (COLLAPSED && len > 0) ? own_of(w, znext) : 0.0;
 
     for (int t = 0; t < steps; ++t) {
       const bool active = t < len, has1 = t + 1 < steps;
       gs = __builtin_amdgcn_readfirstlane(gs);
-      const int zold = active ? p.z[beg + t] : 0;
+      const int zold = znext;
+      const double own = own_next;
       const int ip = active ? p.inv_perm[beg + t] : 0;
       const int w1 = (t + 1 < len) ? p.tok[beg + t + 1] : 0;
+      znext = (t + 1 < len) ? p.z[beg + t + 1] : 0;
+      if (COLLAPSED && t + 1 < len) own_next = own_of(w1, znext);
       if (has1) row_addresses(w1, ran);
       if (active) cnt[zold * 64 + lane] -= 1;                      // UPLDA:1494
       asm volatile("" ::: "memory");
@@ -280,6 +295,14 @@ __global__ __launch_bounds__(64) void pcgs_sliced_kernel(PcgsParams p) {
               n[2 * u] = my_cnt[(s * kSliceTopics + 2 * u) * 64];
               n[2 * u + 1] = my_cnt[(s * kSliceTopics + 2 * u + 1) * 64];
             }
+          if constexpr (COLLAPSED) {
+            const int rel = zold - s * kSliceTopics;               // position of the old topic inside this slice, if any
+#pragma unroll
+            for (int u = 0; u < kSliceUnits; ++u) {
+              if (rel == 2 * u) ph[u].a = own;
+              if (rel == 2 * u + 1) ph[u].b = own;
+            }
+          }
 #pragma unroll
           for (int u = 0; u < kSliceUnits; ++u) {
             constexpr int k0 = s * kSliceTopics;

@@ -198,3 +198,15 @@ def test_python_mirror_serial_collapsed_lda(native, oracle, cats):
     assert len(m.loglikelihood) == 5 and m.logPosterior == []
     ref = sum(o.model_log_likelihood())
     assert abs(m.loglikelihood[-1] - ref) <= 1e-9 * abs(ref)
+
+
+def test_parallel_schedule_two_pass_kernel_below_193_topics(native, oracle, monkeypatch):
+    """K <= 192 normally keeps the token's scores in registers (pcgs_sliced_kernel<KMAX, true>); GGS_DEBUG_PCGS_STREAM=1
+    forces the two-pass kernel that larger K use (pcgs_z_kernel<true>) -- same draws either way."""
+    monkeypatch.setenv("GGS_DEBUG_PCGS_STREAM", "1")
+    c = random_corpus(200, 300, 90, seed=4, empty_every=6)
+    g, o = pair(native, oracle, c, 50, 0.1, 0.01, 8, 2)
+    monkeypatch.delenv("GGS_DEBUG_PCGS_STREAM")
+    g.sweep(3)
+    o.collapsed_parallel_sweep(3)
+    same_counts(g, o, "collapsed two-pass K=50")

@@ -11,6 +11,7 @@
  * (IllegalStateException for GGS:84-85,116-118; IllegalArgumentException for bad arguments).
  */
 #include <jni.h>
+#include <stdlib.h>
 #include "ggs_hip.h"
 
 #define H(h) ((ggs_handle *)(intptr_t)(h))
@@ -105,4 +106,69 @@ JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSetTestC
 }
 JNIEXPORT jdouble JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nHeldOutLogLikelihood(JNIEnv *env, jclass c, jlong h, jint particles) {
   double total = 0; CHECK(H(h), ggs_heldout_log_likelihood(H(h), particles, 0, &total)); return total;   /* MPE:85-121 */
+}
+
+/* ---- one JVM, n GPUs: the group entry points (include/ggs_hip.h, "multi-GPU"); handles travel as a long[] ---------- */
+static ggs_handle **handles_of(JNIEnv *env, jlongArray hs, jsize *n, jlong **raw) {
+  *n = (*env)->GetArrayLength(env, hs);
+  *raw = (*env)->GetLongArrayElements(env, hs, 0);
+  ggs_handle **out = (ggs_handle **)malloc(sizeof(ggs_handle *) * (size_t)*n);
+  for (jsize i = 0; i < *n; i++) out[i] = H((*raw)[i]);
+  return out;
+}
+JNIEXPORT jlongArray JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIPMulti_nGroupCreate(JNIEnv *env, jclass c, jint K, jint V,
+    jdoubleArray alpha, jdouble beta, jlong seed, jintArray deviceIds, jint flags, jint burnIn, jint thin) {
+  ggs_config cfg = {0};
+  jsize n = (*env)->GetArrayLength(env, deviceIds);
+  jint *dev = (*env)->GetIntArrayElements(env, deviceIds, 0);
+  jdouble *a = (*env)->GetDoubleArrayElements(env, alpha, 0);
+  ggs_handle **hs = (ggs_handle **)calloc((size_t)n, sizeof(ggs_handle *));
+  cfg.struct_size = (int32_t)sizeof cfg; cfg.num_topics = K; cfg.num_types = V; cfg.alpha = a; cfg.beta = beta; cfg.seed = (uint64_t)seed;
+  cfg.flags = flags; cfg.phi_burn_in = burnIn; cfg.phi_mean_thin = thin;
+  int rc = ggs_group_create(&cfg, n, (const int32_t *)dev, hs);      /* ncclCommInitAll over the listed devices */
+  (*env)->ReleaseDoubleArrayElements(env, alpha, a, JNI_ABORT);
+  (*env)->ReleaseIntArrayElements(env, deviceIds, dev, JNI_ABORT);
+  jlongArray out = (*env)->NewLongArray(env, n);
+  if (rc) { free(hs); throw_for(env, 0, rc); return out; }
+  for (jsize i = 0; i < n; i++) { jlong v = (jlong)(intptr_t)hs[i]; (*env)->SetLongArrayRegion(env, out, i, 1, &v); }
+  free(hs);
+  return out;
+}
+JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIPMulti_nGroupDestroy(JNIEnv *env, jclass c, jlongArray hs) {
+  jsize n; jlong *raw; ggs_handle **h = handles_of(env, hs, &n, &raw);
+  ggs_group_destroy(h, n);
+  free(h); (*env)->ReleaseLongArrayElements(env, hs, raw, JNI_ABORT);
+}
+/* z: the corpus-wide topic indicators in (document, position) order; shardTokBase[i] .. shardTokBase[i+1] is shard i's slice */
+JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIPMulti_nGroupSetZ(JNIEnv *env, jclass c, jlongArray hs, jintArray z,
+    jlongArray shardTokBase, jboolean redraw) {
+  jsize n; jlong *raw; ggs_handle **h = handles_of(env, hs, &n, &raw);
+  jint *zp = (*env)->GetIntArrayElements(env, z, 0);
+  jlong *base = (*env)->GetLongArrayElements(env, shardTokBase, 0);
+  const int32_t **parts = (const int32_t **)malloc(sizeof(int32_t *) * (size_t)n);
+  for (jsize i = 0; i < n; i++) parts[i] = (const int32_t *)zp + base[i];
+  int rc = ggs_group_set_z(h, n, parts, redraw ? 1 : 0);
+  free(parts);
+  (*env)->ReleaseLongArrayElements(env, shardTokBase, base, JNI_ABORT);
+  (*env)->ReleaseIntArrayElements(env, z, zp, JNI_ABORT);
+  if (rc) throw_for(env, h[0], rc);
+  free(h); (*env)->ReleaseLongArrayElements(env, hs, raw, JNI_ABORT);
+}
+JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIPMulti_nGroupSweep(JNIEnv *env, jclass c, jlongArray hs, jint sweeps) {
+  jsize n; jlong *raw; ggs_handle **h = handles_of(env, hs, &n, &raw);
+  int rc = ggs_group_sweep(h, n, sweeps);              /* loopOverBatches + updateCounts + samplePhi for every device, collectives grouped */
+  if (rc) throw_for(env, h[0], rc);
+  free(h); (*env)->ReleaseLongArrayElements(env, hs, raw, JNI_ABORT);
+}
+JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIPMulti_nSetGlobalTokenCount(JNIEnv *env, jclass c, jlong h, jlong n) {
+  CHECK(H(h), ggs_set_global_token_count(H(h), n));
+}
+
+/* ---- scheme=collapsed (SerialCollapsedLDA): the seeded start and the serial chain share ONE Randoms(seed) ---------- */
+JNIEXPORT void JNICALL Java_cc_mallet_topics_SerialCollapsedLDAHIP_nInitZJavaLcg(JNIEnv *env, jclass c, jlong h, jint seed) {
+  CHECK(H(h), ggs_init_z_java_lcg(H(h), seed));        /* SerialCollapsedLDA.java:789, continued by the sweeps (MSLDA:206) */
+  CHECK(H(h), ggs_init_phi(H(h)));
+}
+JNIEXPORT void JNICALL Java_cc_mallet_topics_SerialCollapsedLDAHIP_nCollapsedSerialSweep(JNIEnv *env, jclass c, jlong h, jint seed, jint sweeps) {
+  CHECK(H(h), ggs_collapsed_serial_sweep(H(h), seed, sweeps));   /* SerialCollapsedLDA.java:159-172 */
 }

@@ -73,6 +73,40 @@ def test_one_rank_through_rccl(native, oracle, scheme, K):
     h.close()
 
 
+def test_callers_own_communicator(native, oracle):
+    """ggs_attach_rccl_comm: the communicator is the caller's (here made with ncclCommInitRank through ctypes on the
+    process's librccl) and is not destroyed with the handle."""
+    import ctypes as C
+    from ldagroupedgibbssampler_amd import _lib
+    _lib.share_rccl_with_torch()
+    try:
+        rccl = C.CDLL("librccl.so.1")
+    except OSError:
+        rccl = C.CDLL("/opt/rocm/lib/librccl.so.1")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+    uid, comm = UniqueId(), C.c_void_p()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    import torch
+    torch.cuda.set_device(0)
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    c = random_corpus(120, 300, 80, seed=21, empty_every=7)
+    K = 30
+    h = native.GGSHandle(K, c.num_types, 0.1, 0.01, 5)
+    h._chk(h._L.ggs_attach_rccl_comm(h._h, 0, 1, comm))
+    h.set_corpus(c.doc_ptr, c.tokens)
+    h.set_z(java_lcg_initial_z(c.num_tokens, K, 4), redraw_phi=True)
+    h.sweep(2)
+    o = reference_run(oracle, c, K, 0.1, 0.01, 5, 4, 2)
+    assert_bit_equal(h.get_z(), o.get_z(), "z")
+    assert_bit_equal(h.get_phi(), o.get_phi(), "phi")
+    h.close()
+    rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+    assert rccl.ncclCommDestroy(comm) == 0           # still alive: the library did not destroy what it does not own
+
+
 class ThreadTransport:
     """In-memory collectives between handles driven by threads of one process."""
 

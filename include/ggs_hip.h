@@ -231,6 +231,11 @@ int ggs_group_create(const ggs_config *cfg, int32_t n, const int32_t *device_ids
 void ggs_group_destroy(ggs_handle **handles, int32_t n);
 int ggs_group_set_z(ggs_handle **handles, int32_t n, const int32_t *const *z /* n pointers, each shard's N */, int32_t redraw_phi);
 int ggs_group_sweep(ggs_handle **handles, int32_t n, int32_t n_sweeps);
+/* Corpus-wide counts onto every handle of the group.  The per-handle getters that need them (ggs_get_type_topic_counts,
+ * ggs_get_topic_totals, ggs_check_invariants, the log likelihoods) would each start a collective of their own --
+ * from one thread, for one device at a time, that cannot complete -- so a one-process driver calls this first; the
+ * getters then find the counts in place.  (GGS_FLAG_PARANOID's per-sweep check is not run by ggs_group_sweep.) */
+int ggs_group_gather_counts(ggs_handle **handles, int32_t n);
 /* Timing aid, NOT a sampler: behaves as rank `rank` of `nranks` with the peers' contributions missing (the collectives
  * become local copies), so that one GPU can time the per-rank compute phases of an N-GPU split.  Counts and Phi are
  * then wrong by construction (ggs_check_invariants fails). */

@@ -33,6 +33,7 @@ public class LDAGroupedGibbsSamplerHIPMulti extends LDAGroupedGibbsSampler {
 	private static native void nGroupDestroy(long[] handles);
 	private static native void nGroupSetZ(long[] handles, int[] z, long[] shardTokBase, boolean redrawPhi);
 	private static native void nGroupSweep(long[] handles, int sweeps);
+	private static native void nGroupGatherCounts(long[] handles);
 	private static native void nSetGlobalTokenCount(long h, long n);
 	// per-handle calls shared with the one-GPU subclass (integration/jni/ggs_jni.c)
 	private static native void nSetCorpus(long h, long[] docPtr, int[] tokens, long docBase, long tokBase);
@@ -87,8 +88,10 @@ public class LDAGroupedGibbsSamplerHIPMulti extends LDAGroupedGibbsSampler {
 	@Override protected void updateCounts() { /* inside nGroupSweep: the reduce-scatter of the count slices */ }
 	@Override protected void samplePhi() { /* inside nGroupSweep: the Phi draw of each GPU's topic slice + the all-gather */ }
 
-	/** Device state into the Java fields the diagnostics read; the corpus-wide getters are collective: every handle, rank order. */
+	/** Device state into the Java fields the diagnostics read.  The counts live as topic slices on the GPUs: one grouped
+	 *  gather first (a getter of a single handle would start a collective that one thread cannot complete). */
 	void syncToJava() {
+		nGroupGatherCounts(handles);
 		for (int r = 0; r < handles.length; r++) {
 			int[] z = new int[(int) (shardTokBase[r + 1] - shardTokBase[r])];
 			nGetZ(handles[r], z);
@@ -101,13 +104,13 @@ public class LDAGroupedGibbsSamplerHIPMulti extends LDAGroupedGibbsSampler {
 			p += z.length;
 		}
 		int[] nwk = new int[numTypes * numTopics];
-		for (long h : handles) nGetTypeTopicCounts(h, nwk);          // identical on every rank after the gather
+		nGetTypeTopicCounts(handles[0], nwk);                        // identical on every rank after the gather
 		for (int w = 0; w < numTypes; w++)
 			for (int k = 0; k < numTopics; k++) {
 				typeTopicCounts[w][k] = nwk[w * numTopics + k];
 				topicTypeCountMapping[k][w] = nwk[w * numTopics + k];
 			}
-		for (long h : handles) nGetTopicTotals(h, tokensPerTopic);
+		nGetTopicTotals(handles[0], tokensPerTopic);
 		double[] flatPhi = new double[numTopics * numTypes];
 		nGetPhi(handles[0], flatPhi);                                // Phi is replicated: any rank
 		for (int k = 0; k < numTopics; k++) System.arraycopy(flatPhi, k * numTypes, phi[k], 0, numTypes);

@@ -160,6 +160,12 @@ JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIPMulti_nGro
   if (rc) throw_for(env, h[0], rc);
   free(h); (*env)->ReleaseLongArrayElements(env, hs, raw, JNI_ABORT);
 }
+JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIPMulti_nGroupGatherCounts(JNIEnv *env, jclass c, jlongArray hs) {
+  jsize n; jlong *raw; ggs_handle **h = handles_of(env, hs, &n, &raw);
+  int rc = ggs_group_gather_counts(h, n);
+  if (rc) throw_for(env, h[0], rc);
+  free(h); (*env)->ReleaseLongArrayElements(env, hs, raw, JNI_ABORT);
+}
 JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIPMulti_nSetGlobalTokenCount(JNIEnv *env, jclass c, jlong h, jlong n) {
   CHECK(H(h), ggs_set_global_token_count(H(h), n));
 }

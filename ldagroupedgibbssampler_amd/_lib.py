@@ -112,6 +112,7 @@ SIGNATURES = {
     "ggs_group_destroy": (None, [C.POINTER(_vp), C.c_int32]),
     "ggs_group_set_z": (C.c_int, [C.POINTER(_vp), C.c_int32, C.POINTER(_ip), C.c_int32]),
     "ggs_group_sweep": (C.c_int, [C.POINTER(_vp), C.c_int32, C.c_int32]),
+    "ggs_group_gather_counts": (C.c_int, [C.POINTER(_vp), C.c_int32]),
     "ggs_attach_null_exchange": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "ggs_get_exchange_info": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
     "ggs_debug_philox": (C.c_int, [C.c_int32, C.c_int64, _up, _up, _up]),

@@ -255,19 +255,26 @@ int exchange_reduce_scatter(ggs_handle *h) {
   return rc;
 }
 
-// Corpus-wide counts in d_n_wk: with an exchange, gathered from the ranks' slices on demand (a COLLECTIVE call).
-int ensure_global_counts(ggs_handle *h) {
-  if (!h->xg || h->counts_global) return GGS_OK;
-  int rc;
-  if ((rc = exchange_reduce_scatter(h))) return rc;
+// Corpus-wide counts in d_n_wk: with an exchange, gathered from the ranks' slices on demand (a COLLECTIVE call).  In
+// steps, so that a one-process group can issue each collective for all of its devices inside ncclGroupStart/End.
+int gather_counts_step_gather(ggs_handle *h) {
   const size_t cells = (size_t)h->xg->nranks * h->V * h->Ksm;
+  int rc;
   if (!h->d_cnt_all && (rc = dev_alloc(h, &h->d_cnt_all, cells))) return rc;
-  if ((rc = xcall(h, h->xg->ops.all_gather_i32(h->xg->ops.ctx, h->d_cnt_own, h->d_cnt_all, (int64_t)h->V * h->Ksm, h->stream), "all_gather_i32"))) return rc;
+  return xcall(h, h->xg->ops.all_gather_i32(h->xg->ops.ctx, h->d_cnt_own, h->d_cnt_all, (int64_t)h->V * h->Ksm, h->stream), "all_gather_i32");
+}
+int gather_counts_step_unslice(ggs_handle *h) {
   hipLaunchKernelGGL(counts_unslice_kernel, dim3(grid_for((int64_t)h->K * h->V, 256)), dim3(256), 0, h->stream, h->d_cnt_all, h->d_koff, h->Ksm, h->d_n_wk,
                      h->K, h->V);
   HIP_TRY(h, hipGetLastError());
   h->counts_global = true; h->n_k_valid = false;
   return GGS_OK;
+}
+int ensure_global_counts(ggs_handle *h) {
+  if (!h->xg || h->counts_global) return GGS_OK;
+  int rc;
+  if ((rc = exchange_reduce_scatter(h)) || (rc = gather_counts_step_gather(h))) return rc;
+  return gather_counts_step_unslice(h);
 }
 
 // tokensPerTopic (and the Dirichlet magnitudes) of the corpus-wide counts
@@ -1437,6 +1444,34 @@ int group_phi(ggs_handle **hs, int32_t n, bool initial, bool in_sweep) {
 }
 }  // namespace
 
+namespace {
+// corpus-wide counts on every handle of the group: the two collectives of ensure_global_counts, each grouped
+int group_gather_counts(ggs_handle **hs, int32_t n) {
+  RcclApi *api = hs[0]->xg->api;
+  auto grouped = [&](auto step) {
+    int r = GGS_OK;
+    api->GroupStart();
+    for (int32_t i = 0; i < n && !r; ++i) {
+      if ((r = bind_device(hs[i]))) break;
+      if (!hs[i]->counts_global) r = step(hs[i]);
+    }
+    if (api->GroupEnd() != ncclSuccess && !r) r = set_err(hs[0], GGS_ERR_HIP, "ncclGroupEnd failed");
+    return r;
+  };
+  int rc;
+  if ((rc = grouped([](ggs_handle *h) { return exchange_reduce_scatter(h); }))) return rc;
+  if ((rc = grouped([](ggs_handle *h) { return gather_counts_step_gather(h); }))) return rc;
+  for (int32_t i = 0; i < n; ++i)
+    if (!hs[i]->counts_global && ((rc = bind_device(hs[i])) || (rc = gather_counts_step_unslice(hs[i])))) return rc;
+  return GGS_OK;
+}
+}  // namespace
+
+int ggs_group_gather_counts(ggs_handle **hs, int32_t n) {
+  if (!is_group(hs, n)) return GGS_ERR_BAD_ARG;
+  return group_gather_counts(hs, n);
+}
+
 int ggs_group_create(const ggs_config *cfg, int32_t n, const int32_t *device_ids, ggs_handle **out) {
   if (!cfg || n < 1 || !device_ids || !out) return GGS_ERR_BAD_ARG;
   for (int32_t i = 0; i < n; ++i) out[i] = nullptr;
@@ -1477,7 +1512,13 @@ int ggs_group_set_z(ggs_handle **hs, int32_t n, const int32_t *const *z, int32_t
   for (int32_t i = 0; i < n; ++i)
     if ((rc = ggs_set_z(hs[i], z[i], 0))) return rc;          // this shard's counts
   if (!redraw_phi) return GGS_OK;
-  if ((rc = group_phi(hs, n, true, false))) return rc;
+  if (hs[0]->collapsed) {                                        // no Phi: the merged counts and tokensPerTopic are the model
+    if ((rc = group_gather_counts(hs, n))) return rc;
+    for (int32_t i = 0; i < n; ++i) {
+      if ((rc = bind_device(hs[i])) || (rc = launch_magnitude(hs[i]))) return rc;
+      hs[i]->have_phi = true;
+    }
+  } else if ((rc = group_phi(hs, n, true, false))) return rc;
   for (int32_t i = 0; i < n; ++i)
     if ((rc = bind_device(hs[i])) || (rc = check_status(hs[i]))) return rc;
   return GGS_OK;
@@ -1487,6 +1528,7 @@ int ggs_group_sweep(ggs_handle **hs, int32_t n, int32_t n_sweeps) {
   if (!is_group(hs, n)) return GGS_ERR_BAD_ARG;
   int rc;
   for (int32_t s = 0; s < n_sweeps; ++s) {
+    if (hs[0]->collapsed && (rc = group_gather_counts(hs, n))) return rc;   // the z step conditions on the corpus-wide sweep-start counts
     for (int32_t i = 0; i < n; ++i) {
       ggs_handle *h = hs[i];
       if ((rc = require_ready(h, true))) return rc;
@@ -1494,7 +1536,19 @@ int ggs_group_sweep(ggs_handle **hs, int32_t n, int32_t n_sweeps) {
       h->iteration += 1;
       if ((rc = z_phase(h))) return rc;
     }
-    if ((rc = group_phi(hs, n, false, true))) return rc;
+    if (hs[0]->collapsed) {                                      // the AD-LDA merge: gathered counts, then tokensPerTopic; no Phi
+      if ((rc = group_gather_counts(hs, n))) return rc;
+      for (int32_t i = 0; i < n; ++i) {
+        ggs_handle *h = hs[i];
+        if ((rc = bind_device(h))) return rc;
+        Events &E = h->evs[h->ev_head];
+        E.exchanged = false;
+        HIP_TRY(h, hipEventRecord(E.e[4], h->stream));
+        if ((rc = launch_magnitude(h))) return rc;
+        HIP_TRY(h, hipEventRecord(E.e[5], h->stream));
+        h->ev_pending += 1;
+      }
+    } else if ((rc = group_phi(hs, n, false, true))) return rc;
     if (s == n_sweeps - 1 || (hs[0]->flags & GGS_FLAG_PARANOID))
       for (int32_t i = 0; i < n; ++i)
         if ((rc = bind_device(hs[i])) || (rc = check_status(hs[i])) || (rc = settle_sweeps(hs[i]))) return rc;

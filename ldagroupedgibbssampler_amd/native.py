@@ -314,6 +314,10 @@ class GGSGroup:
     def sweep(self, n=1):
         self._chk(self._L.ggs_group_sweep(self._arr, len(self.handles), int(n)))
 
+    def gather_counts(self):
+        """Corpus-wide counts onto every handle (grouped collectives); call before the per-handle getters that read them."""
+        self._chk(self._L.ggs_group_gather_counts(self._arr, len(self.handles)))
+
     def close(self):
         if getattr(self, "handles", None):
             for h in self.handles:

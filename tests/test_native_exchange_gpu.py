@@ -278,6 +278,20 @@ def test_one_process_group_api(native, oracle):
     assert_bit_equal(h.get_type_topic_counts(), o.get_type_topic_counts(), "n_wk")
     assert h.get_timings()["sweeps"] == 3
     g.close()
+    # scheme=collapsed through the group: the merge is the grouped gather of the count slices
+    g = native.GGSGroup(K, c.num_types, 0.1, 0.01, 31337, device_ids=[0], flags=native.FLAG_COLLAPSED)
+    h = g.handles[0]
+    h.set_corpus(c.doc_ptr, c.tokens)
+    g.set_z([java_lcg_initial_z(c.num_tokens, K, 9)], redraw_phi=True)
+    g.sweep(2)
+    g.gather_counts()
+    o = oracle.OracleSampler(K, c.num_types, 0.1, 0.01, 31337, threads=2)
+    o.set_corpus(c.doc_ptr, c.tokens)
+    o.set_z(java_lcg_initial_z(c.num_tokens, K, 9), redraw_phi=True)
+    o.collapsed_parallel_sweep(2)
+    assert_bit_equal(h.get_z(), o.get_z(), "collapsed group z")
+    assert_bit_equal(h.get_type_topic_counts(), o.get_type_topic_counts(), "collapsed group n_wk")
+    g.close()
 
 
 def test_attach_order_and_errors(native):

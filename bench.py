@@ -95,7 +95,7 @@ def z_kernels(K, scheme):
         return ["pcgs_sliced_kernel<%d, true>" % kmax] if K <= 192 else ["pcgs_z_kernel<true>"]
     if scheme == "pcgs":
         return ["pcgs_sliced_kernel<%d>" % kmax] if K <= 192 else ["pcgs_z_kernel<false>"]
-    return ["z_sliced_kernel<%d>" % kmax, "z_hot_kernel<%d>" % kmax] if K <= 192 else ["z_stream1_kernel"]
+    return ["z_sliced_kernel<%d>" % kmax, "z_hot_kernel<%d>" % kmax] if K <= 184 else ["z_stream1_kernel"]
 
 
 def row_stats(corpus, K, num_hot):
@@ -109,7 +109,7 @@ def row_stats(corpus, K, num_hot):
     freq = np.bincount(corpus.tokens, minlength=V)
     hot_tokens = int(np.sort(freq)[::-1][:num_hot].sum()) if num_hot > 0 else 0
     row = 8 * (K + (K & 1))
-    gathered = row + (512 if K > 192 else 0)             # the one-pass kernel streams the row once plus one 64-topic group again
+    gathered = row + (512 if K > 184 else 0)             # the one-pass kernel streams the row once plus one 64-topic group again
     return {
         "compulsory_bytes": int(N * (3 * 4 + 4 + 2 * 4) + D * K * 8 + V * row),
         "cold_row_bytes": int((N - hot_tokens) * gathered),
@@ -156,7 +156,7 @@ def roofline_block(corpus, K, scheme, n_local, z_ms, workload, sha, num_hot, z_p
         "traffic_source": src,
         "compulsory_bytes": rs["compulsory_bytes"],
         "limiter": ("instruction issue + L2/Infinity-Cache row gather (far from the HBM roofline: see row_gather and profiles/)"
-                    if K <= 192 else "L2/Infinity-Cache/HBM row gather latency (one pass over the rows; see row_gather and profiles/)"),
+                    if K <= 184 else "L2/Infinity-Cache/HBM row gather latency (one pass over the rows; see row_gather and profiles/)"),
         "row_gather": {"row_bytes": rs["cold_row_bytes"], "GBps": gbs(rs["cold_row_bytes"]), "l2_ceiling_GBps": L2_GATHER_PEAK_GBS,
                        "infinity_cache_ceiling_GBps": MALL_GATHER_PEAK_GBS, "frac_of_l2_ceiling": round(gbs(rs["cold_row_bytes"]) / L2_GATHER_PEAK_GBS, 4),
                        "hot_token_frac_in_lds": rs["hot_token_frac"]},

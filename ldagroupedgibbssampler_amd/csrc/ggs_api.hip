@@ -781,13 +781,18 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     auto alloc_of = [&](int bytes) { return (bytes + kGranule - 1) / kGranule * kGranule; };
     const int pitch = h->pitch16 * 16, thbytes = ((h->Kp * 8 + 15) / 16) * 16;
     // the sliced kernel tags chunk tokens (word ids) in bit 30
-    h->z_sliced = h->K <= kSlicedMaxTopics && h->V < (1 << kSlotShift);
+    // score-register kernels up to K = 184: measured on the benchmark corpus (sweep, ms) K=152: 2.64 sliced / 3.28 streaming,
+    // 168: 3.35 / 3.48, 184: 3.55 / 3.64, 192: 4.22 / 3.59 -- beyond that the one-pass streaming kernel with the next
+    // theta drawn beside it wins (the sliced kernels can take K up to kSlicedMaxTopics = 192: GGS_DEBUG_ZKERNEL=1)
+    const bool sliced_ok = h->K <= kSlicedMaxTopics && h->V < (1 << kSlotShift);
+    h->z_sliced = sliced_ok && h->K <= 184;
     h->z_stream = !h->z_sliced && h->K > 2 * kSliceTopics;
-    if (const char *e = std::getenv("GGS_DEBUG_ZKERNEL")) {          // 0: whole-row tile kernel, 2: streaming kernel where it applies, 3: its two-pass form
+    if (const char *e = std::getenv("GGS_DEBUG_ZKERNEL")) {          // 0: whole-row tile kernel, 1: sliced where possible, 2: streaming kernel where it applies, 3: its two-pass form
       const int mode = std::atoi(e);
-      h->z_sliced = h->z_sliced && mode == 1;
+      h->z_sliced = sliced_ok && mode == 1;
       h->z_stream = (mode == 2 || mode == 3) ? h->K > 2 * kSliceTopics : (h->z_stream && mode != 0);
       h->z_two_pass = mode == 3;
+      if (h->z_sliced) h->z_stream = false;
     }
     if (const char *e = std::getenv("GGS_DEBUG_MARGIN")) h->margin_scale = std::atof(e);
     if (h->z_stream) {

@@ -149,7 +149,7 @@ def test_wide_topic_rows_use_the_streaming_kernel(native, oracle, K):
     compare_state(g, o, "wide K=%d" % K)
 
 
-@pytest.mark.parametrize("mode,K", [(2, 33), (2, 48), (2, 100), (2, 192), (3, 48), (3, 257), (3, 1024), ("margin9", 257), ("margin9", 1024), ("margin13", 64),
+@pytest.mark.parametrize("mode,K", [(2, 33), (2, 48), (2, 100), (2, 184), (1, 192), (1, 185), (3, 48), (3, 257), (3, 1024), ("margin9", 257), ("margin9", 1024), ("margin13", 64),
                                     ("margin13", 300), ("ldsck", 300), ("ldsck", 1024), (0, 5), (0, 100), (0, 257), ("fused", 20), ("fused", 100), ("chain", 9), ("nohot", 20), ("hot3", 100)])
 def test_alternate_z_kernels_agree(native, oracle, K, mode, monkeypatch):
     """The z kernels are interchangeable: GGS_DEBUG_ZKERNEL=2 forces the (one-pass) streaming kernel below 193 topics,

@@ -1,5 +1,6 @@
 // ggs_corpus_demo -- loads a dataset with include/ggs_corpus.hpp and prints it for tests/test_frontend.py:
-//   usage: ggs_corpus_demo dataset.txt stoplist|- rare_threshold keep_numbers(0|1) max_doc_buf_size keep_connectors(0|1)
+//   usage: ggs_corpus_demo dataset.txt stoplist|- rare_threshold keep_numbers(0|1) max_doc_buf_size keep_connectors(0|1) [alphabet.txt frozen(0|1)]
+//          (alphabet.txt: one word per line -- a test set loaded against the training vocabulary, LDAUtils.java:252-257)
 //   output: "D V N", then the doc_ptr, the token ids, the label ids (one line each), then V vocabulary lines,
 //           then D name lines.  Exit code 3 + "overflow" on stderr for the tokenizer's ArrayIndexOutOfBoundsException.
 #include <cstdio>
@@ -9,7 +10,7 @@
 #include "ggs_corpus.hpp"
 
 int main(int argc, char **argv) {
-  if (argc != 7) { std::fprintf(stderr, "usage: %s dataset stoplist|- rare_threshold keep_numbers buf keep_connectors\n", argv[0]); return 2; }
+  if (argc != 7 && argc != 9) { std::fprintf(stderr, "usage: %s dataset stoplist|- rare_threshold keep_numbers buf keep_connectors\n", argv[0]); return 2; }
   ggs::corpus::LoadOptions opt;
   if (std::string(argv[2]) != "-") opt.stoplist_file = argv[2];
   opt.prune_count = std::atoi(argv[3]);
@@ -17,7 +18,13 @@ int main(int argc, char **argv) {
   opt.buffer_size = std::atoi(argv[5]);
   opt.keep_connectors = std::atoi(argv[6]) != 0;
   try {
-    const ggs::corpus::Dataset ds = ggs::corpus::load_instances_prune(argv[1], opt);
+    std::vector<std::string> alphabet;
+    if (argc == 9) {
+      std::ifstream f(argv[7]);
+      std::string w;
+      while (std::getline(f, w)) alphabet.push_back(w);
+    }
+    const ggs::corpus::Dataset ds = ggs::corpus::load_instances_prune(argv[1], opt, argc == 9 ? &alphabet : nullptr, argc == 9 && std::atoi(argv[8]) != 0);
     std::printf("%lld %zu %zu\n", (long long)ds.size(), ds.vocab.size(), ds.tokens.size());
     for (int64_t p : ds.doc_ptr) std::printf("%lld ", (long long)p);
     std::printf("\n");

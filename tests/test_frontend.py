@@ -64,8 +64,8 @@ def corpus_demo(tmp_path_factory):
     return exe
 
 
-def run_cpp(exe, path, stoplist, prune, numbers, buf, connectors):
-    out = subprocess.run([exe, path, stoplist or "-", str(prune), str(int(numbers)), str(buf), str(int(connectors))], capture_output=True)
+def run_cpp(exe, path, stoplist, prune, numbers, buf, connectors, extra=()):
+    out = subprocess.run([exe, path, stoplist or "-", str(prune), str(int(numbers)), str(buf), str(int(connectors))] + list(extra), capture_output=True)
     if out.returncode == 3:
         raise F.TokenBufferOverflow(out.stderr.decode())
     assert out.returncode == 0, out.stderr.decode()
@@ -117,3 +117,20 @@ def test_cpp_loader_equals_python_loader_on_random_unicode(corpus_demo, tmp_path
         f.write("\n".join(lines) + "\n")
     for prune, numbers, connectors in [(0, True, False), (2, False, True), (3, True, True)]:
         same(run_cpp(corpus_demo, path, None, prune, numbers, 10000, connectors), F.load_instances_prune(path, None, prune, numbers, 10000, connectors))
+
+
+def test_test_set_against_the_training_alphabet(corpus_demo, tmp_path):
+    """LDAUtils.loadInstancesPrune(..., dataAlphabet) (LDAUtils.java:252-257,298-303; the pattern of LDAUtilsTest.testLoadTestInstancesPrune):
+    a test set loaded against the training vocabulary keeps the training ids; with the alphabet frozen (Alphabet.stopGrowth)
+    unknown words are dropped, otherwise they extend it."""
+    train = F.load_instances_prune(os.path.join(DATA, "SmallTexts.txt"), None, 0, True)
+    path = os.path.join(DATA, "special_chars.txt")
+    frozen = F.load_instances_prune(path, None, 0, True, 10000, False, tuple(train.corpus.vocab))
+    assert frozen.corpus.vocab == train.corpus.vocab and frozen.corpus.num_docs == 5
+    assert frozen.corpus.num_tokens < F.load_instances_prune(path, None, 0, True).corpus.num_tokens       # "but_i_can" splits into words the training text lacks
+    grown = F.load_instances_prune(path, None, 0, True, 10000, True, list(train.corpus.vocab))
+    assert grown.corpus.vocab[:train.corpus.num_types] == train.corpus.vocab and "but_i_can" in grown.corpus.vocab[train.corpus.num_types:]
+    alpha = tmp_path / "alphabet.txt"
+    alpha.write_text("\n".join(train.corpus.vocab) + "\n", encoding="utf-8")
+    same(run_cpp(corpus_demo, path, None, 0, True, 10000, False, [str(alpha), "1"]), frozen)
+    same(run_cpp(corpus_demo, path, None, 0, True, 10000, True, [str(alpha), "0"]), grown)

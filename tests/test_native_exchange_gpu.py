@@ -171,12 +171,13 @@ def _thread_rank(native, tr, rank, world, whole, K, scheme, zseed, sweeps, out, 
         tr.bar.abort()
 
 
-@pytest.mark.parametrize("scheme,K,world", [("ggs", 100, 3), ("ggs", 7, 4), ("pcgs", 24, 2), ("ggs", 200, 3), ("ggs", 2, 3)])
-def test_topic_sliced_exchange_between_handles(native, oracle, scheme, K, world):
+@pytest.mark.parametrize("scheme,K,world,docs", [("ggs", 100, 3, 310), ("ggs", 7, 4, 310), ("pcgs", 24, 2, 310), ("ggs", 200, 3, 310), ("ggs", 2, 3, 310),
+                                                 ("ggs", 5, 4, 3), ("pcgs", 5, 3, 2)])
+def test_topic_sliced_exchange_between_handles(native, oracle, scheme, K, world, docs):
     """`world` doc shards, each a handle with the callback exchange: z, theta per shard and counts, Phi, phi mean on
     every rank equal the unsharded oracle.  K = 100 over 3 ranks has unequal slices (34, 33, 33); K = 2 over 3 leaves
-    rank 2 without a topic."""
-    whole = random_corpus(310, 900, 120, seed=5 + K, empty_every=9)
+    rank 2 without a topic; 3 documents over 4 ranks (2 over 3) leave a rank without a document."""
+    whole = random_corpus(docs, 900 if docs > 10 else 40, 120 if docs > 10 else 25, seed=5 + K, empty_every=9 if docs > 10 else 0)
     sweeps = 4
     tr, out, errs = ThreadTransport(world), [None] * world, []
     ts = [threading.Thread(target=_thread_rank, args=(native, tr, r, world, whole, K, scheme, 17, sweeps, out, errs)) for r in range(world)]

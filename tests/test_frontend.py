@@ -125,12 +125,12 @@ def test_test_set_against_the_training_alphabet(corpus_demo, tmp_path):
     unknown words are dropped, otherwise they extend it."""
     train = F.load_instances_prune(os.path.join(DATA, "SmallTexts.txt"), None, 0, True)
     path = os.path.join(DATA, "special_chars.txt")
-    frozen = F.load_instances_prune(path, None, 0, True, 10000, False, tuple(train.corpus.vocab))
+    frozen = F.load_instances_prune(path, None, 0, True, 10000, True, tuple(train.corpus.vocab))
     assert frozen.corpus.vocab == train.corpus.vocab and frozen.corpus.num_docs == 5
-    assert frozen.corpus.num_tokens < F.load_instances_prune(path, None, 0, True).corpus.num_tokens       # "but_i_can" splits into words the training text lacks
+    assert frozen.corpus.num_tokens == train.corpus.num_tokens - 3            # "but_i_can" is one unknown word now: dropped
     grown = F.load_instances_prune(path, None, 0, True, 10000, True, list(train.corpus.vocab))
     assert grown.corpus.vocab[:train.corpus.num_types] == train.corpus.vocab and "but_i_can" in grown.corpus.vocab[train.corpus.num_types:]
     alpha = tmp_path / "alphabet.txt"
     alpha.write_text("\n".join(train.corpus.vocab) + "\n", encoding="utf-8")
-    same(run_cpp(corpus_demo, path, None, 0, True, 10000, False, [str(alpha), "1"]), frozen)
+    same(run_cpp(corpus_demo, path, None, 0, True, 10000, True, [str(alpha), "1"]), frozen)
     same(run_cpp(corpus_demo, path, None, 0, True, 10000, True, [str(alpha), "0"]), grown)

@@ -109,7 +109,8 @@ def row_stats(corpus, K, num_hot):
     freq = np.bincount(corpus.tokens, minlength=V)
     hot_tokens = int(np.sort(freq)[::-1][:num_hot].sum()) if num_hot > 0 else 0
     row = 8 * (K + (K & 1))
-    gathered = row + (512 if K > 184 else 0)             # the one-pass kernel streams the row once plus one 64-topic group again
+    ns = (K + 15) // 16
+    gathered = row + (0 if K <= 184 else 128 * (1 if ns <= 16 else 2 if ns <= 32 else 4))   # the one-pass kernel streams the row once plus one checkpoint group again
     return {
         "compulsory_bytes": int(N * (3 * 4 + 4 + 2 * 4) + D * K * 8 + V * row),
         "cold_row_bytes": int((N - hot_tokens) * gathered),

@@ -58,6 +58,7 @@ struct ggs_handle {
   bool z_stream = false;   // streaming kernel (K > kSlicedMaxTopics): rows once (z_stream1_kernel) ...
   bool z_two_pass = false; // ... or twice (z_stream_kernel, GGS_DEBUG_ZKERNEL=3: the cross-check)
   bool z_regck = false;    // z_stream1_kernel keeps its checkpoints in registers (K <= 1024)
+  int32_t z_group = 4;     // ... one per z_group slices
   double margin_scale = 1.0;   // GGS_DEBUG_MARGIN: scales z_stream1_kernel's certainty margin (tests force its exact replay)
 
   hipStream_t stream = nullptr;
@@ -476,8 +477,10 @@ int launch_z(ggs_handle *h, bool force_fused = false, int64_t c0 = 0, int64_t c1
                                  (size_t)(kSlicedWaves * h->wave_lds + h->num_hot * h->hot_pitch), h->stream));
     }
   } else if (h->z_stream && h->z_two_pass) hipLaunchKernelGGL(z_stream_kernel, grid, block, h->z_lds, h->stream, zp);
-  else if (h->z_stream && h->z_regck) hipLaunchKernelGGL(z_stream1_kernel<true>, grid, block, h->z_lds, h->stream, zp);
-  else if (h->z_stream) hipLaunchKernelGGL(z_stream1_kernel<false>, grid, block, h->z_lds, h->stream, zp);
+  else if (h->z_stream && h->z_regck && h->z_group == 1) hipLaunchKernelGGL((z_stream1_kernel<true, 1>), grid, block, h->z_lds, h->stream, zp);
+  else if (h->z_stream && h->z_regck && h->z_group == 2) hipLaunchKernelGGL((z_stream1_kernel<true, 2>), grid, block, h->z_lds, h->stream, zp);
+  else if (h->z_stream && h->z_regck) hipLaunchKernelGGL((z_stream1_kernel<true, 4>), grid, block, h->z_lds, h->stream, zp);
+  else if (h->z_stream) hipLaunchKernelGGL((z_stream1_kernel<false, 4>), grid, block, h->z_lds, h->stream, zp);
   else if (nt <= 1) hipLaunchKernelGGL(z_kernel<1>, grid, block, h->z_lds, h->stream, zp);
   else if (nt <= 2) hipLaunchKernelGGL(z_kernel<2>, grid, block, h->z_lds, h->stream, zp);
   else if (nt <= 4) hipLaunchKernelGGL(z_kernel<4>, grid, block, h->z_lds, h->stream, zp);
@@ -800,11 +803,17 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       // checkpoint groups, plus a checkpoint per group and lane); no score registers, so 8 waves per CU fit the
       // register file and LDS bounds the residency
       h->z_tile_tokens = 64;
-      const int ns = (h->K + kSliceTopics - 1) / kSliceTopics, ng = (ns + kGroupSlices - 1) / kGroupSlices;
-      h->z_regck = !h->z_two_pass && ng <= kRegCheckpoints;          // checkpoints in registers (K <= 1024) or in LDS
+      const int ns = (h->K + kSliceTopics - 1) / kSliceTopics;
+      // checkpoint group: the smallest that keeps the checkpoints in registers (K <= 256: one slice, <= 512: two, <= 1024: four); beyond, four slices and LDS
+      h->z_group = ns <= kRegCheckpoints ? 1 : ns <= 2 * kRegCheckpoints ? 2 : 4;
+      if (const char *e = std::getenv("GGS_DEBUG_GROUP")) { const int gq = std::atoi(e); if (gq == 1 || gq == 2 || gq == 4) h->z_group = gq; }
+      const int ng = (ns + h->z_group - 1) / h->z_group;
+      h->z_regck = !h->z_two_pass && ng <= kRegCheckpoints;          // checkpoints in registers or in LDS
       if (const char *e = std::getenv("GGS_DEBUG_REGCK")) h->z_regck = h->z_regck && std::atoi(e) != 0;
+      if (!h->z_regck) h->z_group = 4;                               // the LDS-checkpoint kernel is instantiated for groups of four
+      const int ngl = (ns + h->z_group - 1) / h->z_group;
       h->z_lds = h->z_two_pass ? kStreamRingSlots * kSliceBytes + ns * kSliceTopics * 8
-                               : kStream1RingSlots * kSliceBytes + ng * kGroupSlices * kSliceTopics * 8 + (h->z_regck ? 0 : ng * 64 * 8);
+                               : kStream1RingSlots * kSliceBytes + ngl * h->z_group * kSliceTopics * 8 + (h->z_regck ? 0 : ngl * 64 * 8);
       if (h->z_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);   // K > ~16000: the theta row itself would need slicing
       // the waves are persistent, so the grid must be what is truly co-resident -- and a CU's 160 KiB cannot be filled
       // to the last granule: measured, 5 x 32 KiB and 4 x 40 KiB leave one workgroup waiting for a second round
@@ -886,8 +895,10 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
   // The attribute is process-global per kernel, not per handle: always the hardware maximum, so that a later handle
   // with a smaller K never lowers the cap under a live one.
   if (h->z_stream && (hipFuncSetAttribute(reinterpret_cast<const void *>(z_stream_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess ||
-                      hipFuncSetAttribute(reinterpret_cast<const void *>(z_stream1_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess ||
-                      hipFuncSetAttribute(reinterpret_cast<const void *>(z_stream1_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess))
+                      hipFuncSetAttribute(reinterpret_cast<const void *>(z_stream1_kernel<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess ||
+                      hipFuncSetAttribute(reinterpret_cast<const void *>(z_stream1_kernel<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess ||
+                      hipFuncSetAttribute(reinterpret_cast<const void *>(z_stream1_kernel<true, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess ||
+                      hipFuncSetAttribute(reinterpret_cast<const void *>(z_stream1_kernel<false, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess))
     return bail(GGS_ERR_HIP);
   for (const void *f : zk)
     if (!h->z_sliced && !h->z_stream && hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess) return bail(GGS_ERR_HIP);
@@ -1629,6 +1640,8 @@ int ggs_set_phi(ggs_handle *h, const double *phi) {
   hipLaunchKernelGGL(phi_to_phiT_kernel, dim3(grid_for((int64_t)kv, 256)), dim3(256), 0, h->stream, static_cast<const double *>(h->d_scratch),
                      h->d_phiT, h->K, h->Kp, h->V);
   HIP_TRY(h, hipGetLastError());
+  // UPLDA:1897-1902: `if (savePhiMeans()) phiMean = new double[numTopics][numTypes]` -- the running sum restarts, noSampledPhi keeps counting
+  if (h->d_phi_mean) HIP_TRY(h, hipMemsetAsync(h->d_phi_mean, 0, kv * sizeof(double), h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   h->have_phi = true;
   return GGS_OK;

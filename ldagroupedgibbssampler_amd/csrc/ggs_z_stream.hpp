@@ -206,16 +206,20 @@ __global__ __launch_bounds__(64) void z_stream_kernel(ZParams p) {
 // the same s_j.  Row traffic per token: 8*K + 512 bytes instead of 16*K.
 // LDS per wave: the 2-slot ring, the theta row zero-padded to whole groups, the checkpoints.
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int kGroupSlices = 4;                                    // slices per checkpoint group (64 topics, 512 B of a row)
+// Slices per checkpoint group G (a template parameter): the group is what is streamed again, so small groups cost less
+// refinement traffic and more checkpoints.  With the checkpoints in registers (at most kRegCheckpoints groups) the host
+// takes the smallest G that fits: 1 up to K = 256 (16 B... one 128-byte slice per token again), 2 up to 512, 4 up to 1024.
+constexpr int kMaxGroupSlices = 4;
 #ifndef GGS_STREAM1_RING
 #define GGS_STREAM1_RING 2
 #endif
 constexpr int kStream1RingSlots = GGS_STREAM1_RING;                // measured at K = 1024 with 4 waves per CU: 2 slots 12.7 ms, 3 slots 12.9; waves per CU matter more
 constexpr int kRegCheckpoints = 16;                                // REGCK: checkpoints in registers for up to 16 groups (K <= 1024): 8 KiB less LDS per wave at K = 1024
 
-template <bool REGCK>
+template <bool REGCK, int kGroupSlices>
 __global__ __launch_bounds__(64) void z_stream1_kernel(ZParams p) {
   constexpr int R = kStream1RingSlots, kAhead = R - 1;
+  static_assert(kGroupSlices == 1 || kGroupSlices == 2 || kGroupSlices == 4, "the checkpoint test masks with G - 1");
   static_assert(kAhead >= 1 && kAhead <= 3, "wait_younger covers up to 3 slices in flight behind the current one");
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x;
@@ -376,7 +380,10 @@ __global__ __launch_bounds__(64) void z_stream1_kernel(ZParams p) {
     for (int m = 0; m < 8; ++m) rr[m] = ra[m] + (size_t)__shfl(gsel, 8 * m + lrow) * (kGroupSlices * 128);
     const int gr = (g + NS) % R;                                   // ring slot of the first refinement slice
 #pragma unroll
-    for (int i = 0; i < kAhead; ++i) issue_slice(i, (gr + i) % R, rr);
+    for (int i = 0; i < kAhead; ++i) {
+      if (i < kGroupSlices) issue_slice(i, (gr + i) % R, rr);
+      else if (has1) issue_slice(i - kGroupSlices, (gr + i) % R, ran);
+    }
     int found = -1;
     double dprev = 0.0;
 #pragma unroll 1

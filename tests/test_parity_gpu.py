@@ -142,15 +142,17 @@ def test_wide_topic_rows_use_the_streaming_kernel(native, oracle, K):
     is K = 1024; > 1024 topics take a second round of theta staging)."""
     c = random_corpus(120, 300, 150, seed=K, empty_every=9)
     g, o = make_pair(native, oracle, c, K, 0.1, 0.01, 7 + K, flags=native.FLAG_PARANOID, zseed=K)
-    groups = ((K + 15) // 16 + 3) // 4
-    assert g.launch_info()["lds_bytes_z"] == 2 * 8192 + groups * 512 + (groups * 512 if groups > 16 else 0)   # ring, theta row, checkpoints (in registers up to 16 groups)
+    ns = (K + 15) // 16
+    gs = 1 if ns <= 16 else 2 if ns <= 32 else 4                   # slices per checkpoint group: the smallest that keeps 16 checkpoints in registers
+    groups = (ns + gs - 1) // gs
+    assert g.launch_info()["lds_bytes_z"] == 2 * 8192 + groups * gs * 128 + (groups * 512 if groups > 16 else 0)   # ring, theta row, checkpoints (LDS beyond 16 groups)
     g.sweep(2)
     o.sweep(2)
     compare_state(g, o, "wide K=%d" % K)
 
 
 @pytest.mark.parametrize("mode,K", [(2, 33), (2, 48), (2, 100), (2, 184), (1, 192), (1, 185), (3, 48), (3, 257), (3, 1024), ("margin9", 257), ("margin9", 1024), ("margin13", 64),
-                                    ("margin13", 300), ("ldsck", 300), ("ldsck", 1024), (0, 5), (0, 100), (0, 257), ("fused", 20), ("fused", 100), ("chain", 9), ("nohot", 20), ("hot3", 100)])
+                                    ("margin13", 300), ("ldsck", 300), ("ldsck", 1024), ("group2", 200), ("group4", 200), ("group4", 500), (0, 5), (0, 100), (0, 257), ("fused", 20), ("fused", 100), ("chain", 9), ("nohot", 20), ("hot3", 100)])
 def test_alternate_z_kernels_agree(native, oracle, K, mode, monkeypatch):
     """The z kernels are interchangeable: GGS_DEBUG_ZKERNEL=2 forces the (one-pass) streaming kernel below 193 topics,
     =3 its two-pass form (every row streamed twice, the walk replayed in full: the cross-check of the one-pass kernel's
@@ -161,9 +163,9 @@ def test_alternate_z_kernels_agree(native, oracle, K, mode, monkeypatch):
     GGS_DEBUG_CHAIN=1 ("chain") walks the Phi normalisers element by element instead of the exact parallel sums;
     GGS_DEBUG_HOT caps the hot-word table (0: every chunk is a cold chunk; 3: three hot words)."""
     env = {"fused": ("GGS_DEBUG_SPLIT", "0"), "chain": ("GGS_DEBUG_CHAIN", "1"), "nohot": ("GGS_DEBUG_HOT", "0"),
-           "hot3": ("GGS_DEBUG_HOT", "3"), "margin9": ("GGS_DEBUG_MARGIN", "1e9"), "margin13": ("GGS_DEBUG_MARGIN", "1e13"), "ldsck": ("GGS_DEBUG_REGCK", "0")}.get(mode, ("GGS_DEBUG_ZKERNEL", str(mode)))
+           "hot3": ("GGS_DEBUG_HOT", "3"), "margin9": ("GGS_DEBUG_MARGIN", "1e9"), "margin13": ("GGS_DEBUG_MARGIN", "1e13"), "ldsck": ("GGS_DEBUG_REGCK", "0"), "group2": ("GGS_DEBUG_GROUP", "2"), "group4": ("GGS_DEBUG_GROUP", "4")}.get(mode, ("GGS_DEBUG_ZKERNEL", str(mode)))
     monkeypatch.setenv(*env)
-    if str(mode).startswith("margin") or mode == "ldsck":
+    if str(mode).startswith("margin") or mode == "ldsck" or str(mode).startswith("group"):
         monkeypatch.setenv("GGS_DEBUG_ZKERNEL", "2")
     c = random_corpus(150, 400, 140, seed=K + (mode if isinstance(mode, int) else 7), empty_every=11)
     g, o = make_pair(native, oracle, c, K, 0.1, 0.01, 70 + K, flags=native.FLAG_PARANOID, zseed=K)
@@ -259,6 +261,16 @@ def test_phi_mean_gating(native, oracle):
     (gm, gn), (om, on) = g.get_phi_mean(), o.get_phi_mean()
     assert gn == on == 3                          # iterations 4, 6, 8 (> burn_in, % thin == 0)
     assert_bit_equal(gm, om, "phi mean")
+    # setPhi restarts the running sum while noSampledPhi keeps counting (UPLDA:1897-1902)
+    p = g.get_phi()
+    g.set_phi(p)
+    o.set_phi(p)
+    g.sweep(2)
+    o.sweep(2)
+    (gm, gn), (om, on) = g.get_phi_mean(), o.get_phi_mean()
+    assert gn == on == 4
+    assert_bit_equal(gm, om, "phi mean after setPhi")
+    assert_bit_equal(gm, g.get_phi() / 4, "phi mean after setPhi = the one Phi accumulated since, over noSampledPhi")
 
 
 @pytest.mark.parametrize("scheme", ["ggs", "pcgs"])

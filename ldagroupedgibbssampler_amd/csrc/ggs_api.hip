@@ -59,6 +59,8 @@ struct ggs_handle {
   bool z_two_pass = false; // ... or twice (z_stream_kernel, GGS_DEBUG_ZKERNEL=3: the cross-check)
   bool z_regck = false;    // z_stream1_kernel keeps its checkpoints in registers (K <= 1024)
   int32_t z_group = 4;     // ... one per z_group slices
+  bool z_two_rows = false; // z_stream1_kernel with two theta rows per wave: chunks may run across one document boundary (K <= 512)
+  int32_t *d_chunk_doc1 = nullptr;
   double margin_scale = 1.0;   // GGS_DEBUG_MARGIN: scales z_stream1_kernel's certainty margin (tests force its exact replay)
 
   hipStream_t stream = nullptr;
@@ -444,11 +446,13 @@ int launch_z(ggs_handle *h, bool force_fused = false, int64_t c0 = 0, int64_t c1
   zp.num_chunks = h->C;
   zp.ablate = h->ablate;
   zp.margin_scale = h->margin_scale;
+  zp.chunk_doc1 = h->d_chunk_doc1; zp.two_rows = (h->z_stream && h->z_two_rows && h->d_chunk_doc1) ? 1 : 0;
   zp.ct_tok = h->d_ct_tok; zp.ct_idx = h->d_ct_idx; zp.ct_ip = h->d_ct_ip; zp.c_docs = h->d_c_docs; zp.num_cold = h->Cc;
   zp.hot_words = h->d_hot_words; zp.num_hot = h->num_hot; zp.hot_pitch = h->hot_pitch;
   zp.wave_lds = h->wave_lds; zp.hot_off = kSlicedWaves * h->wave_lds; zp.ring_base = h->ring_base;
   if (!h->z_sliced) {                                  // a range of the chunk table (the one-document chunks are in document order)
     zp.chunk_start += c0; zp.chunk_doc += c0; zp.chunk_len += c0; zp.num_chunks = c1 - c0;
+    if (zp.chunk_doc1) zp.chunk_doc1 += c0;
   }
   // persistent waves: as many single-wave workgroups as stay resident, each strides the chunk table
   const dim3 grid((unsigned)std::min<int64_t>(zp.num_chunks, (int64_t)h->num_cus * h->z_waves_per_cu)), block(64);
@@ -812,8 +816,13 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       if (const char *e = std::getenv("GGS_DEBUG_REGCK")) h->z_regck = h->z_regck && std::atoi(e) != 0;
       if (!h->z_regck) h->z_group = 4;                               // the LDS-checkpoint kernel is instantiated for groups of four
       const int ngl = (ns + h->z_group - 1) / h->z_group;
+      // Chunks of 64 consecutive tokens across ONE document boundary (two theta rows per wave) instead of near-equal
+      // cuts of single documents: 98 % of the lanes busy instead of 78 % at 200-token documents.  Where the second row
+      // would cost resident waves (K > 512: 8 KiB at K = 1024) the single-document chunks stay.
+      h->z_two_rows = !h->z_two_pass && h->K <= 512;
+      if (const char *e = std::getenv("GGS_DEBUG_TWOROWS")) h->z_two_rows = !h->z_two_pass && std::atoi(e) != 0;
       h->z_lds = h->z_two_pass ? kStreamRingSlots * kSliceBytes + ns * kSliceTopics * 8
-                               : kStream1RingSlots * kSliceBytes + ngl * h->z_group * kSliceTopics * 8 + (h->z_regck ? 0 : ngl * 64 * 8);
+                               : kStream1RingSlots * kSliceBytes + (h->z_two_rows ? 2 : 1) * ngl * h->z_group * kSliceTopics * 8 + (h->z_regck ? 0 : ngl * 64 * 8);
       if (h->z_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);   // K > ~16000: the theta row itself would need slicing
       // the waves are persistent, so the grid must be what is truly co-resident -- and a CU's 160 KiB cannot be filled
       // to the last granule: measured, 5 x 32 KiB and 4 x 40 KiB leave one workgroup waiting for a second round
@@ -976,7 +985,7 @@ void ggs_destroy(ggs_handle *h) {
                   h->d_phiT, h->d_mag, h->d_tot, h->d_phi_mean, h->d_n_wk, h->d_n_k, h->d_perm, h->d_inv_perm, h->d_zw, h->d_seg_word, h->d_seg_begin,
                   h->d_status, h->d_scratch, h->d_sum_pref, h->d_sum_fn, h->d_ct_tok, h->d_ct_idx, h->d_ct_ip, h->d_c_docs, h->d_hot_words, h->d_order,
                   h->d_test_ptr, h->d_test_tok, h->d_test_ll, h->d_test_docs, h->d_koff, h->d_cnt_send, h->d_cnt_own, h->d_cnt_all, h->d_n_k_own,
-                  h->d_phi_own, h->d_phi_all, h->d_mag_own, h->d_tot_own, h->d_lcg};
+                  h->d_phi_own, h->d_phi_all, h->d_mag_own, h->d_tot_own, h->d_lcg, h->d_chunk_doc1};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   if (h->xg) {
@@ -1030,6 +1039,26 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
   std::vector<int64_t> cstart;
   std::vector<int32_t> cdoc, clen;
   cstart.reserve((size_t)(N / 48 + D)); cdoc.reserve(cstart.capacity()); clen.reserve(cstart.capacity());
+  std::vector<int32_t> cdoc1;
+  const bool two_rows = h->z_stream && h->z_two_rows;
+  if (two_rows) {
+    // 64 consecutive tokens per chunk, across at most one document boundary; clen = tokens | tokens of the first document << 8
+    int64_t pos = 0;
+    int64_t d = 0;
+    while (pos < N) {
+      while (doc_ptr[d + 1] <= pos) ++d;                            // the document of token `pos` (empty documents hold none)
+      const int64_t take0 = std::min<int64_t>(64, doc_ptr[d + 1] - pos);
+      int64_t len = take0, d1 = d;
+      if (take0 < 64 && pos + take0 < N) {                          // room left: the next non-empty document joins
+        d1 = d + 1;
+        while (doc_ptr[d1 + 1] <= pos + take0) ++d1;
+        len += std::min<int64_t>(64 - take0, doc_ptr[d1 + 1] - (pos + take0));
+      }
+      cstart.push_back(pos); cdoc.push_back((int32_t)d); cdoc1.push_back((int32_t)d1);
+      clen.push_back((int32_t)(len | (take0 << 8)));
+      pos += len;
+    }
+  } else
   for (int64_t d = 0; d < D; ++d) {
     const int64_t len = doc_ptr[d + 1] - doc_ptr[d];
     if (len == 0) continue;
@@ -1180,6 +1209,10 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
     HIP_TRY(h, hipMemcpy(h->d_chunk_start, cstart.data(), sizeof(int64_t) * cstart.size(), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_chunk_doc, cdoc.data(), sizeof(int32_t) * cdoc.size(), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(h->d_chunk_len, clen.data(), sizeof(int32_t) * clen.size(), hipMemcpyHostToDevice));
+    if (two_rows) {
+      if ((rc = dev_alloc(h, &h->d_chunk_doc1, cdoc1.size()))) return rc;
+      HIP_TRY(h, hipMemcpy(h->d_chunk_doc1, cdoc1.data(), sizeof(int32_t) * cdoc1.size(), hipMemcpyHostToDevice));
+    }
   }
   HIP_TRY(h, hipDeviceSynchronize());   // the uploads and memsets above ran on the null stream; the handle's stream may not synchronise with it
   h->have_corpus = true; h->have_phi = false; h->in_sweep = false; h->global_tokens = -1; h->lcg_ready = false;

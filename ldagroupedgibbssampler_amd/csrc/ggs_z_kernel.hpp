@@ -51,6 +51,10 @@ struct ZParams {
   int32_t hot_off, wave_lds;   // LDS byte offset of the table; bytes of LDS per wave (theta rows + ring)
   int32_t ring_base;           // offset of the ring inside a wave's LDS
   double margin_scale;         // z_stream1_kernel: 1.0; tests scale the certainty margin up to force its exact replay path
+  // z_stream1_kernel with two theta rows per wave (moderate K): a chunk may run across ONE document boundary;
+  // chunk_len then carries len | split << 8 (split = tokens of the first document) and chunk_doc1 the second document
+  const int32_t *chunk_doc1;
+  int32_t two_rows;
 };
 
 struct alignas(16) D2 { double a, b; };

@@ -227,14 +227,15 @@ __global__ __launch_bounds__(64) void z_stream1_kernel(ZParams p) {
   const int NS = (K + kSliceTopics - 1) / kSliceTopics;            // slices of pass 1
   const int NG = (NS + kGroupSlices - 1) / kGroupSlices;           // checkpoint groups
   const int KTG = NG * kGroupSlices * kSliceTopics;                // theta row in LDS, zero padded to whole groups
-  double *thb = reinterpret_cast<double *>(smem + R * kSliceBytes);
-  double *ckb = thb + KTG;                                         // [NG][64] (!REGCK)
+  double *thb = reinterpret_cast<double *>(smem + R * kSliceBytes);   // theta row(s): one, or two with p.two_rows (a chunk across a document boundary)
+  double *ckb = thb + (p.two_rows ? 2 : 1) * KTG;                  // [NG][64] (!REGCK)
   double ck[REGCK ? kRegCheckpoints : 1];                           // REGCK: the lane's checkpoints
   const unsigned char *phib = reinterpret_cast<const unsigned char *>(p.phiT);
   const size_t rowbytes = (size_t)Kp * 8;
   const const_i64_t *cstart = (const const_i64_t *)p.chunk_start;
   const const_i32_t *clen = (const const_i32_t *)p.chunk_len;
   const const_i32_t *cdoc = (const const_i32_t *)p.chunk_doc;
+  const const_i32_t *cdoc1 = (const const_i32_t *)p.chunk_doc1;
   const int64_t C = p.num_chunks;
 
   const int lrow = lane >> 3, lslot = lane & 7;
@@ -259,12 +260,16 @@ __global__ __launch_bounds__(64) void z_stream1_kernel(ZParams p) {
   const int64_t cend = C * (int64_t)(blockIdx.x + 1) / (int64_t)gridDim.x;
   int64_t c = C * (int64_t)blockIdx.x / (int64_t)gridDim.x;
   if (c >= cend) return;
-  int doc_in_lds = -1;
+  int rd0 = -1, rd1 = -1;                                          // the documents whose theta rows sit in LDS rows 0 and 1
   int64_t start0 = cstart[c], start1 = 0;
-  int len0 = clen[c], len1 = 0, doc0 = cdoc[c], doc1 = 0;
-  if (c + 1 < cend) { start1 = cstart[c + 1]; len1 = clen[c + 1]; doc1 = cdoc[c + 1]; }
-  int w0 = (lane < len0) ? p.tok[start0 + lane] : 0;
-  int ip0 = (lane < len0) ? p.inv_perm[start0 + lane] : 0;
+  int len0 = clen[c], len1 = 0, doc0 = cdoc[c], doc1 = 0;          // len: tokens | tokens of the first document << 8 (0: all of them)
+  int docb0 = p.two_rows ? cdoc1[c] : doc0, docb1 = 0;             // the chunk's second document (= the first if it has one only)
+  if (c + 1 < cend) { start1 = cstart[c + 1]; len1 = clen[c + 1]; doc1 = cdoc[c + 1]; docb1 = p.two_rows ? cdoc1[c + 1] : doc1; }
+  const int split_shift = 8;
+  auto tokens_of = [](const int v) { return v & 0xff; };
+  auto split_of = [&](const int v) { const int sp = v >> split_shift; return sp ? sp : (v & 0xff); };
+  int w0 = (lane < tokens_of(len0)) ? p.tok[start0 + lane] : 0;
+  int ip0 = (lane < tokens_of(len0)) ? p.inv_perm[start0 + lane] : 0;
   const unsigned char *ra[8], *ran[8], *rr[8];
   row_addresses(w0, ra);
   // all but the youngest n slices (8 DMA instructions each) have landed
@@ -280,8 +285,12 @@ __global__ __launch_bounds__(64) void z_stream1_kernel(ZParams p) {
 
   for (;;) {
     const bool has1 = c + 1 < cend;
-    if (doc0 != doc_in_lds) {                                      // wave-uniform: consecutive chunks share the document
-      const double *thg = p.theta + (size_t)doc0 * K;
+    // theta rows: the chunk's first document goes where it already is, or into row 0; the second one (if any) into the
+    // other row.  Wave-uniform: consecutive chunks share documents, so most chunks stage one row or none.
+    const int n0 = tokens_of(len0), sp0 = split_of(len0);
+    auto stage_row = [&](const int doc, const int rowi) {
+      const double *thg = p.theta + (size_t)doc * K;
+      double *dst = thb + rowi * KTG;
       for (int base = 0; base < KTG; base += 1024) {               // 16 loads in flight per lane, one round trip per 1024 topics
         double t[16];
 #pragma unroll
@@ -292,18 +301,24 @@ __global__ __launch_bounds__(64) void z_stream1_kernel(ZParams p) {
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
           const int k = base + i * 64 + lane;
-          if (k < KTG) thb[k] = (k < K) ? t[i] : 0.0;
+          if (k < KTG) dst[k] = (k < K) ? t[i] : 0.0;
         }
       }
-      doc_in_lds = doc0;
-    }
+      if (rowi) rd1 = doc; else rd0 = doc;
+    };
+    int rowa = 0;
+    if (p.two_rows && doc0 == rd1) rowa = 1;
+    else if (doc0 != rd0) stage_row(doc0, 0);
+    if (sp0 < n0 && docb0 != (rowa ? rd0 : rd1)) stage_row(docb0, rowa ^ 1);
+    const double *thl = thb + ((lane < sp0) ? rowa : (rowa ^ 1)) * KTG;   // this lane's theta row
     int w1 = 0, ip1 = 0;
     int64_t start2 = 0;
     int len2 = 0, doc2 = 0;
+    int docb2 = 0;
     if (has1) {
-      w1 = (lane < len1) ? p.tok[start1 + lane] : 0;
-      ip1 = (lane < len1) ? p.inv_perm[start1 + lane] : 0;
-      if (c + 2 < cend) { start2 = cstart[c + 2]; len2 = clen[c + 2]; doc2 = cdoc[c + 2]; }
+      w1 = (lane < tokens_of(len1)) ? p.tok[start1 + lane] : 0;
+      ip1 = (lane < tokens_of(len1)) ? p.inv_perm[start1 + lane] : 0;
+      if (c + 2 < cend) { start2 = cstart[c + 2]; len2 = clen[c + 2]; doc2 = cdoc[c + 2]; docb2 = p.two_rows ? cdoc1[c + 2] : doc2; }
       row_addresses(w1, ran);
     }
     asm volatile("" ::: "memory");
@@ -314,9 +329,9 @@ __global__ __launch_bounds__(64) void z_stream1_kernel(ZParams p) {
       const int cur = (g + j) % R;
       if (j + kAhead < NS) issue_slice(j + kAhead, (g + j + kAhead) % R, ra);
       wait_younger(min(kAhead, NS - 1 - j));                       // the pipeline drains at the end: which group to stream next is not known yet
-      if (lane < len0) {
+      if (lane < n0) {
         const unsigned char *rb = my_row + cur * kSliceBytes;
-        const unsigned char *tb = reinterpret_cast<const unsigned char *>(thb) + j * kSliceTopics * 8;
+        const unsigned char *tb = reinterpret_cast<const unsigned char *>(thl) + j * kSliceTopics * 8;
         D2 ph[kSliceUnits], th[kSliceUnits];
 #pragma unroll
         for (int u = 0; u < kSliceUnits; ++u) {
@@ -342,7 +357,7 @@ __global__ __launch_bounds__(64) void z_stream1_kernel(ZParams p) {
     } else {
       for (int j = 0; j < NS; ++j) {
         pass1_slice(j);
-        if (lane < len0 && ((j & (kGroupSlices - 1)) == kGroupSlices - 1 || j == NS - 1)) ckb[(j / kGroupSlices) * 64 + lane] = sum;
+        if (lane < n0 && ((j & (kGroupSlices - 1)) == kGroupSlices - 1 || j == NS - 1)) ckb[(j / kGroupSlices) * 64 + lane] = sum;
       }
     }
 
@@ -350,7 +365,7 @@ __global__ __launch_bounds__(64) void z_stream1_kernel(ZParams p) {
     double t0 = 0.0, delta = 0.0, s = 0.0;
     int gsel = 0;
     bool undecided = true;
-    if (lane < len0) {
+    if (lane < n0) {
       const uint64_t gtok = (uint64_t)(p.tok_base + start0 + lane);
       const U4 o = philox4x32_10((uint32_t)gtok, (uint32_t)(gtok >> 32), (uint32_t)GGS_PURPOSE_Z << 24, p.iteration,
                                  (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
@@ -393,9 +408,9 @@ __global__ __launch_bounds__(64) void z_stream1_kernel(ZParams p) {
       if (ia < kGroupSlices) issue_slice(ia, (gr + ia) % R, rr);
       else if (has1) issue_slice(ia - kGroupSlices, (gr + ia) % R, ran);   // the next chunk's first slices
       wait_younger(has1 ? kAhead : min(kAhead, kGroupSlices - 1 - i));
-      if (lane < len0) {
+      if (lane < n0) {
         const unsigned char *rb = my_row + cur * kSliceBytes;
-        const unsigned char *tb = reinterpret_cast<const unsigned char *>(thb) + ((size_t)gsel * kGroupSlices + i) * kSliceTopics * 8;
+        const unsigned char *tb = reinterpret_cast<const unsigned char *>(thl) + ((size_t)gsel * kGroupSlices + i) * kSliceTopics * 8;
         D2 ph[kSliceUnits], th[kSliceUnits];
 #pragma unroll
         for (int u = 0; u < kSliceUnits; ++u) {
@@ -417,7 +432,7 @@ __global__ __launch_bounds__(64) void z_stream1_kernel(ZParams p) {
     }
     g = (g + NS + kGroupSlices) % R;
 
-    if (lane < len0) {
+    if (lane < n0) {
       int new_topic = found;
       if (undecided || found < 0 || found >= K || !(dprev > delta)) {
         // the exact replay: GGS:108-113 element by element from the raw row (rare; see the header)
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(64) void z_stream1_kernel(ZParams p) {
         while (sample > 0.0) {
           ++new_topic;
           if (new_topic >= K) break;
-          sample -= thb[new_topic] * row[new_topic];
+          sample -= thl[new_topic] * row[new_topic];
         }
         if (new_topic < 0 || new_topic >= K) {                     // GGS:116-118 (and the index past K Java would throw on)
           atomicOr(p.status, ST_INVALID_TOPIC);
@@ -439,8 +454,8 @@ __global__ __launch_bounds__(64) void z_stream1_kernel(ZParams p) {
     }
     if (!has1) break;
     c += 1;
-    start0 = start1; len0 = len1; doc0 = doc1; w0 = w1; ip0 = ip1;
-    start1 = start2; len1 = len2; doc1 = doc2;
+    start0 = start1; len0 = len1; doc0 = doc1; docb0 = docb1; w0 = w1; ip0 = ip1;
+    start1 = start2; len1 = len2; doc1 = doc2; docb1 = docb2;
 #pragma unroll
     for (int m = 0; m < 8; ++m) ra[m] = ran[m];
   }

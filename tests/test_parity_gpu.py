@@ -145,14 +145,15 @@ def test_wide_topic_rows_use_the_streaming_kernel(native, oracle, K):
     ns = (K + 15) // 16
     gs = 1 if ns <= 16 else 2 if ns <= 32 else 4                   # slices per checkpoint group: the smallest that keeps 16 checkpoints in registers
     groups = (ns + gs - 1) // gs
-    assert g.launch_info()["lds_bytes_z"] == 2 * 8192 + groups * gs * 128 + (groups * 512 if groups > 16 else 0)   # ring, theta row, checkpoints (LDS beyond 16 groups)
+    rows = 2 if K <= 512 else 1                                     # up to K = 512 a chunk may run across a document boundary: two theta rows
+    assert g.launch_info()["lds_bytes_z"] == 2 * 8192 + rows * groups * gs * 128 + (groups * 512 if groups > 16 else 0)   # ring, theta row(s), checkpoints (LDS beyond 16 groups)
     g.sweep(2)
     o.sweep(2)
     compare_state(g, o, "wide K=%d" % K)
 
 
 @pytest.mark.parametrize("mode,K", [(2, 33), (2, 48), (2, 100), (2, 184), (1, 192), (1, 185), (3, 48), (3, 257), (3, 1024), ("margin9", 257), ("margin9", 1024), ("margin13", 64),
-                                    ("margin13", 300), ("ldsck", 300), ("ldsck", 1024), ("group2", 200), ("group4", 200), ("group4", 500), (0, 5), (0, 100), (0, 257), ("fused", 20), ("fused", 100), ("chain", 9), ("nohot", 20), ("hot3", 100)])
+                                    ("margin13", 300), ("ldsck", 300), ("ldsck", 1024), ("group2", 200), ("group4", 200), ("group4", 500), ("onerow", 200), ("onerow", 40), ("tworows", 1024), ("tworows", 600), (0, 5), (0, 100), (0, 257), ("fused", 20), ("fused", 100), ("chain", 9), ("nohot", 20), ("hot3", 100)])
 def test_alternate_z_kernels_agree(native, oracle, K, mode, monkeypatch):
     """The z kernels are interchangeable: GGS_DEBUG_ZKERNEL=2 forces the (one-pass) streaming kernel below 193 topics,
     =3 its two-pass form (every row streamed twice, the walk replayed in full: the cross-check of the one-pass kernel's
@@ -163,9 +164,10 @@ def test_alternate_z_kernels_agree(native, oracle, K, mode, monkeypatch):
     GGS_DEBUG_CHAIN=1 ("chain") walks the Phi normalisers element by element instead of the exact parallel sums;
     GGS_DEBUG_HOT caps the hot-word table (0: every chunk is a cold chunk; 3: three hot words)."""
     env = {"fused": ("GGS_DEBUG_SPLIT", "0"), "chain": ("GGS_DEBUG_CHAIN", "1"), "nohot": ("GGS_DEBUG_HOT", "0"),
-           "hot3": ("GGS_DEBUG_HOT", "3"), "margin9": ("GGS_DEBUG_MARGIN", "1e9"), "margin13": ("GGS_DEBUG_MARGIN", "1e13"), "ldsck": ("GGS_DEBUG_REGCK", "0"), "group2": ("GGS_DEBUG_GROUP", "2"), "group4": ("GGS_DEBUG_GROUP", "4")}.get(mode, ("GGS_DEBUG_ZKERNEL", str(mode)))
+           "hot3": ("GGS_DEBUG_HOT", "3"), "margin9": ("GGS_DEBUG_MARGIN", "1e9"), "margin13": ("GGS_DEBUG_MARGIN", "1e13"), "ldsck": ("GGS_DEBUG_REGCK", "0"), "group2": ("GGS_DEBUG_GROUP", "2"), "group4": ("GGS_DEBUG_GROUP", "4"),
+           "onerow": ("GGS_DEBUG_TWOROWS", "0"), "tworows": ("GGS_DEBUG_TWOROWS", "1")}.get(mode, ("GGS_DEBUG_ZKERNEL", str(mode)))
     monkeypatch.setenv(*env)
-    if str(mode).startswith("margin") or mode == "ldsck" or str(mode).startswith("group"):
+    if str(mode).startswith("margin") or mode == "ldsck" or str(mode).startswith("group") or mode in ("onerow", "tworows"):
         monkeypatch.setenv("GGS_DEBUG_ZKERNEL", "2")
     c = random_corpus(150, 400, 140, seed=K + (mode if isinstance(mode, int) else 7), empty_every=11)
     g, o = make_pair(native, oracle, c, K, 0.1, 0.01, 70 + K, flags=native.FLAG_PARANOID, zseed=K)

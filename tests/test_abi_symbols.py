@@ -46,15 +46,16 @@ def test_ctypes_table_matches_header():
 
 
 def test_struct_layouts_match_header():
-    """ggs_config / ggs_timings as ctypes sees them == as a C compiler lays them out."""
+    """ggs_config / ggs_timings / ggs_exchange_ops as ctypes sees them == as a C compiler lays them out."""
     from ldagroupedgibbssampler_amd import _lib
     prog = r'''
 #include <stdio.h>
 #include <stddef.h>
 #include "ggs_hip.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu\n", sizeof(ggs_config), offsetof(ggs_config, alpha), offsetof(ggs_config, beta),
-         offsetof(ggs_config, seed), offsetof(ggs_config, flags), sizeof(ggs_timings), offsetof(ggs_timings, sweeps));
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ggs_config), offsetof(ggs_config, alpha), offsetof(ggs_config, beta),
+         offsetof(ggs_config, seed), offsetof(ggs_config, flags), sizeof(ggs_timings), offsetof(ggs_timings, sweeps),
+         offsetof(ggs_timings, exchange_ms), sizeof(ggs_exchange_ops), offsetof(ggs_exchange_ops, ctx), offsetof(ggs_exchange_ops, all_gather_i32));
   return 0;
 }'''
     exe = os.path.join(ROOT, "tests", ".abi_layout_probe")
@@ -64,9 +65,9 @@ int main(void) {
     finally:
         if os.path.exists(exe):
             os.remove(exe)
-    cfg, tm = _lib.GGSConfig, _lib.GGSTimings
+    cfg, tm, ops = _lib.GGSConfig, _lib.GGSTimings, _lib.GGSExchangeOps
     assert got == [ctypes.sizeof(cfg), cfg.alpha.offset, cfg.beta.offset, cfg.seed.offset, cfg.flags.offset,
-                   ctypes.sizeof(tm), tm.sweeps.offset]
+                   ctypes.sizeof(tm), tm.sweeps.offset, tm.exchange_ms.offset, ctypes.sizeof(ops), ops.ctx.offset, ops.all_gather_i32.offset]
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

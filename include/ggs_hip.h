@@ -271,7 +271,7 @@ int ggs_get_z_parts(ggs_handle *h, int32_t *parts);
 /* ---- primitives, exported so the parity tests can pin each layer ----------- */
 int ggs_debug_philox(int32_t device_id, int64_t n, const uint32_t *ctr /*n*4*/, const uint32_t *key /*n*2*/, uint32_t *out /*n*4*/);
 int ggs_debug_math(int32_t device_id, int32_t op /*0 log,1 pow,2 sqrt,3 div*/, int64_t n, const double *x, const double *y, double *out);
-int ggs_debug_draw(int32_t device_id, int32_t kind /*0 uniform,1 gaussian,2 gamma*/, uint64_t seed, uint32_t iteration,
+int ggs_debug_draw(int32_t device_id, int32_t kind /*0 uniform,1 gaussian,2 gamma (general loops),3 gamma as the kernels draw it: first try then general,4 as 3 with first-try results negated*/, uint64_t seed, uint32_t iteration,
                    uint32_t purpose, uint64_t elem0, int64_t n, const double *shape, double *out, int32_t *status);
 /* replaces: modelLogLikelihood (UPLDA:1644-1758), the Dirichlet-multinomial log likelihood of the current topic
  * assignments, split where a doc-sharded run splits it: doc_side covers THIS handle's documents (sum_d [...] +

@@ -308,7 +308,9 @@ int launch_phi_slice(ggs_handle *h, bool initial, const int32_t *cnt, int32_t cn
   gp.prior_pm = (1.0 / (double)V) * ((double)V * h->beta);
   gp.initial = initial ? 1 : 0;
   const int64_t kv = (int64_t)Ks * V;
-  hipLaunchKernelGGL(phi_gamma_kernel, dim3(grid_for(kv, 256, 2)), dim3(256), 0, h->stream, gp);
+  // tiles small enough that every CU holds several workgroups (a topic slice of one rank in eight is 0.65 M elements)
+  gp.tile = (int32_t)std::max<int64_t>(256, std::min<int64_t>(kPhiTile, (kv / 2048 + 255) / 256 * 256));
+  hipLaunchKernelGGL(phi_gamma_kernel, dim3(grid_for(kv, gp.tile)), dim3(256), 0, h->stream, gp);
   launch_column_sum<double, false>(h, out, out_pitch, Ks, tot);
   hipLaunchKernelGGL(phi_normalise_kernel, dim3(grid_for(kv, 256, 2)), dim3(256), 0, h->stream, out, tot, Ks, out_pitch, V, phi_mean);
   HIP_TRY(h, hipGetLastError());
@@ -863,7 +865,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
   }
   {
     int B = 64;
-    auto lds_of = [&](int b) { const int bp = b | 1; return (int)((size_t)h->K * bp * 8 + (size_t)b * 20); };
+    auto lds_of = [&](int b) { const int bp = b | 1; return (int)((size_t)h->K * bp * 8 + (size_t)b * 20 + kThetaQueueBytes); };
     while (B > 1 && lds_of(B) > 32 * 1024) B >>= 1;
     if (lds_of(B) > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);
     // The request is padded to a quarter of the CU's LDS: at most 4 workgroups (16 waves) of the theta draw per CU.

@@ -49,6 +49,10 @@ struct SumParams {
   int32_t pitch, K, V, nseg;
 };
 
+// These kernels are short, latency-bound links of the chain between the z step and the next one, and they run while
+// the theta draw of the side stream keeps every SIMD busy: their waves ask for instruction issue ahead of its waves.
+__device__ __forceinline__ void chain_priority() { __builtin_amdgcn_s_setprio(3); }
+
 __device__ __forceinline__ int binade_of(double x) { return ((hi32(x) >> 20) & 0x7ff) - 1023; }   // 1024 for NaN/inf, -1023 for 0
 
 template <typename T, bool MAGNITUDE>
@@ -58,6 +62,7 @@ __device__ __forceinline__ double sum_elem(const T *src, size_t idx, double beta
 
 template <typename T, bool MAGNITUDE>
 __global__ __launch_bounds__(kSumBlock) void sum_seg_kernel(SumParams p) {
+  chain_priority();
   const int k = blockIdx.y * kSumBlock + threadIdx.x;
   if (k >= p.K) return;
   const int i = blockIdx.x;
@@ -84,6 +89,7 @@ __global__ __launch_bounds__(kSumBlock) void sum_seg_kernel(SumParams p) {
 
 // one wave per topic: exclusive prefix over the segment sums, in place; pref[nseg][k] = total
 __global__ __launch_bounds__(64) void sum_prefix_kernel(SumParams p) {
+  chain_priority();
   const int k = blockIdx.x, lane = threadIdx.x;
   const int per = (p.nseg + 63) / 64;
   const int i0 = min(lane * per, p.nseg), i1 = min(i0 + per, p.nseg);
@@ -106,6 +112,7 @@ __global__ __launch_bounds__(64) void sum_prefix_kernel(SumParams p) {
 
 template <typename T, bool MAGNITUDE>
 __global__ __launch_bounds__(kSumBlock) void sum_segfn_kernel(SumParams p) {
+  chain_priority();
   const int k = blockIdx.y * kSumBlock + threadIdx.x;
   if (k >= p.K) return;
   const int i = blockIdx.x;
@@ -171,6 +178,7 @@ constexpr int kWalkSuper = 256, kWalkGroups = kWalkSuper / 64, kWalkRawSlots = 1
 
 template <typename T, bool MAGNITUDE>
 __global__ __launch_bounds__(64) void sum_walk_kernel(SumParams p) {
+  chain_priority();
   __shared__ double tup[kWalkSuper][4];                     // 8 KiB
   __shared__ double raw[kWalkRawSlots][kSumSegRows];        // 6 KiB
   __shared__ int16_t dirty_list[kWalkSuper];

@@ -48,7 +48,8 @@ enum StatusBits : uint32_t {
 // One workgroup owns `docs_per_block` consecutive documents.
 //   phase 1  histogram of the current z per document (LDS atomics)
 //   phase 2  one lane per document: magnitude = sum_k (n_dk + alpha_k), in k order
-//   phase 3  all lanes: Gamma(partition*magnitude) draws, one (doc, k) pair each
+//   phase 3  all lanes: Gamma(partition*magnitude) draws, one (doc, k) pair each: straight-line first try, then the
+//            general rejection loops for the elements it left over, gathered into full waves
 //   phase 4  one lane per document: sum of the gammas, in k order
 //   phase 5  all lanes: normalise, clamp <=0 to Double.MIN_VALUE, coalesced store
 // LDS: one 8-byte cell per (k, document), [K][BP] with BP = docs_per_block | 1 (odd => the
@@ -67,6 +68,9 @@ struct ThetaParams {
   int32_t K, docs_per_block;
 };
 
+constexpr int kGammaQueue = 768;             // uint16 element indices: a workgroup's cells number < 65536 (LDS / 8)
+constexpr int kThetaQueueBytes = 8 + 2 * kGammaQueue;
+
 template <int BLOCK>
 __global__ __launch_bounds__(BLOCK) void theta_kernel(ThetaParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -76,12 +80,15 @@ __global__ __launch_bounds__(BLOCK) void theta_kernel(ThetaParams p) {
   double *mag = gam + (size_t)K * BP;                                // [B]
   double *tot = mag + B;                                             // [B]
   int32_t *len = reinterpret_cast<int32_t *>(tot + B);               // [B]
+  int32_t *qn = len + B;                                             // [2] (one used) fill of the queue below
+  uint16_t *queue = reinterpret_cast<uint16_t *>(qn + 2);            // [kGammaQueue] elements left to the general draw
 
   const int tid = threadIdx.x;
   const int64_t d0 = (int64_t)blockIdx.x * B;
   const int nb = (int)min((int64_t)B, p.num_docs - d0);
 
   for (int i = tid; i < K * BP; i += BLOCK) hist[2 * i] = 0;
+  if (tid == 0) *qn = 0;
   __syncthreads();
 
   constexpr int NW = BLOCK / 64;
@@ -100,22 +107,40 @@ __global__ __launch_bounds__(BLOCK) void theta_kernel(ThetaParams p) {
   }
   __syncthreads();
 
+  // phase 3a: every lane tries the straight-line draw (rgamma_first_try); the ~14 % of elements it does not settle are
+  // queued and drawn by the general rgamma in full waves (3b) -- or on the spot when the queue is full
+  auto shape_of = [&](int k, int b) {
+    const double pk = (double)hist[2 * (k * BP + b)] + p.alpha[k];   // GGS:68
+    const double m = mag[b];
+    return (pk / m) * m;                                             // partition[i] * magnitude
+  };
+  auto draw_general = [&](int k, int b, double shape) {
+    DrawStream rs(p.seed, p.iteration, GGS_PURPOSE_THETA, (uint64_t)(p.doc_base + d0 + b) * (uint64_t)K + (uint64_t)k);
+    const double g = rgamma(rs, shape);
+    if (rs.exhausted) atomicOr(p.status, ST_RNG_EXHAUSTED);
+    return g;
+  };
   for (int i = tid; i < nb * K; i += BLOCK) {
     const int k = i / nb, b = i - k * nb;
     if (len[b] == 0) continue;                                       // GGS:52-53
-    const double pk = (double)hist[2 * (k * BP + b)] + p.alpha[k];   // GGS:68
-    const double m = mag[b];
-    const double shape = (pk / m) * m;                               // partition[i] * magnitude
+    const double shape = shape_of(k, b);
     double g;
     if (shape > 0) {
-      DrawStream rs(p.seed, p.iteration, GGS_PURPOSE_THETA, (uint64_t)(p.doc_base + d0 + b) * (uint64_t)K + (uint64_t)k);
-      g = rgamma(rs, shape);
-      if (rs.exhausted) atomicOr(p.status, ST_RNG_EXHAUSTED);
+      if (!rgamma_first_try(p.seed, p.iteration, GGS_PURPOSE_THETA, (uint64_t)(p.doc_base + d0 + b) * (uint64_t)K + (uint64_t)k, shape, g)) {
+        const int slot = atomicAdd(qn, 1);
+        if (slot < kGammaQueue) { queue[slot] = (uint16_t)i; continue; }   // the cell keeps its count until 3b
+        g = draw_general(k, b, shape);
+      }
     } else {
       g = __builtin_nan("");
       atomicOr(p.status, ST_BAD_SHAPE);
     }
     gam[k * BP + b] = g;
+  }
+  __syncthreads();
+  for (int q = tid, m = min(*qn, kGammaQueue); q < m; q += BLOCK) {
+    const int i = queue[q], k = i / nb, b = i - k * nb;
+    gam[k * BP + b] = draw_general(k, b, shape_of(k, b));
   }
   __syncthreads();
 
@@ -160,6 +185,7 @@ struct CountParams {
 constexpr int kCountSegsPerBlock = 8;   // most words are rare: a workgroup per <= 256-token segment would be mostly dispatch overhead
 
 __global__ __launch_bounds__(256) void count_sorted_kernel(CountParams p) {
+  __builtin_amdgcn_s_setprio(3);   // a link of the chain to the next z step: issue ahead of the theta draw beside it (ggs_exact_sum.hpp)
   extern __shared__ __align__(16) unsigned char smem[];
   int32_t *hist = reinterpret_cast<int32_t *>(smem);
   const int tid = threadIdx.x, K = p.K;
@@ -316,37 +342,69 @@ struct PhiGammaParams {
   double beta;         // sweep draw: shape = ((beta+n)/mag)*mag
   double prior_pm;     // initial draw: partition*magnitude = (1.0/V)*(V*beta)
   int32_t initial;
+  int32_t tile;        // elements per workgroup and round: a multiple of 256, <= kPhiTile
 };
 
+// A workgroup takes tiles of up to 2048 consecutive elements: the straight-line first try for all of them, then the general
+// rejection loops for the elements it left over (queued in LDS, so that they fill whole waves; drawn on the spot when
+// the queue is full).
+constexpr int kPhiTile = 2048, kPhiQueue = 640;
+
 __global__ __launch_bounds__(256) void phi_gamma_kernel(PhiGammaParams p) {
+  __shared__ uint16_t queue[kPhiQueue];
+  __shared__ int32_t qn;
+  const int tid = threadIdx.x;
   const int64_t n = (int64_t)p.V * p.K;
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int v = (int)(i / p.K), k = (int)(i - (int64_t)v * p.K);
+  const int64_t tiles = (n + p.tile - 1) / p.tile;
+  auto shape_of = [&](int v, int k) {
     const int32_t cnt = p.n_wk[(size_t)v * p.cnt_pitch + k];
-    double shape;
-    if (p.initial) {
-      shape = (cnt == 0) ? p.prior_pm : p.prior_pm + (double)cnt;   // MarsagliaSparseDirichlet.java:37-41
-    } else {
-      const double pk = p.beta + (double)cnt;                       // GGS:188
-      const double m = p.mag[k];
-      shape = (pk / m) * m;
+    if (p.initial) return (cnt == 0) ? p.prior_pm : p.prior_pm + (double)cnt;   // MarsagliaSparseDirichlet.java:37-41
+    const double pk = p.beta + (double)cnt;                                     // GGS:188
+    const double m = p.mag[k];
+    return (pk / m) * m;
+  };
+  auto draw_general = [&](int v, int k, double shape) {
+    DrawStream rs(p.seed, p.iteration, p.purpose, (uint64_t)(p.k0 + k) * (uint64_t)p.V + (uint64_t)v);
+    const double g = rgamma(rs, shape);
+    if (rs.exhausted) atomicOr(p.status, ST_RNG_EXHAUSTED);
+    return g;
+  };
+  for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+    const int64_t base = tile * p.tile;
+    if (tid == 0) qn = 0;
+    __syncthreads();
+#pragma unroll 1
+    for (int j = tid; j < p.tile; j += 256) {
+      const int64_t i = base + j;
+      if (i >= n) break;
+      const int v = (int)(i / p.K), k = (int)(i - (int64_t)v * p.K);
+      const double shape = shape_of(v, k);
+      double g;
+      if (shape > 0) {
+        if (!rgamma_first_try(p.seed, p.iteration, p.purpose, (uint64_t)(p.k0 + k) * (uint64_t)p.V + (uint64_t)v, shape, g)) {
+          const int slot = atomicAdd(&qn, 1);
+          if (slot < kPhiQueue) { queue[slot] = (uint16_t)j; continue; }
+          g = draw_general(v, k, shape);
+        }
+      } else {
+        g = __builtin_nan("");
+        atomicOr(p.status, ST_BAD_SHAPE);
+      }
+      p.phiT[(size_t)v * p.Kp + k] = g;
     }
-    double g;
-    if (shape > 0) {
-      DrawStream rs(p.seed, p.iteration, p.purpose, (uint64_t)(p.k0 + k) * (uint64_t)p.V + (uint64_t)v);
-      g = rgamma(rs, shape);
-      if (rs.exhausted) atomicOr(p.status, ST_RNG_EXHAUSTED);
-    } else {
-      g = __builtin_nan("");
-      atomicOr(p.status, ST_BAD_SHAPE);
+    __syncthreads();
+    for (int q = tid, m = min(qn, kPhiQueue); q < m; q += 256) {
+      const int64_t i = base + queue[q];
+      const int v = (int)(i / p.K), k = (int)(i - (int64_t)v * p.K);
+      p.phiT[(size_t)v * p.Kp + k] = draw_general(v, k, shape_of(v, k));
     }
-    p.phiT[(size_t)v * p.Kp + k] = g;
+    __syncthreads();
   }
 }
 
 __global__ __launch_bounds__(256) void phi_normalise_kernel(double *phiT, const double *tot, int32_t K, int32_t Kp, int32_t V,
                                                             double *phi_mean /* [V][K] or null */) {
+  __builtin_amdgcn_s_setprio(3);
   const int64_t n = (int64_t)V * K;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -463,9 +521,12 @@ __global__ void debug_draw_kernel(int kind, uint64_t seed, uint32_t iteration, u
   double r;
   if (kind == 0) r = rs.next_double();
   else if (kind == 1) r = rs.next_gaussian();
-  else {
+  else if (kind == 2 || !(shape[i] > 0)) {
     if (shape[i] > 0) r = rgamma(rs, shape[i]);
     else { r = __builtin_nan(""); atomicOr(status, ST_BAD_SHAPE); }
+  } else {                                                           // kind 3: as the theta and Phi kernels draw
+    if (!rgamma_first_try(seed, iteration, purpose, elem0 + (uint64_t)i, shape[i], r)) r = rgamma(rs, shape[i]);
+    else if (kind == 4) r = -r;                                      // kind 4 marks the draws the first try settled
   }
   if (rs.exhausted) atomicOr(status, ST_RNG_EXHAUSTED);
   out[i] = r;

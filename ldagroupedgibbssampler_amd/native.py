@@ -363,7 +363,7 @@ def debug_draw(kind, seed, iteration, purpose, elem0, n=None, shape=None, device
         n = shape.size
     out = np.empty(n, np.float64)
     st = C.c_int32()
-    rc = L.ggs_debug_draw(device_id, {"uniform": 0, "gaussian": 1, "gamma": 2}[kind], seed, iteration, purpose, elem0, n,
+    rc = L.ggs_debug_draw(device_id, {"uniform": 0, "gaussian": 1, "gamma": 2, "gamma_first_try": 3, "gamma_first_try_marked": 4}[kind], seed, iteration, purpose, elem0, n,
                           _dp(shape) if shape is not None else None, _dp(out), C.byref(st))
     if rc:
         raise GGSError(rc, "ggs_debug_draw")

@@ -76,7 +76,16 @@ def test_draw_streams_bit_exact(native, oracle):
                             [1.0, 1e-6, 0.01, 0.1, 5.0, 1e4]])
     dev, st = native.debug_draw("gamma", seed, it, native.PURPOSE_PHI, 99, shape=shape)
     assert st == 0
-    assert_bit_equal(dev, oracle.gammas(seed, it, oracle.PURPOSE_PHI, 99, shape), "Marsaglia-Tsang gamma")
+    want = oracle.gammas(seed, it, oracle.PURPOSE_PHI, 99, shape)
+    assert_bit_equal(dev, want, "Marsaglia-Tsang gamma")
+    # the way the theta and Phi kernels draw: a straight-line first try, the general loops for what it leaves over
+    dev, st = native.debug_draw("gamma_first_try", seed, it, native.PURPOSE_PHI, 99, shape=shape)
+    assert st == 0
+    assert_bit_equal(dev, want, "gamma, first try + general")
+    marked, _ = native.debug_draw("gamma_first_try_marked", seed, it, native.PURPOSE_PHI, 99, shape=shape)
+    settled = np.signbit(marked) & (want > 0)
+    assert_bit_equal(np.abs(marked), want, "gamma, marked")
+    assert 0.70 < settled.mean() < 0.92, settled.mean()       # measured 79 %: both polar pairs rejected 4.6 %, the squeeze failed, v <= 0
 
 
 # ---------------------------------------------------------------- full path

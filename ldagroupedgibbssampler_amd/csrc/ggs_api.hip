@@ -94,6 +94,7 @@ struct ggs_handle {
   // (side stream) while the following parts are still being sampled: the streaming z kernel waits on memory, the theta
   // draw on the VALU.  The last part's theta runs beside the Phi phase as before.
   int32_t z_parts = 1, theta_lds_beside_z = 0;
+  int32_t gamma_queue_cap = 1 << 20;   // GGS_DEBUG_GAMMA_QUEUE: a tiny queue sends the leftovers of the first try down the on-the-spot path
   std::vector<int64_t> part_doc, part_chunk;           // [z_parts + 1] boundaries
   hipEvent_t ev_part[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   int64_t theta_ahead_iter = INT64_MIN;     // iteration the side-stream theta was drawn for, or none
@@ -310,6 +311,7 @@ int launch_phi_slice(ggs_handle *h, bool initial, const int32_t *cnt, int32_t cn
   const int64_t kv = (int64_t)Ks * V;
   // tiles small enough that every CU holds several workgroups (a topic slice of one rank in eight is 0.65 M elements)
   gp.tile = (int32_t)std::max<int64_t>(256, std::min<int64_t>(kPhiTile, (kv / 2048 + 255) / 256 * 256));
+  gp.queue_cap = std::min(kPhiQueue, h->gamma_queue_cap);
   hipLaunchKernelGGL(phi_gamma_kernel, dim3(grid_for(kv, gp.tile)), dim3(256), 0, h->stream, gp);
   launch_column_sum<double, false>(h, out, out_pitch, Ks, tot);
   hipLaunchKernelGGL(phi_normalise_kernel, dim3(grid_for(kv, 256, 2)), dim3(256), 0, h->stream, out, tot, Ks, out_pitch, V, phi_mean);
@@ -369,7 +371,7 @@ int launch_theta(ggs_handle *h, hipStream_t stream, double *dst, int32_t iterati
   ThetaParams tp{};
   tp.doc_ptr = h->d_doc_ptr + d0; tp.z = h->d_z; tp.alpha = h->d_alpha; tp.theta = dst + (size_t)d0 * h->K; tp.status = h->d_status;
   tp.num_docs = d1 - d0; tp.doc_base = h->doc_base + d0; tp.seed = h->seed; tp.iteration = (uint32_t)iteration;
-  tp.K = h->K; tp.docs_per_block = h->theta_docs_per_block;
+  tp.K = h->K; tp.docs_per_block = h->theta_docs_per_block; tp.queue_cap = std::min(kGammaQueue, h->gamma_queue_cap);
   const int64_t grid = (d1 - d0 + h->theta_docs_per_block - 1) / h->theta_docs_per_block;
   hipLaunchKernelGGL(theta_kernel<kThetaBlock>, dim3((unsigned)grid), dim3(kThetaBlock), lds ? lds : h->theta_lds, stream, tp);
   HIP_TRY(h, hipGetLastError());
@@ -964,6 +966,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     if (hipEventCreate(&E.th0) != hipSuccess || hipEventCreate(&E.th1) != hipSuccess) return bail(GGS_ERR_HIP);
   }
   if (const char *e = std::getenv("GGS_DEBUG_NO_OVERLAP")) h->overlap_theta = std::atoi(e) == 0;
+  if (const char *e = std::getenv("GGS_DEBUG_GAMMA_QUEUE")) h->gamma_queue_cap = std::max(0, std::atoi(e));
   {
     // lowest priority: the theta draw fills whatever the Phi phase (on the caller's stream) leaves idle
     int lo = 0, hi = 0;

@@ -71,6 +71,7 @@ struct ThetaParams {
   uint64_t seed;
   uint32_t iteration;
   int32_t K, docs_per_block;
+  int32_t queue_cap;   // <= kGammaQueue (smaller only in tests: the draw-on-the-spot path of a full queue)
 };
 
 constexpr int kGammaQueue = 768;             // uint16 element indices: a workgroup's cells number < 65536 (LDS / 8)
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(BLOCK) void theta_kernel(ThetaParams p) {
     if (shape > 0) {
       if (!rgamma_first_try(p.seed, p.iteration, GGS_PURPOSE_THETA, (uint64_t)(p.doc_base + d0 + b) * (uint64_t)K + (uint64_t)k, shape, g)) {
         const int slot = atomicAdd(qn, 1);
-        if (slot < kGammaQueue) { queue[slot] = (uint16_t)i; continue; }   // the cell keeps its count until 3b
+        if (slot < p.queue_cap) { queue[slot] = (uint16_t)i; continue; }   // the cell keeps its count until 3b
         g = draw_general(k, b, shape);
       }
     } else {
@@ -144,7 +145,7 @@ __global__ __launch_bounds__(BLOCK) void theta_kernel(ThetaParams p) {
     gam[k * BP + b] = g;
   }
   __syncthreads();
-  for (int q = tid, m = min(*qn, kGammaQueue); q < m; q += BLOCK) {
+  for (int q = tid, m = min(*qn, p.queue_cap); q < m; q += BLOCK) {
     const int i = queue[q], k = udiv_small(i, m_nb), b = i - k * nb;
     gam[k * BP + b] = draw_general(k, b, shape_of(k, b));
   }
@@ -349,6 +350,7 @@ struct PhiGammaParams {
   double prior_pm;     // initial draw: partition*magnitude = (1.0/V)*(V*beta)
   int32_t initial;
   int32_t tile;        // elements per workgroup and round: a multiple of 256, <= kPhiTile
+  int32_t queue_cap;   // <= kPhiQueue (smaller only in tests)
 };
 
 // A workgroup takes tiles of up to 2048 consecutive elements: the straight-line first try for all of them, then the general
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(256) void phi_gamma_kernel(PhiGammaParams p) {
       if (shape > 0) {
         if (!rgamma_first_try(p.seed, p.iteration, p.purpose, (uint64_t)(p.k0 + k) * (uint64_t)p.V + (uint64_t)v, shape, g)) {
           const int slot = atomicAdd(&qn, 1);
-          if (slot < kPhiQueue) { queue[slot] = (uint16_t)j; continue; }
+          if (slot < p.queue_cap) { queue[slot] = (uint16_t)j; continue; }
           g = draw_general(v, k, shape);
         }
       } else {
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(256) void phi_gamma_kernel(PhiGammaParams p) {
       p.phiT[(size_t)v * p.Kp + k] = g;
     }
     __syncthreads();
-    for (int q = tid, m = min(qn, kPhiQueue); q < m; q += 256) {
+    for (int q = tid, m = min(qn, p.queue_cap); q < m; q += 256) {
       const int j = queue[q], dv = udiv_small(k0 + j, m_K), v = v0 + dv, k = k0 + j - dv * p.K;
       p.phiT[(size_t)v * p.Kp + k] = draw_general(v, k, shape_of(v, k));
     }

@@ -352,6 +352,8 @@ def main():
     def exchange_factory():
         if args.exchange == "torch":
             return TorchHipExchange
+        if os.environ.get("GGS_BENCH_FAIL_NATIVE"):      # rehearsal of run_sharded_or_fall_back
+            raise RuntimeError("native exchange refused (GGS_BENCH_FAIL_NATIVE)")
         return rccl_exchange(rank, world) if args.backend == "nccl" else gloo_callback_exchange(rank, world)
 
     K = args.topics
@@ -360,6 +362,16 @@ def main():
         """One measurement over `world` ranks: dict(dt, phases, docs, tokens, n_local, V, info, local corpus)"""
         corpus = synthetic_lda_corpus(args.docs, args.types, args.mean_len, true_topics=100, seed=args.seed + (rank if weak else 0))
         h = make_handle(native, K, corpus.num_types, args, local_rank)
+        try:
+            return run_sharded_on(h, corpus, weak)
+        except Exception:
+            try:
+                h.close()
+            except Exception:       # noqa: BLE001 -- the first error is the one to report
+                pass
+            raise
+
+    def run_sharded_on(h, corpus, weak):
         if weak:
             sizes = gather_shard_sizes(corpus, rank, world, device="cuda" if args.backend == "nccl" else None)
             total_docs, total_tokens = sum(d for d, _ in sizes), sum(t for _, t in sizes)
@@ -388,14 +400,37 @@ def main():
         h.close()                       # before a second leg builds its handle: hardware queues are few
         return res
 
+    fallback = []
+
+    def run_sharded_or_fall_back(weak):
+        """A native exchange that cannot be set up on every rank (librccl not loadable, ncclCommInitRank refused) would cost
+        the whole scaling record: all ranks then agree to repeat the leg over torch.distributed (round 1's form: dense
+        count all-reduce, Phi re-drawn everywhere) and the line says so.  Only failures every rank sees before its first
+        sweep are covered -- one rank failing inside a collective leaves the others waiting, as with any collective."""
+        err = None
+        try:
+            res = run_sharded(weak)
+        except Exception as e:      # noqa: BLE001 -- whatever it was, the other ranks must hear of it
+            res, err = None, "%s: %s" % (type(e).__name__, e)
+        bad = torch.tensor([0 if err is None else 1], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if int(bad.item()) == 0:
+            return res
+        if args.exchange != "native":
+            raise RuntimeError(err or "another rank failed")
+        sys.stderr.write("[bench rank %d] native exchange failed (%s); falling back to --exchange torch\n" % (rank, err or "on another rank"))
+        fallback.append(err or "failed on another rank")
+        args.exchange = "torch"
+        return run_sharded(weak)
+
     sha = csrc_sha16()
     other = None
     corpus = z0 = None
     if sharded:
         weak_first = args.scaling == "weak"
-        r = run_sharded(weak_first)
+        r = run_sharded_or_fall_back(weak_first)
         if world > 1 and not args.no_weak_leg:
-            r2 = run_sharded(not weak_first)
+            r2 = run_sharded_or_fall_back(not weak_first)
             other = {"value": round(r2["tokens"] * args.steps / r2["dt"] / 1e6, 3), "unit": "M tokens/s",
                      "ms_per_step": round(r2["dt"] / args.steps * 1e3, 4), "phase_ms_per_sweep": r2["phases"],
                      "workload": ("every rank brings D=%d documents: D=%d, N=%d tokens over %d ranks" % (args.docs, r2["docs"], r2["tokens"], world)) if not weak_first
@@ -421,6 +456,8 @@ def main():
                    else "native exchange over the callback provider (gloo, host staged)" if args.exchange == "native"
                    else "torch.distributed int32 count all-reduce (%s), Phi re-drawn on every rank" % ("RCCL" if args.backend == "nccl" else "gloo"))
             par = "doc-sharded x%d, %s%s" % (world, how, ", ALL RANKS ON ONE GPU (rehearsal)" if args.single_device else "")
+            if fallback:
+                par += " [FELL BACK from the native exchange: %s]" % fallback[0][:200]
         else:
             par = "1 GPU"
         line = {

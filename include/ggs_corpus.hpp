@@ -8,6 +8,7 @@
 //   cc/mallet/pipe: SimpleTokenizerLarge.java:52-135, NumericAlsoTokenizer, KeepConnectorPunctuation{TokenizerLarge,
 //   NumericAlsoTokenizer}) -> stoplist -> alphabet in first-appearance order; rare_threshold > 0 adds a counting pass
 //   whose rare types (count < threshold) join the stoplist (:243-289).
+//   util/LDAUtils.loadInstancesKeep (:355-452) + pipe/TfIdfPipe.java: the same with a TF-IDF cut of the vocabulary.
 //
 // Unicode: general categories and lower-casing come from include/ggs_unicode_tables.hpp (generated, Unicode 13.0); a
 // JDK speaks its own Unicode version (Java 8: 6.2) and lower-cases in the default locale -- corpora in ASCII / Latin-1
@@ -15,6 +16,7 @@
 // and this loader against the Python one on the bundled datasets and on random Unicode text.
 #pragma once
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <fstream>
 #include <stdexcept>
@@ -193,6 +195,7 @@ inline bool match_line(const std::string &line, std::string &name, std::string &
 struct LoadOptions : TokenizerOptions {
   std::string stoplist_file;       // empty = USE_EMPTY_STOPLIST
   int prune_count = 0;             // cfg key rare_threshold
+  int keep_count = 0;              // cfg key tfidf_vocab_size (load_instances_keep)
 };
 
 struct Dataset {
@@ -219,19 +222,8 @@ inline void for_each_instance(const std::string &path, PerLine &&fn) {
   }
 }
 
-// LDAUtils.loadInstancesPrune.  `alphabet`: an existing vocabulary to extend (a test set against the training
-// alphabet); `frozen` = Alphabet.stopGrowth(): unknown words are dropped.
-inline Dataset load_instances_prune(const std::string &path, const LoadOptions &opt, const std::vector<std::string> *alphabet = nullptr, bool frozen = false) {
-  Stoplist stoplist;
-  if (!opt.stoplist_file.empty()) stoplist = read_stoplist(opt.stoplist_file);
-  if (opt.prune_count > 0) {
-    std::unordered_map<std::string, int64_t> counts;
-    for_each_instance(path, [&](const std::string &, const std::string &, const std::string &data) {
-      tokenize(to_lower(decode_utf8(data)), stoplist, opt, [&](const std::string &t) { ++counts[t]; });
-    });
-    for (const auto &kv : counts)
-      if (kv.second < opt.prune_count) stoplist.insert(kv.first);          // FeatureCountPipe.addPrunedWordsToStoplist
-  }
+// The second halves of loadInstancesPrune and loadInstancesKeep (LDAUtils.java:291-330, 413-452)
+inline Dataset load_with_stoplist(const std::string &path, const Stoplist &stoplist, const LoadOptions &opt, const std::vector<std::string> *alphabet, bool frozen) {
   Dataset ds;
   std::unordered_map<std::string, int32_t> index, label_index;
   if (alphabet) {
@@ -258,6 +250,64 @@ inline Dataset load_instances_prune(const std::string &path, const LoadOptions &
     ds.labels.push_back(li->second);
   });
   return ds;
+}
+
+// LDAUtils.loadInstancesPrune.  `alphabet`: an existing vocabulary to extend (a test set against the training
+// alphabet); `frozen` = Alphabet.stopGrowth(): unknown words are dropped.
+inline Dataset load_instances_prune(const std::string &path, const LoadOptions &opt, const std::vector<std::string> *alphabet = nullptr, bool frozen = false) {
+  Stoplist stoplist;
+  if (!opt.stoplist_file.empty()) stoplist = read_stoplist(opt.stoplist_file);
+  if (opt.prune_count > 0) {
+    std::unordered_map<std::string, int64_t> counts;
+    for_each_instance(path, [&](const std::string &, const std::string &, const std::string &data) {
+      tokenize(to_lower(decode_utf8(data)), stoplist, opt, [&](const std::string &t) { ++counts[t]; });
+    });
+    for (const auto &kv : counts)
+      if (kv.second < opt.prune_count) stoplist.insert(kv.first);          // FeatureCountPipe.addPrunedWordsToStoplist
+  }
+  return load_with_stoplist(path, stoplist, opt, alphabet, frozen);
+}
+
+// LDAUtils.loadInstancesKeep (LDAUtils.java:355-452): the vocabulary cut by TF-IDF.  With opt.keep_count > 0 a first pass
+// counts, per type, its occurrences (tf) and the documents it occurs in (df) -- indexing the caller's alphabet when one
+// is given, as Java does --, every type ranked keep_count or later by tf * ln(D / df) (pipe/TfIdfPipe.java:73-104; 0 when
+// either count is 0) joins the stoplist and the file is read again.  Equal weights keep their alphabet order: a stable
+// sort under MALLET 2.0.8's IDSorter.compareTo, which answers 0 for equal weights (restated from the published source).
+// `grown`: receives the alphabet as the first pass left it (Java grows the caller's Alphabet object in place).
+inline Dataset load_instances_keep(const std::string &path, const LoadOptions &opt, const std::vector<std::string> *alphabet = nullptr, bool frozen = false,
+                                   std::vector<std::string> *grown = nullptr) {
+  Stoplist stoplist;
+  if (!opt.stoplist_file.empty()) stoplist = read_stoplist(opt.stoplist_file);
+  std::vector<std::string> vocab;
+  if (alphabet) vocab = *alphabet;
+  if (opt.keep_count > 0) {
+    std::unordered_map<std::string, int32_t> index;
+    for (size_t i = 0; i < vocab.size(); ++i) index.emplace(vocab[i], (int32_t)i);
+    std::vector<int64_t> tf(vocab.size(), 0), df(vocab.size(), 0), last_doc(vocab.size(), -1);
+    int64_t docs = 0;
+    for_each_instance(path, [&](const std::string &, const std::string &, const std::string &data) {
+      tokenize(to_lower(decode_utf8(data)), stoplist, opt, [&](const std::string &t) {
+        auto it = index.find(t);
+        if (it == index.end()) {
+          if (frozen) return;
+          it = index.emplace(t, (int32_t)vocab.size()).first;
+          vocab.push_back(t); tf.push_back(0); df.push_back(0); last_doc.push_back(-1);
+        }
+        const size_t i = (size_t)it->second;
+        ++tf[i];
+        if (last_doc[i] != docs) { last_doc[i] = docs; ++df[i]; }
+      });
+      ++docs;
+    });
+    std::vector<double> w(vocab.size());
+    for (size_t i = 0; i < w.size(); ++i) w[i] = (tf[i] == 0 || df[i] == 0) ? 0.0 : (double)tf[i] * std::log((double)docs / (double)df[i]);
+    std::vector<int32_t> ranks(vocab.size());
+    for (size_t i = 0; i < ranks.size(); ++i) ranks[i] = (int32_t)i;
+    std::stable_sort(ranks.begin(), ranks.end(), [&](int32_t a, int32_t b) { return w[(size_t)a] > w[(size_t)b]; });
+    for (size_t r = (size_t)opt.keep_count; r < ranks.size(); ++r) stoplist.insert(vocab[(size_t)ranks[r]]);
+  }
+  if (grown) *grown = vocab;
+  return load_with_stoplist(path, stoplist, opt, alphabet ? &vocab : nullptr, frozen);   // a caller's alphabet: as the first pass grew it
 }
 
 }  // namespace corpus

@@ -12,6 +12,8 @@ LDAUtils.java:140-182 -> loadInstancesPrune, :233-330):
           --StringList2FeatureSequence(alphabet)-->  type ids       first appearance order
     rare_threshold > 0: a first pass counts every type; types seen fewer than `rare_threshold` times join the stoplist
     (FeatureCountPipe.addPrunedWordsToStoplist) and the file is read again with a fresh alphabet      :243-289
+    tfidf_vocab_size > 0 (loadInstancesKeep, :355-452) instead ranks the types by tf * ln(D / df) (pipe/TfIdfPipe.java) and
+    stops all but the first tfidf_vocab_size of them
 
 Not under /root/reference (cc.mallet:mallet:2.0.8, pom.xml:130-134), restated from the published sources: CsvIterator
 (one instance per line, `find()` of the regex, IllegalStateException on a line that does not match), CharSequenceLowercase
@@ -126,6 +128,12 @@ def load_instances_prune(path, stoplist_file=None, prune_count=0, keep_numbers=T
             for t in tokenize(data.lower(), stoplist, keep_numbers, keep_connectors, max_buf_size):
                 counts[t] = counts.get(t, 0) + 1
         stoplist = stoplist | {t for t, c in counts.items() if c < prune_count}           # FeatureCountPipe.addPrunedWordsToStoplist
+    return _load_with_stoplist(path, stoplist, keep_numbers, max_buf_size, keep_connectors, data_alphabet)
+
+
+def _load_with_stoplist(path, stoplist, keep_numbers, max_buf_size, keep_connectors, data_alphabet):
+    """The second halves of loadInstancesPrune and loadInstancesKeep (LDAUtils.java:291-330, 413-452): lower case,
+    tokenise, drop stop words, index against the alphabet, label."""
     frozen = isinstance(data_alphabet, tuple)
     vocab = list(data_alphabet) if data_alphabet is not None else []
     index = {w: i for i, w in enumerate(vocab)}
@@ -149,9 +157,53 @@ def load_instances_prune(path, stoplist_file=None, prune_count=0, keep_numbers=T
     return LoadedDataset(corpus, names, np.asarray(labels, np.int32), label_alphabet)
 
 
+def tfidf_ranks(tf, df, corpus_size):
+    """TfIdfPipe.getTfIdf + freqSortWords (pipe/TfIdfPipe.java:73-104): weight = tf * ln(corpusSize / df) (0 when either
+    count is 0), types ordered by falling weight.  Arrays.sort on objects is a stable merge sort and MALLET 2.0.8's
+    IDSorter.compareTo answers 0 for equal weights (restated from the published source, not under /root/reference), so
+    equal weights keep their alphabet order -- which words survive at the cut among equals rests on that."""
+    import math
+    w = [0.0 if (t == 0 or d == 0) else float(t) * math.log(corpus_size / float(d)) for t, d in zip(tf, df)]
+    return sorted(range(len(w)), key=lambda i: -w[i]), w
+
+
+def load_instances_keep(path, stoplist_file=None, keep_count=0, keep_numbers=True, max_buf_size=10000, keep_connectors=False,
+                        data_alphabet=None):
+    """LDAUtils.loadInstancesKeep (LDAUtils.java:355-452): the vocabulary cut by TF-IDF.  With keep_count > 0 a first
+    pass over the file counts, per type, its occurrences (tf) and the documents it occurs in (df); every type ranked
+    keep_count or later by tf * ln(D / df) joins the stoplist (TfIdfPipe.addPrunedWordsToStoplist) and the file is read
+    again.  As in Java the first pass indexes a caller's alphabet when one is given (and grows it unless it is frozen:
+    a tuple), so a test set is cut among the training vocabulary's ids; without one each pass starts a fresh alphabet."""
+    stoplist = read_stoplist(stoplist_file)
+    if keep_count > 0:
+        frozen = isinstance(data_alphabet, tuple)
+        vocab = data_alphabet if isinstance(data_alphabet, list) else (list(data_alphabet) if data_alphabet is not None else [])
+        index = {w: i for i, w in enumerate(vocab)}
+        tf, df, docs = [0] * len(vocab), [0] * len(vocab), 0
+        for _, _, data in iter_instances(path):
+            seen = set()
+            for t in tokenize(data.lower(), stoplist, keep_numbers, keep_connectors, max_buf_size):
+                i = index.get(t)
+                if i is None:
+                    if frozen:
+                        continue
+                    i = index[t] = len(vocab)
+                    vocab.append(t); tf.append(0); df.append(0)
+                tf[i] += 1
+                if i not in seen:
+                    seen.add(i); df[i] += 1
+            docs += 1
+        ranks, _ = tfidf_ranks(tf, df, docs)
+        stoplist = stoplist | {vocab[i] for i in ranks[keep_count:]}
+    return _load_with_stoplist(path, stoplist, keep_numbers, max_buf_size, keep_connectors, data_alphabet)
+
+
 def load_dataset(path, stoplist="stoplist.txt", rare_threshold=0, keep_numbers=True, max_doc_buf_size=10000,
-                 keep_connecting_punctuation=False, alphabet=None):
-    """LDAUtils.loadDataset for a single file with tfidf_vocab_size <= 0 (LDAUtils.java:140-182; defaults of
-    LDAConfiguration.java: stoplist.txt, rare_threshold 0, max_doc_buf_size 10000).  Directories of documents and the
-    TF-IDF vocabulary cut (loadInstanceDirectory, loadInstancesKeep) are other front-ends and not provided."""
+                 keep_connecting_punctuation=False, alphabet=None, tfidf_vocab_size=-1):
+    """LDAUtils.loadDataset for a single file (LDAUtils.java:140-182; defaults of LDAConfiguration.java: stoplist.txt,
+    rare_threshold 0, max_doc_buf_size 10000, tfidf_vocab_size -1): the TF-IDF cut when tfidf_vocab_size > 0, the
+    rare-word cut otherwise.  A DIRECTORY of documents (loadInstanceDirectory: another tokenisation, and the files in
+    File.listFiles order, which Java leaves to the file system) is not provided."""
+    if tfidf_vocab_size > 0:
+        return load_instances_keep(path, stoplist, tfidf_vocab_size, keep_numbers, max_doc_buf_size, keep_connecting_punctuation, alphabet)
     return load_instances_prune(path, stoplist, rare_threshold, keep_numbers, max_doc_buf_size, keep_connecting_punctuation, alphabet)

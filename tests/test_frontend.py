@@ -35,6 +35,53 @@ def test_reference_known_answers():
     assert a.names == ["docno:%d" % i for i in range(1, 6)] and a.label_alphabet == ["X"]
 
 
+def test_tfidf_vocabulary_cut(tmp_path):
+    """LDAUtils.loadInstancesKeep.  Reference-held answers: SimpleTokenizerLargeTest.testSpecialChars runs it with
+    tfidf_vocab_size = 7700 (special_chars.cfg:15) and finds `but_i_can` only with keep_connecting_punctuation (:78-98);
+    testIntegrationTfIdfPrune expects the token-buffer ArrayIndexOutOfBoundsException out of the FIRST pass (:50-75).
+    The cut itself (which types survive) is checked against TfIdfPipe's formula recomputed here."""
+    sc = os.path.join(DATA, "special_chars.txt")
+    c = F.load_instances_keep(sc, None, 7700, True, 10000, False)
+    assert "but_i_can" not in c.corpus.vocab and "but" in c.corpus.vocab
+    c = F.load_instances_keep(sc, None, 7700, True, 10000, True)
+    assert "but_i_can" in c.corpus.vocab
+    with pytest.raises(F.TokenBufferOverflow):
+        F.load_instances_keep(os.path.join(DATA, "SmallTexts.txt"), None, 7700, True, 3)
+    # keep_count <= 0: no cut at all (the loader then equals loadInstancesPrune without a threshold)
+    cats_path = os.path.join(DATA, "cats.txt")
+    full = F.load_instances_prune(cats_path, None, 0, True)
+    same = F.load_instances_keep(cats_path, None, 0, True)
+    assert same.corpus.vocab == full.corpus.vocab and np.array_equal(same.corpus.tokens, full.corpus.tokens)
+    # the cut on cats: tf, df recomputed from the uncut encoding, weight = tf * ln(D / df), equal weights in alphabet order
+    V, D = full.corpus.num_types, full.corpus.num_docs
+    tf = np.bincount(full.corpus.tokens, minlength=V)
+    df = np.zeros(V, np.int64)
+    for d in range(D):
+        df[np.unique(full.corpus.tokens[full.corpus.doc_ptr[d]:full.corpus.doc_ptr[d + 1]])] += 1
+    w = tf * np.log(D / df)
+    for keep in (1, 17, 100, 302, 303, 5000):
+        kept_ids = sorted(np.argsort(-w, kind="stable")[:keep].tolist())
+        want_vocab_set = {full.corpus.vocab[i] for i in kept_ids}
+        k = F.load_instances_keep(cats_path, None, keep, True)
+        assert set(k.corpus.vocab) == want_vocab_set and k.corpus.num_types == min(keep, V)
+        # survivors keep their relative order of first appearance; the token stream is the uncut one minus the dropped types
+        keep_mask = np.isin(full.corpus.tokens, kept_ids)
+        assert [k.corpus.vocab[i] for i in k.corpus.tokens] == [full.corpus.vocab[i] for i in full.corpus.tokens[keep_mask]]
+        assert k.corpus.num_docs == D
+    # a type that occurs in every document weighs tf * ln(1) = 0 however frequent it is, and goes first when the cut bites;
+    # equal weights keep their alphabet order (x before y before z: one occurrence in one of three documents each)
+    small = tmp_path / "every.txt"
+    small.write_text("d1\tL\tthe the the x\nd2\tL\tthe y\nd3\tL\tthe z z\n", encoding="utf-8")
+    assert F.load_instances_keep(str(small), None, 3, True).corpus.vocab == ["x", "y", "z"]
+    assert F.load_instances_keep(str(small), None, 2, True).corpus.vocab == ["x", "z"]        # z: 2 ln 3; x, y: ln 3 each, x first
+    assert F.load_instances_keep(str(small), None, 1, True).corpus.vocab == ["z"]
+    # load_dataset dispatches on tfidf_vocab_size as LDAUtils.loadDataset does (LDAUtils.java:163-181)
+    assert F.load_dataset(cats_path, stoplist=None, tfidf_vocab_size=50).corpus.num_types == 50
+    # a test set against the training alphabet: cut among the training ids, unknown words dropped when the alphabet is frozen
+    t = F.load_instances_keep(os.path.join(DATA, "SmallTexts.txt"), None, 5, True, data_alphabet=tuple(full.corpus.vocab))
+    assert t.corpus.num_types == V and len(set(t.corpus.tokens.tolist())) <= 5
+
+
 def test_cats_is_the_golden_encoding(cats):
     d = F.load_dataset(os.path.join(DATA, "cats.txt"), stoplist=None)                    # plda-cats-test.cfg:21-24: empty stoplist, keep numbers
     assert (d.corpus.num_docs, d.corpus.num_types, d.corpus.num_tokens) == (23, 303, 7788)
@@ -89,6 +136,25 @@ def test_cpp_loader_equals_python_loader_on_the_bundled_datasets(corpus_demo, na
     path = os.path.join(DATA, name)
     stop = os.path.join(DATA, stop) if stop else None
     same(run_cpp(corpus_demo, path, stop, prune, numbers, 10000, connectors), F.load_instances_prune(path, stop, prune, numbers, 10000, connectors))
+
+
+@pytest.mark.parametrize("name,stop,keep,numbers,connectors", [
+    ("special_chars.txt", None, 7700, True, False), ("special_chars.txt", None, 7700, True, True), ("SmallTexts.txt", None, 6, True, False),
+    ("cats.txt", None, 100, True, False), ("cats.txt", "stoplist.txt", 40, False, True), ("small.txt", None, 25, True, False)])
+def test_cpp_tfidf_cut_equals_python(corpus_demo, name, stop, keep, numbers, connectors, tmp_path):
+    path = os.path.join(DATA, name)
+    stop = os.path.join(DATA, stop) if stop else None
+    same(run_cpp(corpus_demo, path, stop, "tfidf:%d" % keep, numbers, 10000, connectors), F.load_instances_keep(path, stop, keep, numbers, 10000, connectors))
+    if name == "cats.txt" and stop is None:             # a test set cut among the training alphabet's ids (grown, and frozen)
+        train = F.load_instances_prune(os.path.join(DATA, "SmallTexts.txt"), None, 0, True)
+        alpha = tmp_path / "alphabet.txt"
+        alpha.write_text("\n".join(train.corpus.vocab) + "\n", encoding="utf-8")
+        same(run_cpp(corpus_demo, path, None, "tfidf:%d" % keep, True, 10000, False, [str(alpha), "1"]),
+             F.load_instances_keep(path, None, keep, True, 10000, False, tuple(train.corpus.vocab)))
+        same(run_cpp(corpus_demo, path, None, "tfidf:%d" % keep, True, 10000, False, [str(alpha), "0"]),
+             F.load_instances_keep(path, None, keep, True, 10000, False, list(train.corpus.vocab)))
+    with pytest.raises(F.TokenBufferOverflow):          # testIntegrationTfIdfPrune: out of the first pass
+        run_cpp(corpus_demo, os.path.join(DATA, "SmallTexts.txt"), None, "tfidf:7700", True, 3, False)
 
 
 def test_cpp_loader_known_answers_and_overflow(corpus_demo):

@@ -271,8 +271,9 @@ inline Dataset load_instances_prune(const std::string &path, const LoadOptions &
 // LDAUtils.loadInstancesKeep (LDAUtils.java:355-452): the vocabulary cut by TF-IDF.  With opt.keep_count > 0 a first pass
 // counts, per type, its occurrences (tf) and the documents it occurs in (df) -- indexing the caller's alphabet when one
 // is given, as Java does --, every type ranked keep_count or later by tf * ln(D / df) (pipe/TfIdfPipe.java:73-104; 0 when
-// either count is 0) joins the stoplist and the file is read again.  Equal weights keep their alphabet order: a stable
-// sort under MALLET 2.0.8's IDSorter.compareTo, which answers 0 for equal weights (restated from the published source).
+// either count is 0) joins the stoplist and the file is read again.  Equal weights rank by FALLING id: MALLET's
+// IDSorter.compareTo (not under /root/reference) breaks ties that way, pinned by the reference's TfIdfPipeTest.testRank
+// (the three weight-0 types of tfidf-samples.txt, ids 0, 1, 2, rank 5, 4, 3; TfIdfPipeTest.java:124-145).
 // `grown`: receives the alphabet as the first pass left it (Java grows the caller's Alphabet object in place).
 inline Dataset load_instances_keep(const std::string &path, const LoadOptions &opt, const std::vector<std::string> *alphabet = nullptr, bool frozen = false,
                                    std::vector<std::string> *grown = nullptr) {
@@ -303,7 +304,7 @@ inline Dataset load_instances_keep(const std::string &path, const LoadOptions &o
     for (size_t i = 0; i < w.size(); ++i) w[i] = (tf[i] == 0 || df[i] == 0) ? 0.0 : (double)tf[i] * std::log((double)docs / (double)df[i]);
     std::vector<int32_t> ranks(vocab.size());
     for (size_t i = 0; i < ranks.size(); ++i) ranks[i] = (int32_t)i;
-    std::stable_sort(ranks.begin(), ranks.end(), [&](int32_t a, int32_t b) { return w[(size_t)a] > w[(size_t)b]; });
+    std::sort(ranks.begin(), ranks.end(), [&](int32_t a, int32_t b) { return w[(size_t)a] != w[(size_t)b] ? w[(size_t)a] > w[(size_t)b] : a > b; });
     for (size_t r = (size_t)opt.keep_count; r < ranks.size(); ++r) stoplist.insert(vocab[(size_t)ranks[r]]);
   }
   if (grown) *grown = vocab;

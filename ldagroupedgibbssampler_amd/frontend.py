@@ -159,12 +159,12 @@ def _load_with_stoplist(path, stoplist, keep_numbers, max_buf_size, keep_connect
 
 def tfidf_ranks(tf, df, corpus_size):
     """TfIdfPipe.getTfIdf + freqSortWords (pipe/TfIdfPipe.java:73-104): weight = tf * ln(corpusSize / df) (0 when either
-    count is 0), types ordered by falling weight.  Arrays.sort on objects is a stable merge sort and MALLET 2.0.8's
-    IDSorter.compareTo answers 0 for equal weights (restated from the published source, not under /root/reference), so
-    equal weights keep their alphabet order -- which words survive at the cut among equals rests on that."""
+    count is 0), types ordered by falling weight; EQUAL weights by falling id -- MALLET's IDSorter.compareTo (not under
+    /root/reference) breaks ties that way, which the reference's own TfIdfPipeTest.testRank pins: the three weight-0
+    types of tfidf-samples.txt, ids 0, 1, 2, rank 5, 4, 3 (TfIdfPipeTest.java:124-145)."""
     import math
     w = [0.0 if (t == 0 or d == 0) else float(t) * math.log(corpus_size / float(d)) for t, d in zip(tf, df)]
-    return sorted(range(len(w)), key=lambda i: -w[i]), w
+    return sorted(range(len(w)), key=lambda i: (-w[i], -i)), w
 
 
 def load_instances_keep(path, stoplist_file=None, keep_count=0, keep_numbers=True, max_buf_size=10000, keep_connectors=False,

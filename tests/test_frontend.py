@@ -7,6 +7,7 @@ Pinned by the REFERENCE'S OWN known answers, on the data files its tests read (c
   SimpleTokenizerLargeTest.testSpecialChars  special_chars.txt: "but_i_can" is a type only with keep_connecting_punctuation (:78-98)
   SimpleTokenizerLargeTest.testIntegrationRareWordPrune  a token longer than max_doc_buf_size -> ArrayIndexOutOfBoundsException (:118-136)
   the bundled cats corpus                  D=23, V=303, N=7788, ids in first-appearance order
+  TfIdfPipeTest (tfidf-samples.txt)        tf, df, ranks incl. the tie rule, cut sizes of loadInstancesKeep          (TfIdfPipeTest.java:41-243)
 The C++ loader must produce exactly what the Python one produces, on those files and on random Unicode text."""
 import os
 import subprocess
@@ -39,7 +40,20 @@ def test_tfidf_vocabulary_cut(tmp_path):
     """LDAUtils.loadInstancesKeep.  Reference-held answers: SimpleTokenizerLargeTest.testSpecialChars runs it with
     tfidf_vocab_size = 7700 (special_chars.cfg:15) and finds `but_i_can` only with keep_connecting_punctuation (:78-98);
     testIntegrationTfIdfPrune expects the token-buffer ArrayIndexOutOfBoundsException out of the FIRST pass (:50-75).
-    The cut itself (which types survive) is checked against TfIdfPipe's formula recomputed here."""
+    TfIdfPipeTest (tfidf-samples.txt) holds the counts, the ranking INCLUDING its tie rule, and the cut sizes.
+    The cut on a larger file (which types survive) is checked against TfIdfPipe's formula recomputed here."""
+    ts = os.path.join(DATA, "tfidf-samples.txt")
+    full = F.load_instances_prune(ts, None, 0, True)
+    assert full.corpus.vocab == ["this", "is", "a", "sample", "another", "example"]
+    tf = np.bincount(full.corpus.tokens, minlength=6).tolist()
+    df = [sum(1 for d in range(2) if i in full.corpus.tokens[full.corpus.doc_ptr[d]:full.corpus.doc_ptr[d + 1]]) for i in range(6)]
+    assert tf == [2, 2, 2, 1, 2, 3]                                                       # TfIdfPipeTest.testTf
+    assert df == [2, 2, 2, 1, 1, 1]                                                       # testIdf
+    assert F.tfidf_ranks(tf, df, 2)[0] == [5, 4, 3, 2, 1, 0]                              # testRank: weight-0 ties by falling id
+    assert F.load_instances_keep(ts, None, 3, True).corpus.num_types == 3                 # testLoadInstances
+    assert F.load_instances_keep(ts, None, 3, True).corpus.vocab == ["sample", "another", "example"]
+    assert F.load_instances_keep(ts, None, 2, True).corpus.num_types == 2                 # testCutoff: two types left unstopped
+    assert F.load_instances_keep(ts, None, -1, True).corpus.num_types == 6                # testLoadInstancesNegCnt
     sc = os.path.join(DATA, "special_chars.txt")
     c = F.load_instances_keep(sc, None, 7700, True, 10000, False)
     assert "but_i_can" not in c.corpus.vocab and "but" in c.corpus.vocab
@@ -52,7 +66,7 @@ def test_tfidf_vocabulary_cut(tmp_path):
     full = F.load_instances_prune(cats_path, None, 0, True)
     same = F.load_instances_keep(cats_path, None, 0, True)
     assert same.corpus.vocab == full.corpus.vocab and np.array_equal(same.corpus.tokens, full.corpus.tokens)
-    # the cut on cats: tf, df recomputed from the uncut encoding, weight = tf * ln(D / df), equal weights in alphabet order
+    # the cut on cats: tf, df recomputed from the uncut encoding, weight = tf * ln(D / df), equal weights by falling id
     V, D = full.corpus.num_types, full.corpus.num_docs
     tf = np.bincount(full.corpus.tokens, minlength=V)
     df = np.zeros(V, np.int64)
@@ -60,7 +74,7 @@ def test_tfidf_vocabulary_cut(tmp_path):
         df[np.unique(full.corpus.tokens[full.corpus.doc_ptr[d]:full.corpus.doc_ptr[d + 1]])] += 1
     w = tf * np.log(D / df)
     for keep in (1, 17, 100, 302, 303, 5000):
-        kept_ids = sorted(np.argsort(-w, kind="stable")[:keep].tolist())
+        kept_ids = sorted(sorted(range(V), key=lambda i: (-w[i], -i))[:keep])
         want_vocab_set = {full.corpus.vocab[i] for i in kept_ids}
         k = F.load_instances_keep(cats_path, None, keep, True)
         assert set(k.corpus.vocab) == want_vocab_set and k.corpus.num_types == min(keep, V)
@@ -69,11 +83,11 @@ def test_tfidf_vocabulary_cut(tmp_path):
         assert [k.corpus.vocab[i] for i in k.corpus.tokens] == [full.corpus.vocab[i] for i in full.corpus.tokens[keep_mask]]
         assert k.corpus.num_docs == D
     # a type that occurs in every document weighs tf * ln(1) = 0 however frequent it is, and goes first when the cut bites;
-    # equal weights keep their alphabet order (x before y before z: one occurrence in one of three documents each)
+    # equal weights rank by falling id (y before x: one occurrence in one of three documents each)
     small = tmp_path / "every.txt"
     small.write_text("d1\tL\tthe the the x\nd2\tL\tthe y\nd3\tL\tthe z z\n", encoding="utf-8")
     assert F.load_instances_keep(str(small), None, 3, True).corpus.vocab == ["x", "y", "z"]
-    assert F.load_instances_keep(str(small), None, 2, True).corpus.vocab == ["x", "z"]        # z: 2 ln 3; x, y: ln 3 each, x first
+    assert F.load_instances_keep(str(small), None, 2, True).corpus.vocab == ["y", "z"]        # z: 2 ln 3; x, y: ln 3 each, y (the later id) first
     assert F.load_instances_keep(str(small), None, 1, True).corpus.vocab == ["z"]
     # load_dataset dispatches on tfidf_vocab_size as LDAUtils.loadDataset does (LDAUtils.java:163-181)
     assert F.load_dataset(cats_path, stoplist=None, tfidf_vocab_size=50).corpus.num_types == 50
@@ -140,6 +154,7 @@ def test_cpp_loader_equals_python_loader_on_the_bundled_datasets(corpus_demo, na
 
 @pytest.mark.parametrize("name,stop,keep,numbers,connectors", [
     ("special_chars.txt", None, 7700, True, False), ("special_chars.txt", None, 7700, True, True), ("SmallTexts.txt", None, 6, True, False),
+    ("tfidf-samples.txt", None, 3, True, False), ("tfidf-samples.txt", None, 2, True, False), ("tfidf-samples.txt", None, 4, True, False),
     ("cats.txt", None, 100, True, False), ("cats.txt", "stoplist.txt", 40, False, True), ("small.txt", None, 25, True, False)])
 def test_cpp_tfidf_cut_equals_python(corpus_demo, name, stop, keep, numbers, connectors, tmp_path):
     path = os.path.join(DATA, name)

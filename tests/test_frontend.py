@@ -54,6 +54,10 @@ def test_tfidf_vocabulary_cut(tmp_path):
     assert F.load_instances_keep(ts, None, 3, True).corpus.vocab == ["sample", "another", "example"]
     assert F.load_instances_keep(ts, None, 2, True).corpus.num_types == 2                 # testCutoff: two types left unstopped
     assert F.load_instances_keep(ts, None, -1, True).corpus.num_types == 6                # testLoadInstancesNegCnt
+    st = F.load_instances_keep(os.path.join(DATA, "SmallTexts.txt"), None, 20, True)
+    assert st.corpus.num_types == 20                                                      # LDAUtilsTest.testLoadInstancesKeep (:303-307)
+    again = F.load_instances_keep(os.path.join(DATA, "SmallTexts.txt"), None, 20, True, 1000, True, tuple(st.corpus.vocab))
+    assert again.corpus.vocab == st.corpus.vocab and again.corpus.num_docs == 5           # the pattern of testLoadTestInstancesKeep (:309-320): frozen training alphabet
     sc = os.path.join(DATA, "special_chars.txt")
     c = F.load_instances_keep(sc, None, 7700, True, 10000, False)
     assert "but_i_can" not in c.corpus.vocab and "but" in c.corpus.vocab

@@ -37,6 +37,13 @@ int main(int argc, char **argv) {
     F::append_log_likelihood(dir, 3, -123456.789);
     F::append_heldout_log_likelihood(dir, 3, -1.0e-5);
     F::append_log_posterior(dir, 3, -98765.4321987, 1700000000000LL);
+    const double big[9] = {1.0, 2.0, 3.0, 4.0, 5.0, 6.0, 7.0, 8.0, 9.0};                      // the matrices of LDAUtilsTest.java:37-216
+    const int32_t ibig[9] = {1, 2, 3, 4, 5, 6, 7, 8, 9};
+    F::write_binary_double_matrix_rows(big, 3, 1, 3, 3, dir + "/drows", {0, 2});
+    F::write_binary_int_matrix_rows(ibig, 3, 1, 3, 3, dir + "/irows", {0, 2});
+    F::write_binary_double_matrix_cols(big, 3, 1, 3, 3, dir + "/dcols", {0, 2});
+    F::write_binary_int_matrix_cols(ibig, 3, 1, 3, 3, dir + "/icols", {2, 1});
+    F::write_binary_double_matrix_indices(big, 3, 1, dir + "/dsel", {{0, 2}, {1, 2}, {0, 1}});
     const auto back = F::read_binary_int_matrix(2, 3, dir + "/" + F::binary_matrix_name("N", 2, 3, 12));
     const auto dback = F::read_binary_double_matrix(3, 2, dir + "/" + F::binary_matrix_name("phi", 3, 2, 12));
     return (std::memcmp(back.data(), im, sizeof im) == 0 && std::memcmp(dback.data(), dm, sizeof dm) == 0) ? 0 : 3;

@@ -57,6 +57,57 @@ inline void write_binary_int_matrix(const int32_t *m, int64_t rows, int64_t cols
   out.append((size_t)rows * cols * 4, '\0');          // the file is mapped at the double writer's size: the second half stays zero
   write_file(fn, out);
 }
+// The subset writers (LDAUtils.java:1037-1122): the selection at the head of a file named and MAPPED (8*rows*cols bytes,
+// the double writer's size, for the int variants too) for the whole matrix; the tail stays zero.  m is row-major [..][ld].
+inline void pad_to(std::string &out, int64_t bytes) { if ((int64_t)out.size() < bytes) out.append((size_t)(bytes - (int64_t)out.size()), '\0'); }
+inline void put_double_be(std::string &out, double v) { uint64_t bits; std::memcpy(&bits, &v, 8); put_be(out, bits, 8); }
+inline std::string write_binary_double_matrix_rows(const double *m, int64_t ld, int iteration, int64_t rows, int64_t cols, const std::string &prefix,
+                                                   const std::vector<int32_t> &row_indices) {                    // LDAUtils.java:1037-1051
+  std::string out;
+  for (int32_t r : row_indices) for (int64_t c = 0; c < cols; ++c) put_double_be(out, m[(int64_t)r * ld + c]);
+  pad_to(out, 8 * rows * cols);
+  const std::string fn = binary_matrix_name(prefix, rows, cols, iteration);
+  write_file(fn, out);
+  return fn;
+}
+inline std::string write_binary_int_matrix_rows(const int32_t *m, int64_t ld, int iteration, int64_t rows, int64_t cols, const std::string &prefix,
+                                                const std::vector<int32_t> &row_indices) {                       // LDAUtils.java:1053-1067
+  std::string out;
+  for (int32_t r : row_indices) for (int64_t c = 0; c < cols; ++c) put_be(out, (uint32_t)m[(int64_t)r * ld + c], 4);
+  pad_to(out, 8 * rows * cols);
+  const std::string fn = binary_matrix_name(prefix, rows, cols, iteration);
+  write_file(fn, out);
+  return fn;
+}
+inline std::string write_binary_double_matrix_cols(const double *m, int64_t ld, int iteration, int64_t rows, int64_t cols, const std::string &prefix,
+                                                   const std::vector<int32_t> &col_indices) {                    // LDAUtils.java:1069-1083
+  std::string out;
+  for (int64_t r = 0; r < rows; ++r) for (int32_t c : col_indices) put_double_be(out, m[r * ld + c]);
+  pad_to(out, 8 * rows * cols);
+  const std::string fn = binary_matrix_name(prefix, rows, cols, iteration);
+  write_file(fn, out);
+  return fn;
+}
+inline std::string write_binary_int_matrix_cols(const int32_t *m, int64_t ld, int iteration, int64_t rows, int64_t cols, const std::string &prefix,
+                                                const std::vector<int32_t> &col_indices) {                       // LDAUtils.java:1108-1122
+  std::string out;
+  for (int64_t r = 0; r < rows; ++r) for (int32_t c : col_indices) put_be(out, (uint32_t)m[r * ld + c], 4);
+  pad_to(out, 8 * rows * cols);
+  const std::string fn = binary_matrix_name(prefix, rows, cols, iteration);
+  write_file(fn, out);
+  return fn;
+}
+// row r contributes m[r][indices[r][j]] for every j: the driver's Selected_Phi_KxV of each topic's top words (UPLDA:888)
+inline std::string write_binary_double_matrix_indices(const double *m, int64_t ld, int iteration, const std::string &prefix,
+                                                      const std::vector<std::vector<int32_t>> &indices) {        // LDAUtils.java:1085-1106
+  const int64_t rows = (int64_t)indices.size(), cols = rows ? (int64_t)indices[0].size() : 0;
+  std::string out;
+  for (int64_t r = 0; r < rows; ++r) for (int32_t c : indices[(size_t)r]) put_double_be(out, m[r * ld + c]);
+  pad_to(out, 8 * rows * cols);
+  const std::string fn = binary_matrix_name(prefix, rows, cols, iteration);
+  write_file(fn, out);
+  return fn;
+}
 inline std::vector<int32_t> read_binary_int_matrix(int64_t rows, int64_t cols, const std::string &fn) {        // LDAUtils.java:1255-1267
   std::ifstream f(fn, std::ios::binary);
   std::vector<int32_t> m((size_t)rows * cols);

@@ -44,6 +44,60 @@ def write_binary_int_matrix(matrix, fn):
         f.write(b"\0" * (4 * m.size))
 
 
+def _write_mapped(fn, payload, mapped_bytes):
+    """RandomAccessFile + FileChannel.map(READ_WRITE, 0, bufferSize): the file is bufferSize bytes long whatever is put."""
+    with open(fn, "wb") as f:
+        f.write(payload)
+        if mapped_bytes > len(payload):
+            f.write(b"\0" * (mapped_bytes - len(payload)))
+
+
+def write_binary_double_matrix_rows(matrix, iteration, rows, cols, prefix, row_indices):
+    """LDAUtils.writeBinaryDoubleMatrixRows (LDAUtils.java:1037-1051): the listed rows, in the listed order, at the head of
+    a file named and MAPPED for the whole rows x cols matrix (the tail stays zero).  Returns the file name."""
+    m = np.asarray(matrix, np.float64)
+    fn = binary_matrix_name(prefix, rows, cols, iteration)
+    _write_mapped(fn, np.ascontiguousarray(m[np.asarray(row_indices, np.int64), :cols]).astype(">f8").tobytes(), 8 * rows * cols)
+    return fn
+
+
+def write_binary_int_matrix_rows(matrix, iteration, rows, cols, prefix, row_indices):
+    """LDAUtils.writeBinaryIntMatrixRows (LDAUtils.java:1053-1067); mapped at 8*rows*cols bytes like every writer here."""
+    m = np.asarray(matrix, np.int32)
+    fn = binary_matrix_name(prefix, rows, cols, iteration)
+    _write_mapped(fn, np.ascontiguousarray(m[np.asarray(row_indices, np.int64), :cols]).astype(">i4").tobytes(), 8 * rows * cols)
+    return fn
+
+
+def write_binary_double_matrix_cols(matrix, iteration, rows, cols, prefix, col_indices):
+    """LDAUtils.writeBinaryDoubleMatrixCols (LDAUtils.java:1069-1083): every row, the listed columns in the listed order."""
+    m = np.asarray(matrix, np.float64)
+    fn = binary_matrix_name(prefix, rows, cols, iteration)
+    _write_mapped(fn, np.ascontiguousarray(m[:rows][:, np.asarray(col_indices, np.int64)]).astype(">f8").tobytes(), 8 * rows * cols)
+    return fn
+
+
+def write_binary_int_matrix_cols(matrix, iteration, rows, cols, prefix, col_indices):
+    """LDAUtils.writeBinaryIntMatrixCols (LDAUtils.java:1108-1122)."""
+    m = np.asarray(matrix, np.int32)
+    fn = binary_matrix_name(prefix, rows, cols, iteration)
+    _write_mapped(fn, np.ascontiguousarray(m[:rows][:, np.asarray(col_indices, np.int64)]).astype(">i4").tobytes(), 8 * rows * cols)
+    return fn
+
+
+def write_binary_double_matrix_indices(matrix, iteration, prefix, indices, rows=None, cols=None):
+    """LDAUtils.writeBinaryDoubleMatrixIndices (LDAUtils.java:1085-1106): row r contributes matrix[r][indices[r][j]] for
+    every j -- the driver's Selected_Phi_KxV file of each topic's top words (UPLDA:888).  The name carries
+    indices.length x indices[0].length unless the caller gives the dimensions; returns the file name."""
+    m = np.asarray(matrix, np.float64)
+    rows = len(indices) if rows is None else rows
+    cols = len(indices[0]) if cols is None else cols
+    fn = binary_matrix_name(prefix, rows, cols, iteration)
+    payload = b"".join(np.ascontiguousarray(m[r, np.asarray(idx, np.int64)]).astype(">f8").tobytes() for r, idx in enumerate(indices))
+    _write_mapped(fn, payload, 8 * rows * cols)
+    return fn
+
+
 def read_binary_int_matrix(rows, cols, fn):
     """LDAUtils.java:1255-1267 (DataInputStream.readInt: big-endian; trailing bytes ignored)."""
     return np.fromfile(fn, dtype=">i4", count=rows * cols).astype(np.int32).reshape(rows, cols)

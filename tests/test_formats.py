@@ -36,6 +36,29 @@ def test_binary_int_matrix_keeps_the_reference_file_size(tmp_path):
     assert np.array_equal(F.read_binary_int_matrix(2, 3, fn), m)          # readInt x rows*cols, the rest ignored
 
 
+def test_subset_writers_follow_the_reference_tests(tmp_path):
+    """LDAUtilsTest.testWriteDoubleMatrixRows / IntMatrixRows / DobuleMatrixIndices(Explicit) / DobuleMatrixCols / IntMatrixCols
+    (LDAUtilsTest.java:37-216): a 3x3 matrix 1..9, a selection written, the file read back value by value from its head; the
+    file itself is named and sized for the whole matrix (8*rows*cols bytes: FileChannel.map), zeros behind the selection."""
+    m = np.arange(1.0, 10.0).reshape(3, 3)
+    im = np.arange(1, 10, dtype=np.int32).reshape(3, 3)
+    fn = F.write_binary_double_matrix_rows(m, 1, 3, 3, str(tmp_path / "a"), [0, 2])
+    assert fn.endswith("a_3_3_00001.BINARY") and os.path.getsize(fn) == 72
+    assert np.fromfile(fn, ">f8").tolist() == [1, 2, 3, 7, 8, 9, 0, 0, 0]
+    fn = F.write_binary_int_matrix_rows(im, 1, 3, 3, str(tmp_path / "b"), [0, 2])
+    assert os.path.getsize(fn) == 72 and np.fromfile(fn, ">i4").tolist() == [1, 2, 3, 7, 8, 9] + [0] * 12
+    fn = F.write_binary_double_matrix_cols(m, 1, 3, 3, str(tmp_path / "c"), [0, 2])
+    assert np.fromfile(fn, ">f8").tolist() == [1, 3, 4, 6, 7, 9, 0, 0, 0]
+    fn = F.write_binary_int_matrix_cols(im, 1, 3, 3, str(tmp_path / "d"), [0, 2])
+    assert np.fromfile(fn, ">i4").tolist() == [1, 3, 4, 6, 7, 9] + [0] * 12
+    idx = [[1, 2], [0, 1], [0, 2]]                                     # testWriteDobuleMatrixIndices: per-row column lists
+    fn = F.write_binary_double_matrix_indices(m, 1, str(tmp_path / "e"), idx)
+    assert fn.endswith("e_3_2_00001.BINARY") and os.path.getsize(fn) == 3 * 2 * 8          # assertEquals(indices.length*indices[0].length*8, ttmp.length())
+    assert np.fromfile(fn, ">f8").tolist() == [2, 3, 4, 5, 7, 9]
+    fn = F.write_binary_double_matrix_indices(m, 1, str(tmp_path / "f"), idx, rows=3, cols=2)      # ...Explicit: the caller passes the same dimensions
+    assert fn.endswith("f_3_2_00001.BINARY") and os.path.getsize(fn) == 48 and np.fromfile(fn, ">f8").tolist() == [2, 3, 4, 5, 7, 9]
+
+
 def test_topic_indicator_and_int_csv(tmp_path):
     doc_ptr = np.array([0, 3, 3, 5], np.int64)
     z = np.array([4, 0, 11, 2, 2], np.int32)
@@ -144,7 +167,13 @@ def test_cpp_files_equal_the_python_files(formats_demo, tmp_path):
     F.append_log_likelihood(str(pdir), 3, -123456.789)
     F.append_heldout_log_likelihood(str(pdir), 3, -1.0e-5)
     F.append_log_posterior(str(pdir), 3, -98765.4321987, 1700000000000)
+    big, ibig = np.arange(1.0, 10.0).reshape(3, 3), np.arange(1, 10, dtype=np.int32).reshape(3, 3)
+    F.write_binary_double_matrix_rows(big, 1, 3, 3, str(pdir / "drows"), [0, 2])
+    F.write_binary_int_matrix_rows(ibig, 1, 3, 3, str(pdir / "irows"), [0, 2])
+    F.write_binary_double_matrix_cols(big, 1, 3, 3, str(pdir / "dcols"), [0, 2])
+    F.write_binary_int_matrix_cols(ibig, 1, 3, 3, str(pdir / "icols"), [2, 1])
+    F.write_binary_double_matrix_indices(big, 1, str(pdir / "dsel"), [[0, 2], [1, 2], [0, 1]])
     names = sorted(os.listdir(pdir))
-    assert names == sorted(os.listdir(cdir)) and len(names) == 8
+    assert names == sorted(os.listdir(cdir)) and len(names) == 13
     for n in names:
         assert (cdir / n).read_bytes() == (pdir / n).read_bytes(), n

@@ -210,3 +210,55 @@ def test_parallel_schedule_two_pass_kernel_below_193_topics(native, oracle, monk
     g.sweep(3)
     o.collapsed_parallel_sweep(3)
     same_counts(g, o, "collapsed two-pass K=50")
+
+
+def test_collapsed_and_uncollapsed_agree_on_state_and_likelihood(native, cats):
+    """The reference's LogLikelihoodTest.testLogLikelihood (LogLikelihoodTest.java:29-131), on the bundled cats corpus in
+    place of the missing nips.txt: a collapsed and an uncollapsed sampler given the same seed start from the same topic
+    indicators and counts and report the same model log likelihood; topic indicators carried over from one to the other
+    (getZIndicators -> setZIndicators) reproduce the counts and the likelihood, in both directions, after each has sampled."""
+    K, alpha, beta, seed = 20, 1.0 / 20, 0.01, 4711
+    col = native.GGSHandle(K, cats.num_types, alpha, beta, seed, flags=native.FLAG_COLLAPSED | native.FLAG_PARANOID)
+    unc = native.GGSHandle(K, cats.num_types, alpha, beta, seed, flags=native.FLAG_PARANOID)
+    for s in (col, unc):
+        s.set_corpus(cats.doc_ptr, cats.tokens)
+        s.init_z_java_lcg(seed)
+        s.init_phi()
+
+    def same_state(tag):
+        assert_bit_equal(col.get_z(), unc.get_z(), tag + " z")
+        assert_bit_equal(col.get_type_topic_counts(), unc.get_type_topic_counts(), tag + " type-topic counts")
+        assert_bit_equal(col.get_topic_totals(), unc.get_topic_totals(), tag + " topic totals")
+        a, b = col.model_log_likelihood(), unc.model_log_likelihood()
+        assert a == b, (tag, a, b)                         # the Java test's epsilon is 1e-33: equality
+
+    same_state("start")
+    col.collapsed_serial_sweep(seed, 50)                   # "sample 50 iterations ... to something other than the start state"
+    unc.set_z(col.get_z(), redraw_phi=True)
+    same_state("collapsed -> uncollapsed")
+    unc.sweep(5)                                           # "sample 5 iterations to change z"
+    col.set_z(unc.get_z(), redraw_phi=True)
+    same_state("uncollapsed -> collapsed")
+
+
+def test_uncollapsed_heldout_within_ten_percent_of_adlda(native):
+    """The reference's MarginalProbEstimatorPlainTest (MarginalProbEstimatorPlainTest.java:36-94): after 100 iterations the
+    left-to-right held-out estimate (100 particles) from the uncollapsed sampler's counts lies within 10 % of the one
+    from ADLDA's.  Here: scheme=ggs against the parallel collapsed schedule (the AD-LDA decomposition), K = 20,
+    alphaSum = 1, beta = 0.01 as in the Java test, on a slice of the benchmark corpus in place of the missing nips.txt."""
+    full = synthetic_lda_corpus(660, 5000, 120, true_topics=20, seed=4711)
+    train, _, _ = full.shard(0, 600)
+    test, _, _ = full.shard(600, 660)
+    K, alpha, beta = 20, 1.0 / 20, 0.01
+    out = {}
+    for name, flags in (("uncollapsed", 0), ("adlda", native.FLAG_COLLAPSED)):
+        g = native.GGSHandle(K, train.num_types, alpha, beta, 4711, flags=flags)
+        g.set_corpus(train.doc_ptr, train.tokens)
+        g.init_z_java_lcg(4711)
+        g.init_phi()
+        g.sweep(100)
+        g.set_test_corpus(test.doc_ptr, test.tokens)
+        out[name] = g.heldout_log_likelihood(100)[0]
+        g.close()
+    a, b = out["uncollapsed"], out["adlda"]
+    assert a < 0 and b < 0 and abs(a - b) <= 0.1 * abs(b), out

@@ -233,6 +233,14 @@ def test_collapsed_and_uncollapsed_agree_on_state_and_likelihood(native, cats):
         assert a == b, (tag, a, b)                         # the Java test's epsilon is 1e-33: equality
 
     same_state("start")
+    pc = native.GGSHandle(K, cats.num_types, alpha, beta, seed, flags=native.FLAG_PCGS)      # TestInitialization.testEqualInitialization
+    pc.set_corpus(cats.doc_ptr, cats.tokens)                                                # (TestInitialization.java:10-200): every scheme
+    pc.init_z_java_lcg(seed)                                                                # starts from the same indicators, counts, likelihood
+    pc.init_phi()
+    assert_bit_equal(pc.get_z(), col.get_z(), "pcgs start z")
+    assert_bit_equal(pc.get_type_topic_counts(), col.get_type_topic_counts(), "pcgs start counts")
+    assert pc.model_log_likelihood() == col.model_log_likelihood()
+    pc.close()
     col.collapsed_serial_sweep(seed, 50)                   # "sample 50 iterations ... to something other than the start state"
     unc.set_z(col.get_z(), redraw_phi=True)
     same_state("collapsed -> uncollapsed")

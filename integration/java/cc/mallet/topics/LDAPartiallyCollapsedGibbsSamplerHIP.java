@@ -1,36 +1,25 @@
 /*
- * LDAGroupedGibbsSamplerHIP -- scheme=ggs with the sweep on MI355X: the reference-side binding of libggs_hip.so.
+ * LDAPartiallyCollapsedGibbsSamplerHIP -- scheme=pcgs with the sweep on MI355X (createModel case "pcgs",
+ * tui/ParallelLDA.java:414-416).  The same binding as LDAGroupedGibbsSamplerHIP over the other reference class: the
+ * handle is created with GGS_FLAG_PCGS, so loopOverBatches runs the z loop of UPLDA:1466-1544 (theta integrated out,
+ * score (n_dk + alpha_k) * phi[k][w], sequential inside a document) instead of GGS:47-132; counts, the Phi draw
+ * (LDAPartiallyCollapsedGibbsSampler.java:48-118: beta-smoothed counts, the ggs draw) and the multi-GPU exchange are the
+ * same.  The scheme keeps its name, so UncollapsedParallelLDA.sample takes its non-"ggs" branch (UPLDA:710-714): the
+ * diagnostic theta is a fresh draw from the document-topic counts, which ggs_log_posterior reproduces on the device
+ * from the Philox stream GGS_PURPOSE_THETA.
  *
- * SOURCE ONLY: the build image has no JDK / Maven / MALLET jar, so this file has never been compiled; what a compiler
- * would check first -- every native declaration against its JNIEXPORT, every overridden / called reference member
- * against the reference's own declarations -- tests/test_jni_binding.py checks from the sources.
- *
- * Where it plugs in, against the reference at the surveyed revision:
- *   - it extends LDAGroupedGibbsSampler and keeps scheme "ggs" (UncollapsedParallelLDA.sample branches on the scheme
- *     string, UPLDA:143,710-721); tui/ParallelLDA.createModel picks it when the optional cfg key gpu_devices is set
- *     (INTEGRATION.md section 1 shows the three-line edit of ParallelLDA.java:404-408);
- *   - it overrides the three protected hooks of the iteration, UPLDA:660-687:
- *       loopOverBatches()  -> GGSDevice.zStep    (ggs_sweep_begin: theta draw, z draw, the device's counts;
- *                                                 several GPUs: the whole ggs_group_sweep)
- *       updateCounts()     -> nothing left to do (the counts were rebuilt on the device)
- *       samplePhi()        -> GGSDevice.phiStep  (ggs_sweep_end: Phi re-draw, phi-mean accumulation)
- *   - Java-side arrays that diagnostics read as FIELDS (typeTopicCounts, topicTypeCountMapping, tokensPerTopic, phi,
- *     thetaMatrix, each document's topicSequence; UPLDA:1573-1758) are refreshed lazily by GGSDevice.syncToJava(),
- *     called from postPhi() only when a diagnostic of this iteration needs them, and always from postSample();
- *   - getPhiMeans() reads the device's running mean (Java's phiMean[][] stays empty) and setPhi() uploads the matrix,
- *     so the two LDASamplerWithPhi methods act on the state that is sampled from.
- * All native methods live in GGSNative; all device state in GGSDevice (shared with the pcgs subclass).
+ * SOURCE ONLY, like the other files of this directory; checked by tests/test_jni_binding.py.
  */
 package cc.mallet.topics;
 
 import cc.mallet.configuration.LDAConfiguration;
 import cc.mallet.types.InstanceList;
 
-public class LDAGroupedGibbsSamplerHIP extends LDAGroupedGibbsSampler {
+public class LDAPartiallyCollapsedGibbsSamplerHIP extends LDAPartiallyCollapsedGibbsSampler {
 	private static final long serialVersionUID = 1L;
-	private final GGSDevice device = new GGSDevice(this, 0);
+	private final GGSDevice device = new GGSDevice(this, GGSNative.FLAG_PCGS);
 
-	public LDAGroupedGibbsSamplerHIP(LDAConfiguration config) { super(config); }
+	public LDAPartiallyCollapsedGibbsSamplerHIP(LDAConfiguration config) { super(config); }
 
 	@Override
 	public void addInstances(InstanceList training) {
@@ -61,7 +50,7 @@ public class LDAGroupedGibbsSamplerHIP extends LDAGroupedGibbsSampler {
 	protected void updateCounts() { /* rebuilt on the device inside zStep (several GPUs: the reduce-scatter of the count slices) */ }
 
 	@Override
-	protected void samplePhi() {                        // GGS:139-171
+	protected void samplePhi() {                        // LDAPartiallyCollapsedGibbsSampler.java:48-83
 		device.phiStep();
 		if (savePhiMeans() && samplePhiThisIteration()) noSampledPhi++;
 	}

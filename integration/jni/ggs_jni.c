@@ -1,6 +1,9 @@
 /*
- * ggs_jni.c -- JNI glue between cc.mallet.topics.LDAGroupedGibbsSamplerHIP and the C-ABI of
- * include/ggs_hip.h.  SOURCE ONLY (no jni.h in the build image).  Build on a box with a JDK:
+ * ggs_jni.c -- JNI glue between cc.mallet.topics.GGSNative (the one class that declares native methods;
+ * integration/java/cc/mallet/topics/GGSNative.java) and the C-ABI of include/ggs_hip.h.  JNI resolves a native method
+ * by its DECLARING class, so every export is Java_cc_mallet_topics_GGSNative_<method>, whichever sampler subclass
+ * calls it.  tests/test_jni_binding.py checks declarations against exports (names, JNI types, arity), both ways.
+ * SOURCE ONLY (no jni.h in the build image).  Build on a box with a JDK:
  *
  *   gcc -shared -fPIC -I$JAVA_HOME/include -I$JAVA_HOME/include/linux -Iinclude \
  *       integration/jni/ggs_jni.c -Lldagroupedgibbssampler_amd/csrc -lggs_hip -o libggs_jni.so
@@ -22,7 +25,7 @@ static void throw_for(JNIEnv *env, ggs_handle *h, int rc) {
 }
 #define CHECK(h, call) do { int rc_ = (call); if (rc_) throw_for(env, (h), rc_); } while (0)
 
-JNIEXPORT jlong JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nCreate(JNIEnv *env, jclass c, jint K, jint V,
+JNIEXPORT jlong JNICALL Java_cc_mallet_topics_GGSNative_nCreate(JNIEnv *env, jclass c, jint K, jint V,
     jdoubleArray alpha, jdouble beta, jlong seed, jint device, jint flags, jint burnIn, jint thin) {
   ggs_config cfg = {0};
   ggs_handle *h = 0;
@@ -34,9 +37,9 @@ JNIEXPORT jlong JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nCreate(
   if (rc) throw_for(env, 0, rc);
   return (jlong)(intptr_t)h;
 }
-JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nDestroy(JNIEnv *env, jclass c, jlong h) { ggs_destroy(H(h)); }
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nDestroy(JNIEnv *env, jclass c, jlong h) { ggs_destroy(H(h)); }
 
-JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSetCorpus(JNIEnv *env, jclass c, jlong h,
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nSetCorpus(JNIEnv *env, jclass c, jlong h,
     jlongArray docPtr, jintArray tokens, jlong docBase, jlong tokBase) {
   jsize D = (*env)->GetArrayLength(env, docPtr) - 1;
   jlong *p = (*env)->GetLongArrayElements(env, docPtr, 0);
@@ -46,57 +49,69 @@ JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSetCorpu
   (*env)->ReleaseLongArrayElements(env, docPtr, p, JNI_ABORT);
   if (rc) throw_for(env, H(h), rc);
 }
-JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSetZ(JNIEnv *env, jclass c, jlong h, jintArray z, jboolean redraw) {
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nSetZ(JNIEnv *env, jclass c, jlong h, jintArray z, jboolean redraw) {
   jint *p = (*env)->GetIntArrayElements(env, z, 0);
   int rc = ggs_set_z(H(h), (const int32_t *)p, redraw ? 1 : 0);
   (*env)->ReleaseIntArrayElements(env, z, p, JNI_ABORT);
   if (rc) throw_for(env, H(h), rc);
 }
-JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSetIteration(JNIEnv *env, jclass c, jlong h, jint it) { CHECK(H(h), ggs_set_iteration(H(h), it)); }
-JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSweepBegin(JNIEnv *env, jclass c, jlong h) { CHECK(H(h), ggs_sweep_begin(H(h))); }
-JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSweepEnd(JNIEnv *env, jclass c, jlong h) { CHECK(H(h), ggs_sweep_end(H(h))); }
-JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSampleZGivenPhi(JNIEnv *env, jclass c, jlong h, jint n) { CHECK(H(h), ggs_sample_z_given_phi(H(h), n)); }
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nSetIteration(JNIEnv *env, jclass c, jlong h, jint it) { CHECK(H(h), ggs_set_iteration(H(h), it)); }
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nSweepBegin(JNIEnv *env, jclass c, jlong h) { CHECK(H(h), ggs_sweep_begin(H(h))); }
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nSweepEnd(JNIEnv *env, jclass c, jlong h) { CHECK(H(h), ggs_sweep_end(H(h))); }
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nSampleZGivenPhi(JNIEnv *env, jclass c, jlong h, jint n) { CHECK(H(h), ggs_sample_z_given_phi(H(h), n)); }
 
-#define GETTER_INT(NAME, CALL) \
-JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_##NAME(JNIEnv *env, jclass c, jlong h, jintArray out) { \
-  jint *p = (*env)->GetIntArrayElements(env, out, 0); int rc = CALL(H(h), (int32_t *)p); \
-  (*env)->ReleaseIntArrayElements(env, out, p, 0); if (rc) throw_for(env, H(h), rc); }
-GETTER_INT(nGetZ, ggs_get_z)
-GETTER_INT(nGetTypeTopicCounts, ggs_get_type_topic_counts)
-GETTER_INT(nGetTopicTotals, ggs_get_topic_totals)
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nGetZ(JNIEnv *env, jclass c, jlong h, jintArray out) {
+  jint *p = (*env)->GetIntArrayElements(env, out, 0); int rc = ggs_get_z(H(h), (int32_t *)p);
+  (*env)->ReleaseIntArrayElements(env, out, p, 0); if (rc) throw_for(env, H(h), rc);
+}
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nGetTypeTopicCounts(JNIEnv *env, jclass c, jlong h, jintArray out) {
+  jint *p = (*env)->GetIntArrayElements(env, out, 0); int rc = ggs_get_type_topic_counts(H(h), (int32_t *)p);
+  (*env)->ReleaseIntArrayElements(env, out, p, 0); if (rc) throw_for(env, H(h), rc);
+}
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nGetTopicTotals(JNIEnv *env, jclass c, jlong h, jintArray out) {
+  jint *p = (*env)->GetIntArrayElements(env, out, 0); int rc = ggs_get_topic_totals(H(h), (int32_t *)p);
+  (*env)->ReleaseIntArrayElements(env, out, p, 0); if (rc) throw_for(env, H(h), rc);
+}
 
-JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nGetPhi(JNIEnv *env, jclass c, jlong h, jdoubleArray out) {
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nGetPhi(JNIEnv *env, jclass c, jlong h, jdoubleArray out) {
   jdouble *p = (*env)->GetDoubleArrayElements(env, out, 0); int rc = ggs_get_phi(H(h), p);
   (*env)->ReleaseDoubleArrayElements(env, out, p, 0); if (rc) throw_for(env, H(h), rc);
 }
-JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSetPhi(JNIEnv *env, jclass c, jlong h, jdoubleArray in) {
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nSetPhi(JNIEnv *env, jclass c, jlong h, jdoubleArray in) {
   jdouble *p = (*env)->GetDoubleArrayElements(env, in, 0); int rc = ggs_set_phi(H(h), p);
   (*env)->ReleaseDoubleArrayElements(env, in, p, JNI_ABORT); if (rc) throw_for(env, H(h), rc);
 }
-JNIEXPORT jint JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nGetPhiMean(JNIEnv *env, jclass c, jlong h, jdoubleArray out) {
+JNIEXPORT jint JNICALL Java_cc_mallet_topics_GGSNative_nGetPhiMean(JNIEnv *env, jclass c, jlong h, jdoubleArray out) {
   int32_t n = 0; jdouble *p = (*env)->GetDoubleArrayElements(env, out, 0); int rc = ggs_get_phi_mean(H(h), p, &n);
   (*env)->ReleaseDoubleArrayElements(env, out, p, 0); if (rc) throw_for(env, H(h), rc); return n;
 }
-JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nGetTheta(JNIEnv *env, jclass c, jlong h, jlong b, jlong e, jdoubleArray out) {
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nGetTheta(JNIEnv *env, jclass c, jlong h, jlong b, jlong e, jdoubleArray out) {
   jdouble *p = (*env)->GetDoubleArrayElements(env, out, 0); int rc = ggs_get_theta(H(h), b, e, p);
   (*env)->ReleaseDoubleArrayElements(env, out, p, 0); if (rc) throw_for(env, H(h), rc);
 }
-JNIEXPORT jdoubleArray JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nGetTimings(JNIEnv *env, jclass c, jlong h) {
-  ggs_timings t; jdouble v[4]; jdoubleArray out = (*env)->NewDoubleArray(env, 4);
+JNIEXPORT jdoubleArray JNICALL Java_cc_mallet_topics_GGSNative_nGetTimings(JNIEnv *env, jclass c, jlong h) {
+  ggs_timings t; jdouble v[5]; jdoubleArray out = (*env)->NewDoubleArray(env, 5);
   if (ggs_get_timings(H(h), &t)) return out;
-  v[0] = t.theta_ms; v[1] = t.z_ms; v[2] = t.merge_ms; v[3] = t.phi_ms;
-  (*env)->SetDoubleArrayRegion(env, out, 0, 4, v);
+  v[0] = t.theta_ms; v[1] = t.z_ms; v[2] = t.merge_ms; v[3] = t.phi_ms; v[4] = t.exchange_ms;
+  (*env)->SetDoubleArrayRegion(env, out, 0, 5, v);
   return out;
 }
 
-/* diagnostics computed on the device-resident state: two doubles (or one) cross JNI, no matrices */
-JNIEXPORT jdouble JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nModelLogLikelihood(JNIEnv *env, jclass c, jlong h) {
-  double a = 0, b = 0; CHECK(H(h), ggs_model_log_likelihood(H(h), &a, &b)); return a + b;       /* UPLDA:1644-1758 */
+/* diagnostics computed on the device-resident state: one double crosses JNI, no matrices.  Each C-ABI call returns the
+ * documents' side of THIS handle and the (replicated) topic side; a sharded run adds every handle's first to one second. */
+JNIEXPORT jdouble JNICALL Java_cc_mallet_topics_GGSNative_nModelLogLikelihoodDocSide(JNIEnv *env, jclass c, jlong h) {
+  double a = 0, b = 0; CHECK(H(h), ggs_model_log_likelihood(H(h), &a, &b)); return a;           /* UPLDA:1674-1694 */
 }
-JNIEXPORT jdouble JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nLogPosterior(JNIEnv *env, jclass c, jlong h) {
-  double a = 0, b = 0; CHECK(H(h), ggs_log_posterior(H(h), &a, &b)); return a + b;              /* UPLDA:1573-1634 */
+JNIEXPORT jdouble JNICALL Java_cc_mallet_topics_GGSNative_nModelLogLikelihoodTopicSide(JNIEnv *env, jclass c, jlong h) {
+  double a = 0, b = 0; CHECK(H(h), ggs_model_log_likelihood(H(h), &a, &b)); return b;           /* UPLDA:1701-1747 */
 }
-JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSetTestCorpus(JNIEnv *env, jclass c, jlong h,
+JNIEXPORT jdouble JNICALL Java_cc_mallet_topics_GGSNative_nLogPosteriorDocSide(JNIEnv *env, jclass c, jlong h) {
+  double a = 0, b = 0; CHECK(H(h), ggs_log_posterior(H(h), &a, &b)); return a;                  /* UPLDA:1573-1634 */
+}
+JNIEXPORT jdouble JNICALL Java_cc_mallet_topics_GGSNative_nLogPosteriorTopicSide(JNIEnv *env, jclass c, jlong h) {
+  double a = 0, b = 0; CHECK(H(h), ggs_log_posterior(H(h), &a, &b)); return b;
+}
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nSetTestCorpus(JNIEnv *env, jclass c, jlong h,
                                                                                       jlongArray docPtr, jintArray tokens) {
   jsize D = (*env)->GetArrayLength(env, docPtr) - 1;
   jlong *dp = (*env)->GetLongArrayElements(env, docPtr, 0); jint *tk = (*env)->GetIntArrayElements(env, tokens, 0);
@@ -104,7 +119,7 @@ JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nSetTestC
   (*env)->ReleaseLongArrayElements(env, docPtr, dp, JNI_ABORT); (*env)->ReleaseIntArrayElements(env, tokens, tk, JNI_ABORT);
   if (rc) throw_for(env, H(h), rc);
 }
-JNIEXPORT jdouble JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIP_nHeldOutLogLikelihood(JNIEnv *env, jclass c, jlong h, jint particles) {
+JNIEXPORT jdouble JNICALL Java_cc_mallet_topics_GGSNative_nHeldOutLogLikelihood(JNIEnv *env, jclass c, jlong h, jint particles) {
   double total = 0; CHECK(H(h), ggs_heldout_log_likelihood(H(h), particles, 0, &total)); return total;   /* MPE:85-121 */
 }
 
@@ -116,7 +131,7 @@ static ggs_handle **handles_of(JNIEnv *env, jlongArray hs, jsize *n, jlong **raw
   for (jsize i = 0; i < *n; i++) out[i] = H((*raw)[i]);
   return out;
 }
-JNIEXPORT jlongArray JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIPMulti_nGroupCreate(JNIEnv *env, jclass c, jint K, jint V,
+JNIEXPORT jlongArray JNICALL Java_cc_mallet_topics_GGSNative_nGroupCreate(JNIEnv *env, jclass c, jint K, jint V,
     jdoubleArray alpha, jdouble beta, jlong seed, jintArray deviceIds, jint flags, jint burnIn, jint thin) {
   ggs_config cfg = {0};
   jsize n = (*env)->GetArrayLength(env, deviceIds);
@@ -134,13 +149,13 @@ JNIEXPORT jlongArray JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIPMult
   free(hs);
   return out;
 }
-JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIPMulti_nGroupDestroy(JNIEnv *env, jclass c, jlongArray hs) {
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nGroupDestroy(JNIEnv *env, jclass c, jlongArray hs) {
   jsize n; jlong *raw; ggs_handle **h = handles_of(env, hs, &n, &raw);
   ggs_group_destroy(h, n);
   free(h); (*env)->ReleaseLongArrayElements(env, hs, raw, JNI_ABORT);
 }
 /* z: the corpus-wide topic indicators in (document, position) order; shardTokBase[i] .. shardTokBase[i+1] is shard i's slice */
-JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIPMulti_nGroupSetZ(JNIEnv *env, jclass c, jlongArray hs, jintArray z,
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nGroupSetZ(JNIEnv *env, jclass c, jlongArray hs, jintArray z,
     jlongArray shardTokBase, jboolean redraw) {
   jsize n; jlong *raw; ggs_handle **h = handles_of(env, hs, &n, &raw);
   jint *zp = (*env)->GetIntArrayElements(env, z, 0);
@@ -154,27 +169,27 @@ JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIPMulti_nGro
   if (rc) throw_for(env, h[0], rc);
   free(h); (*env)->ReleaseLongArrayElements(env, hs, raw, JNI_ABORT);
 }
-JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIPMulti_nGroupSweep(JNIEnv *env, jclass c, jlongArray hs, jint sweeps) {
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nGroupSweep(JNIEnv *env, jclass c, jlongArray hs, jint sweeps) {
   jsize n; jlong *raw; ggs_handle **h = handles_of(env, hs, &n, &raw);
   int rc = ggs_group_sweep(h, n, sweeps);              /* loopOverBatches + updateCounts + samplePhi for every device, collectives grouped */
   if (rc) throw_for(env, h[0], rc);
   free(h); (*env)->ReleaseLongArrayElements(env, hs, raw, JNI_ABORT);
 }
-JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIPMulti_nGroupGatherCounts(JNIEnv *env, jclass c, jlongArray hs) {
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nGroupGatherCounts(JNIEnv *env, jclass c, jlongArray hs) {
   jsize n; jlong *raw; ggs_handle **h = handles_of(env, hs, &n, &raw);
   int rc = ggs_group_gather_counts(h, n);
   if (rc) throw_for(env, h[0], rc);
   free(h); (*env)->ReleaseLongArrayElements(env, hs, raw, JNI_ABORT);
 }
-JNIEXPORT void JNICALL Java_cc_mallet_topics_LDAGroupedGibbsSamplerHIPMulti_nSetGlobalTokenCount(JNIEnv *env, jclass c, jlong h, jlong n) {
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nSetGlobalTokenCount(JNIEnv *env, jclass c, jlong h, jlong n) {
   CHECK(H(h), ggs_set_global_token_count(H(h), n));
 }
 
 /* ---- scheme=collapsed (SerialCollapsedLDA): the seeded start and the serial chain share ONE Randoms(seed) ---------- */
-JNIEXPORT void JNICALL Java_cc_mallet_topics_SerialCollapsedLDAHIP_nInitZJavaLcg(JNIEnv *env, jclass c, jlong h, jint seed) {
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nInitZJavaLcg(JNIEnv *env, jclass c, jlong h, jint seed) {
   CHECK(H(h), ggs_init_z_java_lcg(H(h), seed));        /* SerialCollapsedLDA.java:789, continued by the sweeps (MSLDA:206) */
   CHECK(H(h), ggs_init_phi(H(h)));
 }
-JNIEXPORT void JNICALL Java_cc_mallet_topics_SerialCollapsedLDAHIP_nCollapsedSerialSweep(JNIEnv *env, jclass c, jlong h, jint seed, jint sweeps) {
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nCollapsedSerialSweep(JNIEnv *env, jclass c, jlong h, jint seed, jint sweeps) {
   CHECK(H(h), ggs_collapsed_serial_sweep(H(h), seed, sweeps));   /* SerialCollapsedLDA.java:159-172 */
 }

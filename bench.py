@@ -215,7 +215,7 @@ def make_handle(native, K, V, args, local_rank):
 
 def phases(tm):
     n = max(tm["sweeps"], 1)
-    return {k: round(tm[k] / n, 4) for k in ("theta_ms", "z_ms", "merge_ms", "phi_ms", "exchange_ms")}
+    return {k: round(tm[k] / n, 4) for k in ("theta_ms", "z_ms", "merge_ms", "phi_ms", "exchange_ms", "exchange_rs_ms", "exchange_ag_ms")}
 
 
 def run_single(native, corpus, z0, K, args, local_rank, steps, warmup, fence):

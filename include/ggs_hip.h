@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define GGS_ABI_VERSION 2
+#define GGS_ABI_VERSION 3
 
 typedef struct ggs_handle ggs_handle;
 
@@ -111,6 +111,10 @@ typedef struct ggs_timings {
   int64_t tokens_sampled;
   double exchange_ms; /* cumulative: the collectives of an attached exchange (count reduce-scatter + Phi all-gather);
                          0 without one.  ABI version 2. */
+  double exchange_rs_ms; /* ... of which the count reduce-scatter.  ABI version 3. */
+  double exchange_ag_ms; /* ... of which what the sweep WAITS for of the Phi all-gathers: the first half of the gammas
+                            travels under the draw of the second half, so this is the time from the end of the slice's
+                            draw to both halves being in.  exchange_ms = exchange_rs_ms + exchange_ag_ms.  ABI version 3. */
 } ggs_timings;
 
 /* ---- lifecycle ------------------------------------------------------------ */
@@ -308,6 +312,12 @@ int ggs_heldout_log_likelihood(ggs_handle *h, int32_t num_particles, double *doc
  * beta + counts[v][k]): the Phi normalisers' exact parallel column sum on its own, for adversarial inputs */
 int ggs_debug_column_sum(int32_t device_id, int32_t V, int32_t K, const double *x /*V*K or NULL*/, const int32_t *counts /*V*K or NULL*/,
                          double beta, double *out /*K*/);
+/* The same with the caller's GUESS of the running sums at every 64-row segment start (guess [V/64 rounded up + 1][K],
+ * or NULL: the kernels make their own) -- what a sweep feeds from the previous sweep's exact values.  The guess must
+ * never decide a result: the tests pass wrong, zero, NaN and exact ones.  pref_out (same shape, or NULL) = the exact
+ * running sums the walk leaves behind; n_k_out (K, or NULL; counts only) = the integer column sums (tokensPerTopic). */
+int ggs_debug_column_sum_guided(int32_t device_id, int32_t V, int32_t K, const double *x, const int32_t *counts, double beta,
+                                const double *guess, double *out, double *pref_out, int32_t *n_k_out);
 
 #ifdef __cplusplus
 }

@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GGS_HIP_LIB") or os.path.join(CSRC, "libggs_hip.so")   # override: kernel experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ggs_hip.h")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 class GGSConfig(C.Structure):
@@ -42,6 +42,8 @@ class GGSTimings(C.Structure):
         ("sweeps", C.c_int64),
         ("tokens_sampled", C.c_int64),
         ("exchange_ms", C.c_double),
+        ("exchange_rs_ms", C.c_double),
+        ("exchange_ag_ms", C.c_double),
     ]
 
 
@@ -124,6 +126,7 @@ SIGNATURES = {
     "ggs_set_test_corpus": (C.c_int, [_vp, C.c_int64, _lp, _ip, C.c_int64]),
     "ggs_heldout_log_likelihood": (C.c_int, [_vp, C.c_int32, _dp, _dp]),
     "ggs_debug_column_sum": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _ip, C.c_double, _dp]),
+    "ggs_debug_column_sum_guided": (C.c_int, [C.c_int32, C.c_int32, C.c_int32, _dp, _ip, C.c_double, _dp, _dp, _dp, _ip]),
 }
 
 

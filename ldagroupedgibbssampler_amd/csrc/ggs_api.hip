@@ -34,7 +34,7 @@ constexpr int kMaxLdsBytes = 160 * 1024;
 constexpr int kEvRing = 8;
 struct Events {
   hipEvent_t e[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  hipEvent_t x[3] = {nullptr, nullptr, nullptr};   // with an exchange: after the count reduce-scatter, after the slice's Phi draw, after the all-gather
+  hipEvent_t x[3] = {nullptr, nullptr, nullptr};   // with an exchange: after the count reduce-scatter, after the slice's Phi draw, after the last all-gather (both halves in)
   hipEvent_t th0 = nullptr, th1 = nullptr;   // side-stream theta draw consumed by this sweep
   bool used_ahead = false, exchanged = false;
 };
@@ -103,6 +103,9 @@ struct ggs_handle {
   double *d_sum_pref = nullptr, *d_sum_fn = nullptr;   // work space of the exact parallel column sums (ggs_exact_sum.hpp)
   int32_t sum_nseg = 0;
   bool exact_sum = true;                               // GGS_DEBUG_CHAIN=1: the element-by-element column_chain_kernel instead
+  bool sum_guided = true;                              // GGS_DEBUG_GUIDED=0: every magnitude sum makes its own guess (seg + prefix launches)
+  const void *guess_src = nullptr;                     // d_sum_pref = the exact running sums of the last magnitude sum over this buffer ...
+  int32_t guess_cols = 0;                              // ... and this many columns: a good guess for the next one
   uint32_t *d_status = nullptr;
   // test set of the held-out estimator (ggs_heldout.hpp)
   int64_t *d_test_ptr = nullptr;
@@ -121,7 +124,13 @@ struct ggs_handle {
   int32_t Ks = 0, Ksm = 0, k0 = 0;                     // this rank's topic slice [k0, k0 + Ks), widest slice Ksm
   int64_t *d_koff = nullptr;                           // [K] column of topic k in the slice-major arrays
   int32_t *d_cnt_send = nullptr, *d_cnt_own = nullptr, *d_cnt_all = nullptr, *d_n_k_own = nullptr;
-  double *d_phi_own = nullptr, *d_phi_all = nullptr, *d_mag_own = nullptr, *d_tot_own = nullptr;
+  // the rank's unnormalised gammas [V][Ksm] and, behind them, their Ksm column sums; gathered in two halves (rows below /
+  // from v_split), the first half's all-gather on `comm_stream` under the second half's draw, the sums riding with the second
+  double *d_phi_own = nullptr, *d_phi_all0 = nullptr, *d_phi_all1 = nullptr, *d_mag_own = nullptr;
+  int32_t *d_krank = nullptr, *d_kcol = nullptr;      // [K] owner rank and column in its slice, for the repack
+  int32_t seg_split = 0, v_split = 0;                  // first segment / row of the second half (0: one all-gather)
+  hipStream_t comm_stream = nullptr;
+  hipEvent_t ev_half_drawn = nullptr, ev_half_gathered = nullptr;
   bool counts_global = true;                           // d_n_wk holds the corpus-wide counts
   bool cnt_own_valid = false;                          // d_cnt_own = reduce-scatter of the current d_cnt_send
   bool n_k_valid = false;                              // d_n_k follows d_n_wk
@@ -215,32 +224,40 @@ int launch_count_rebuild(ggs_handle *h) {
 }
 
 // out[k] = sum over v, in index order, of src[v][k] (MAGNITUDE: of beta + src[v][k]) for the Ks columns of a topic
-// slice -- the exact parallel formulation of ggs_exact_sum.hpp, or the element-by-element chain it replaces
+// slice -- the exact parallel formulation of ggs_exact_sum.hpp, or the element-by-element chain it replaces.
+// `guided`: h->d_sum_pref already holds a guess of the running sums for these columns (the exact values of the last
+// magnitude sum over the same buffer); otherwise two extra launches make one.  The walk leaves the exact running
+// sums there (write_pref): the next sweep's guess, and this sweep's guess for the sum of the gammas.
 template <typename T, bool MAGNITUDE>
-void launch_column_sum(ggs_handle *h, const T *src, int32_t pitch, int32_t Ks, double *out, int32_t *n_k = nullptr) {
+void launch_column_sum(ggs_handle *h, const T *src, int32_t pitch, int32_t Ks, double *out, int32_t *n_k, bool guided, bool write_pref) {
   if (Ks <= 0) return;
   if (!h->exact_sum) {
     hipLaunchKernelGGL((column_chain_kernel<T, MAGNITUDE>), dim3((Ks + 7) / 8), dim3(256), 0, h->stream, src, pitch, Ks, h->V, h->beta, out);
     return;
   }
   SumParams sp{};
-  sp.src = src; sp.pref = h->d_sum_pref; sp.fn = h->d_sum_fn; sp.out = out; sp.beta = h->beta; sp.n_k = n_k;
-  sp.pitch = pitch; sp.K = Ks; sp.V = h->V; sp.nseg = h->sum_nseg;
+  sp.src = src; sp.guess = h->d_sum_pref; sp.fn = h->d_sum_fn; sp.out = out; sp.beta = h->beta; sp.n_k = n_k;
+  sp.pitch = pitch; sp.K = Ks; sp.V = h->V; sp.nseg = h->sum_nseg; sp.write_pref = write_pref ? 1 : 0;
   const dim3 rows((unsigned)h->sum_nseg, (unsigned)((Ks + kSumBlock - 1) / kSumBlock));
-  hipLaunchKernelGGL((sum_seg_kernel<T, MAGNITUDE>), rows, dim3(kSumBlock), 0, h->stream, sp);
-  hipLaunchKernelGGL(sum_prefix_kernel, dim3((unsigned)Ks), dim3(64), 0, h->stream, sp);
-  hipLaunchKernelGGL((sum_segfn_kernel<T, MAGNITUDE>), rows, dim3(kSumBlock), 0, h->stream, sp);
+  if (!guided) {
+    hipLaunchKernelGGL((sum_seg_kernel<T, MAGNITUDE>), rows, dim3(kSumBlock), 0, h->stream, sp);
+    hipLaunchKernelGGL(sum_prefix_kernel, dim3((unsigned)Ks), dim3(64), 0, h->stream, sp);
+  }
+  hipLaunchKernelGGL((sum_segfn_kernel<T, MAGNITUDE>), dim3((unsigned)h->sum_nseg, (unsigned)((Ks + kSegFnCols - 1) / kSegFnCols)), dim3(256), 0, h->stream, sp);
   hipLaunchKernelGGL((sum_walk_kernel<T, MAGNITUDE>), dim3((unsigned)Ks), dim3(64), 0, h->stream, sp);
 }
 
 // magnitude_k = sum_v (beta + n_kv) and tokensPerTopic for the Ks columns of `cnt`
 int launch_magnitude_on(ggs_handle *h, const int32_t *cnt, int32_t pitch, int32_t Ks, double *mag, int32_t *n_k) {
   if (Ks <= 0) return GGS_OK;
-  HIP_TRY(h, hipMemsetAsync(n_k, 0, sizeof(int32_t) * (size_t)Ks, h->stream));
   if (h->exact_sum) {
-    launch_column_sum<int32_t, true>(h, cnt, pitch, Ks, mag, n_k);   // tokensPerTopic falls out of the first pass
+    // the guess of the guided form is only a guess for the SAME columns of the SAME buffer
+    const bool guided = h->sum_guided && h->guess_src == cnt && h->guess_cols == Ks;
+    launch_column_sum<int32_t, true>(h, cnt, pitch, Ks, mag, n_k, guided, true);   // tokensPerTopic falls out of the segment pass
+    h->guess_src = cnt; h->guess_cols = Ks;
   } else {
-    launch_column_sum<int32_t, true>(h, cnt, pitch, Ks, mag);
+    HIP_TRY(h, hipMemsetAsync(n_k, 0, sizeof(int32_t) * (size_t)Ks, h->stream));
+    launch_column_sum<int32_t, true>(h, cnt, pitch, Ks, mag, nullptr, false, false);
     hipLaunchKernelGGL(topic_totals_kernel, dim3(grid_for((int64_t)Ks * h->V, 256, 16)), dim3(256), (size_t)Ks * sizeof(int32_t), h->stream, cnt,
                        Ks, pitch, h->V, n_k);
   }
@@ -293,58 +310,114 @@ int launch_magnitude(ggs_handle *h) {
 }
 
 // Phi draw: initial (K8) or per sweep (K6) for the topics [k0, k0 + Ks) from their corpus-wide counts
-// cnt [V][cnt_pitch]; normalised rows into out [V][out_pitch].
-int launch_phi_slice(ggs_handle *h, bool initial, const int32_t *cnt, int32_t cnt_pitch, int32_t Ks, int32_t k0, double *out, int32_t out_pitch,
-                     double *mag, double *tot, int32_t *n_k, double *phi_mean) {
-  if (Ks <= 0) return GGS_OK;
-  const int V = h->V;
-  int rc = launch_magnitude_on(h, cnt, cnt_pitch, Ks, mag, n_k);
-  if (rc) return rc;
+// cnt [V][cnt_pitch]; rows into out [V][out_pitch].  In steps, so that the exchange can slot its collectives in:
+//   phi_slice_magnitude   the Dirichlet magnitudes (and tokensPerTopic)
+//   phi_slice_gamma       the gamma draws of the segments [seg0, seg1) + the segment functions of their column sums
+//   phi_slice_total       the walk of those: tot[k] = sum_v gamma, in index order
+//   phi_slice_normalise   one GPU: divide in place (with an exchange the division is done by the repack kernel)
+int phi_slice_gamma(ggs_handle *h, bool initial, const int32_t *cnt, int32_t cnt_pitch, int32_t Ks, int32_t k0, double *out, int32_t out_pitch,
+                    const double *mag, int32_t seg0, int32_t seg1) {
+  if (Ks <= 0 || seg1 <= seg0) return GGS_OK;
   PhiGammaParams gp{};
   gp.n_wk = cnt; gp.mag = mag; gp.phiT = out; gp.status = h->d_status;
   gp.seed = h->seed; gp.iteration = (uint32_t)h->iteration;
   gp.purpose = initial ? GGS_PURPOSE_INIT_PHI : GGS_PURPOSE_PHI;
-  gp.K = Ks; gp.Kp = out_pitch; gp.V = V; gp.cnt_pitch = cnt_pitch; gp.k0 = k0; gp.beta = h->beta;
+  gp.K = Ks; gp.Kp = out_pitch; gp.V = h->V; gp.cnt_pitch = cnt_pitch; gp.k0 = k0; gp.beta = h->beta;
   // Dirichlet(int size, double beta): magnitude = V*beta, partition = 1.0/V
-  gp.prior_pm = (1.0 / (double)V) * ((double)V * h->beta);
+  gp.prior_pm = (1.0 / (double)h->V) * ((double)h->V * h->beta);
   gp.initial = initial ? 1 : 0;
-  const int64_t kv = (int64_t)Ks * V;
-  // tiles small enough that every CU holds several workgroups (a topic slice of one rank in eight is 0.65 M elements)
-  gp.tile = (int32_t)std::max<int64_t>(256, std::min<int64_t>(kPhiTile, (kv / 2048 + 255) / 256 * 256));
+  // tiles of one 64-row segment x kc <= kPhiCols topics, the column groups as equal as they come.  A single wave per
+  // tile issues an instruction every ~8 cycles, so what makes the draw fast is waves per SIMD: a narrow slice (one rank
+  // in eight draws 13 topics) is cut into narrower tiles until there are ~4 waves for each of the chip's SIMDs; the price
+  // is a thinner leftover queue per tile (the general rejection loops then run with fewer lanes in use).
+  const int64_t want_tiles = (int64_t)h->num_cus * 4 * 4;
+  int kc_cap = (int)std::min<int64_t>(kPhiCols, std::max<int64_t>(2, (int64_t)Ks * (seg1 - seg0) / want_tiles));
+  if (const char *e = std::getenv("GGS_DEBUG_PHICOLS")) kc_cap = std::max(1, std::min(kPhiCols, std::atoi(e)));
+  gp.ncg = (Ks + kc_cap - 1) / kc_cap;
+  gp.kc = (Ks + gp.ncg - 1) / gp.ncg;
+  gp.ncg = (Ks + gp.kc - 1) / gp.kc;
+  gp.seg_begin = seg0; gp.seg_end = seg1;
   gp.queue_cap = std::min(kPhiQueue, h->gamma_queue_cap);
-  hipLaunchKernelGGL(phi_gamma_kernel, dim3(grid_for(kv, gp.tile)), dim3(256), 0, h->stream, gp);
-  launch_column_sum<double, false>(h, out, out_pitch, Ks, tot);
-  hipLaunchKernelGGL(phi_normalise_kernel, dim3(grid_for(kv, 256, 2)), dim3(256), 0, h->stream, out, tot, Ks, out_pitch, V, phi_mean);
+  gp.guess = h->exact_sum ? h->d_sum_pref : nullptr; gp.fn = h->d_sum_fn;
+  const int64_t tiles = (int64_t)(seg1 - seg0) * gp.ncg;
+  // single-wave workgroups; a grid of at most 32 per CU, the rest by striding
+  hipLaunchKernelGGL(phi_gamma_kernel, dim3((unsigned)std::min<int64_t>(tiles, (int64_t)h->num_cus * 32)), dim3(64), 0, h->stream, gp);
+  HIP_TRY(h, hipGetLastError());
+  return GGS_OK;
+}
+int phi_slice_total(ggs_handle *h, const double *out, int32_t out_pitch, int32_t Ks, double *tot) {
+  if (Ks <= 0) return GGS_OK;
+  if (h->exact_sum) {
+    SumParams sp{};
+    sp.src = out; sp.guess = h->d_sum_pref; sp.fn = h->d_sum_fn; sp.out = tot; sp.beta = h->beta; sp.n_k = nullptr;
+    sp.pitch = out_pitch; sp.K = Ks; sp.V = h->V; sp.nseg = h->sum_nseg; sp.write_pref = 0;   // the guess stays the magnitudes' running sums
+    hipLaunchKernelGGL((sum_walk_kernel<double, false>), dim3((unsigned)Ks), dim3(64), 0, h->stream, sp);
+  } else {
+    launch_column_sum<double, false>(h, out, out_pitch, Ks, tot, nullptr, false, false);
+  }
+  HIP_TRY(h, hipGetLastError());
+  return GGS_OK;
+}
+int launch_phi_slice(ggs_handle *h, bool initial, const int32_t *cnt, int32_t cnt_pitch, int32_t Ks, int32_t k0, double *out, int32_t out_pitch,
+                     double *mag, double *tot, int32_t *n_k, double *phi_mean) {
+  if (Ks <= 0) return GGS_OK;
+  int rc;
+  if ((rc = launch_magnitude_on(h, cnt, cnt_pitch, Ks, mag, n_k)) || (rc = phi_slice_gamma(h, initial, cnt, cnt_pitch, Ks, k0, out, out_pitch, mag, 0, h->sum_nseg)) ||
+      (rc = phi_slice_total(h, out, out_pitch, Ks, tot)))
+    return rc;
+  hipLaunchKernelGGL(phi_normalise_kernel, dim3(grid_for((int64_t)Ks * h->V, 256, 2)), dim3(256), 0, h->stream, out, tot, Ks, out_pitch, h->V, phi_mean);
   HIP_TRY(h, hipGetLastError());
   return GGS_OK;
 }
 
-// The three steps of the Phi phase with an exchange attached (ggs_group_sweep issues each step for all handles of a
-// one-process group inside ncclGroupStart/End; one handle per process runs them back to back):
-//   A  reduce-scatter of the counts by topic slice
-//   B  this rank's slice: magnitudes, gammas, normalisers; then the all-gather of the fp64 slices
-//   C  repack [nranks][V][Ksm] -> phiT [V][Kp] (+ the running phi mean)
-int phi_step_a(ggs_handle *h, Events *E) {
-  int rc = exchange_reduce_scatter(h);
-  if (rc) return rc;
-  if (E) HIP_TRY(h, hipEventRecord(E->x[0], h->stream));
+// The steps of the Phi phase with an exchange attached (ggs_group_sweep issues each for all handles of a one-process
+// group, the collective ones inside ncclGroupStart/End; one handle per process runs them back to back):
+//   A     reduce-scatter of the counts by topic slice
+//   B1    this rank's slice: magnitudes, the gammas of the first half of the vocabulary
+//   G0    all-gather of that half on the communication stream -- it runs UNDER step B2
+//   B2    the gammas of the second half, then the walk of the column sums (it needs every gamma of the slice)
+//   G1    all-gather of the second half with the Ksm column sums behind it, on the main stream
+//   C     repack [nranks][..] -> phiT [V][Kp], dividing by the owner's column sum on the way (the same IEEE division
+//         the one-GPU normalise kernel does: bit-identical) (+ the running phi mean)
+// What travels is therefore the UNNORMALISED gammas: the division does not have to wait for the slice to be complete
+// before the first bytes go out.  Events are recorded by the callers AFTER a grouped step (inside
+// ncclGroupStart/End the collectives are only collected, not enqueued).
+size_t half0_elems(const ggs_handle *h) { return (size_t)h->v_split * h->Ksm; }
+size_t half1_elems(const ggs_handle *h) { return (size_t)(h->V - h->v_split) * h->Ksm + (size_t)h->Ksm; }
+int phi_step_a(ggs_handle *h) { return exchange_reduce_scatter(h); }
+int phi_step_b1(ggs_handle *h, bool initial) {
+  int rc;
+  if ((rc = launch_magnitude_on(h, h->d_cnt_own, h->Ksm, h->Ks, h->d_mag_own, h->d_n_k_own))) return rc;
+  if (h->seg_split > 0) {
+    if ((rc = phi_slice_gamma(h, initial, h->d_cnt_own, h->Ksm, h->Ks, h->k0, h->d_phi_own, h->Ksm, h->d_mag_own, 0, h->seg_split))) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev_half_drawn, h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(h->comm_stream, h->ev_half_drawn, 0));
+  }
   return GGS_OK;
 }
-int phi_step_b_compute(ggs_handle *h, bool initial, Events *E) {
-  int rc = launch_phi_slice(h, initial, h->d_cnt_own, h->Ksm, h->Ks, h->k0, h->d_phi_own, h->Ksm, h->d_mag_own, h->d_tot_own, h->d_n_k_own, nullptr);
-  if (rc) return rc;
-  if (E) HIP_TRY(h, hipEventRecord(E->x[1], h->stream));
-  return GGS_OK;
+int phi_step_g0(ggs_handle *h) {
+  if (h->seg_split <= 0) return GGS_OK;
+  return xcall(h, h->xg->ops.all_gather_f64(h->xg->ops.ctx, h->d_phi_own, h->d_phi_all0, (int64_t)half0_elems(h), h->comm_stream), "all_gather_f64");
 }
-int phi_step_b_gather(ggs_handle *h, Events *E) {
-  int rc = xcall(h, h->xg->ops.all_gather_f64(h->xg->ops.ctx, h->d_phi_own, h->d_phi_all, (int64_t)h->V * h->Ksm, h->stream), "all_gather_f64");
-  if (rc) return rc;
-  if (E) HIP_TRY(h, hipEventRecord(E->x[2], h->stream));
+int phi_step_b2(ggs_handle *h, bool initial) {
+  int rc;
+  if (h->seg_split > 0) HIP_TRY(h, hipEventRecord(h->ev_half_gathered, h->comm_stream));
+  if ((rc = phi_slice_gamma(h, initial, h->d_cnt_own, h->Ksm, h->Ks, h->k0, h->d_phi_own, h->Ksm, h->d_mag_own, h->seg_split, h->sum_nseg))) return rc;
+  return phi_slice_total(h, h->d_phi_own, h->Ksm, h->Ks, h->d_phi_own + (size_t)h->V * h->Ksm);
+}
+int phi_step_g1(ggs_handle *h) {
+  return xcall(h, h->xg->ops.all_gather_f64(h->xg->ops.ctx, h->d_phi_own + half0_elems(h), h->d_phi_all1, (int64_t)half1_elems(h), h->stream), "all_gather_f64");
+}
+int phi_join_halves(ggs_handle *h) {                   // the main stream goes on only when the first half has arrived too
+  if (h->seg_split > 0) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_half_gathered, 0));
   return GGS_OK;
 }
 int phi_step_c(ggs_handle *h, bool accumulate_mean) {
-  hipLaunchKernelGGL(phi_unslice_kernel, dim3(grid_for((int64_t)h->K * h->V, 256, 2)), dim3(256), 0, h->stream, h->d_phi_all, h->d_koff, h->Ksm, h->d_phiT,
-                     h->K, h->Kp, h->V, accumulate_mean ? h->d_phi_mean : nullptr);
+  PhiRepackParams rp{};
+  rp.all0 = h->d_phi_all0; rp.all1 = h->d_phi_all1; rp.krank = h->d_krank; rp.kcol = h->d_kcol; rp.phiT = h->d_phiT;
+  rp.phi_mean = accumulate_mean ? h->d_phi_mean : nullptr;
+  rp.c0 = (int64_t)half0_elems(h); rp.c1 = (int64_t)half1_elems(h); rp.K = h->K; rp.Kp = h->Kp; rp.V = h->V; rp.Ksm = h->Ksm; rp.v_split = h->v_split;
+  hipLaunchKernelGGL(phi_repack_kernel, dim3(grid_for((int64_t)h->K * h->V, 256, 2)), dim3(256), 0, h->stream, rp);
   HIP_TRY(h, hipGetLastError());
   h->have_phi = true;
   return GGS_OK;
@@ -355,7 +428,12 @@ int phi_step_c(ggs_handle *h, bool accumulate_mean) {
 int launch_phi(ggs_handle *h, bool initial, bool accumulate_mean, Events *E = nullptr) {
   int rc;
   if (h->xg) {
-    if ((rc = phi_step_a(h, E)) || (rc = phi_step_b_compute(h, initial, E)) || (rc = phi_step_b_gather(h, E))) return rc;
+    if ((rc = phi_step_a(h))) return rc;
+    if (E) HIP_TRY(h, hipEventRecord(E->x[0], h->stream));
+    if ((rc = phi_step_b1(h, initial)) || (rc = phi_step_g0(h)) || (rc = phi_step_b2(h, initial))) return rc;
+    if (E) HIP_TRY(h, hipEventRecord(E->x[1], h->stream));
+    if ((rc = phi_step_g1(h)) || (rc = phi_join_halves(h))) return rc;
+    if (E) HIP_TRY(h, hipEventRecord(E->x[2], h->stream));
     return phi_step_c(h, accumulate_mean);
   }
   if ((rc = launch_phi_slice(h, initial, h->d_n_wk, h->K, h->K, 0, h->d_phiT, h->Kp, h->d_mag, h->d_tot, h->d_n_k, accumulate_mean ? h->d_phi_mean : nullptr)))
@@ -551,10 +629,10 @@ int settle_sweeps(ggs_handle *h) {
     h->tm.theta_ms += ms;
     HIP_TRY(h, hipEventElapsedTime(&ms, E.e[1], E.e[2])); h->tm.z_ms += ms;
     HIP_TRY(h, hipEventElapsedTime(&ms, E.e[2], E.e[3])); h->tm.merge_ms += ms;
-    if (E.exchanged) {   // reduce-scatter | slice draw | all-gather | repack
-      HIP_TRY(h, hipEventElapsedTime(&ms, E.e[4], E.x[0])); h->tm.exchange_ms += ms;
+    if (E.exchanged) {   // reduce-scatter | slice draw (the first half's all-gather beneath it) | what is left of the all-gathers | repack
+      HIP_TRY(h, hipEventElapsedTime(&ms, E.e[4], E.x[0])); h->tm.exchange_ms += ms; h->tm.exchange_rs_ms += ms;
       HIP_TRY(h, hipEventElapsedTime(&ms, E.x[0], E.x[1])); h->tm.phi_ms += ms;
-      HIP_TRY(h, hipEventElapsedTime(&ms, E.x[1], E.x[2])); h->tm.exchange_ms += ms;
+      HIP_TRY(h, hipEventElapsedTime(&ms, E.x[1], E.x[2])); h->tm.exchange_ms += ms; h->tm.exchange_ag_ms += ms;
       HIP_TRY(h, hipEventElapsedTime(&ms, E.x[2], E.e[5])); h->tm.phi_ms += ms;
     } else {
       HIP_TRY(h, hipEventElapsedTime(&ms, E.e[4], E.e[5])); h->tm.phi_ms += ms;
@@ -687,29 +765,70 @@ int finish_sweep(ggs_handle *h, bool with_phi, bool settle = true) {
   return finish_sweep_settle(h);
 }
 
-// Buffers and the column map of an attached exchange; the handle moves to a stream of its own.
+// An Exchange that never got attached: its communicator goes with it when the library created it.
+void exchange_free(Exchange *x) {
+  if (!x) return;
+  if (x->own_comm && x->comm && x->api) (void)x->api->CommDestroy(x->comm);
+  delete x;
+}
+// what every attach call checks BEFORE it creates anything (ncclCommInitRank is a blocking collective)
+int exchange_precheck(ggs_handle *h, int32_t rank, int32_t nranks) {
+  if (!h) return GGS_ERR_BAD_ARG;
+  if (h->xg) return set_err(h, GGS_ERR_STATE, "an exchange is already attached");
+  if (h->have_corpus) return set_err(h, GGS_ERR_STATE, "attach the exchange before ggs_set_corpus");
+  if (nranks < 1 || rank < 0 || rank >= nranks) return set_err(h, GGS_ERR_BAD_ARG, "rank outside [0, nranks)");
+  return bind_device(h);
+}
+
+// Buffers and the column map of an attached exchange; the handle moves to a stream of its own.  Takes ownership of x.
 int setup_exchange(ggs_handle *h, Exchange *x) {
-  int rc = bind_device(h);
-  if (rc) { delete x; return rc; }
-  if (h->xg) { delete x; return set_err(h, GGS_ERR_STATE, "an exchange is already attached"); }
-  if (h->have_corpus) { delete x; return set_err(h, GGS_ERR_STATE, "attach the exchange before ggs_set_corpus"); }
-  if (x->nranks < 1 || x->rank < 0 || x->rank >= x->nranks) { delete x; return set_err(h, GGS_ERR_BAD_ARG, "rank outside [0, nranks)"); }
+  int rc = exchange_precheck(h, x->rank, x->nranks);
+  if (rc) { exchange_free(x); return rc; }
   const std::vector<int32_t> sl = topic_slices(h->K, x->nranks);
   h->xg = x;
   h->k0 = sl[(size_t)x->rank]; h->Ks = sl[(size_t)x->rank + 1] - h->k0; h->Ksm = (h->K + x->nranks - 1) / x->nranks;
   std::vector<int64_t> koff((size_t)h->K);
   for (int32_t r = 0; r < x->nranks; ++r)
     for (int32_t k = sl[(size_t)r]; k < sl[(size_t)r + 1]; ++k) koff[(size_t)k] = (int64_t)r * h->V * h->Ksm + (k - sl[(size_t)r]);
+  std::vector<int32_t> krank((size_t)h->K), kcol((size_t)h->K);
+  for (int32_t r = 0; r < x->nranks; ++r)
+    for (int32_t k = sl[(size_t)r]; k < sl[(size_t)r + 1]; ++k) { krank[(size_t)k] = r; kcol[(size_t)k] = k - sl[(size_t)r]; }
+  // the all-gather of the gammas in two halves of the vocabulary (whole 64-row segments: the draw's tiles); a short
+  // vocabulary goes in one
+  h->seg_split = h->sum_nseg >= 16 ? h->sum_nseg / 2 : 0;
+  if (const char *e = std::getenv("GGS_DEBUG_AGSPLIT")) h->seg_split = std::max(0, std::min(h->sum_nseg - 1, std::atoi(e)));
+  h->v_split = h->seg_split * kSumSegRows;
   const size_t slice = (size_t)h->V * h->Ksm, all = slice * (size_t)x->nranks;
-  if ((rc = dev_alloc(h, &h->d_koff, (size_t)h->K)) || (rc = dev_alloc(h, &h->d_cnt_send, all)) || (rc = dev_alloc(h, &h->d_cnt_own, slice)) ||
-      (rc = dev_alloc(h, &h->d_phi_own, slice)) || (rc = dev_alloc(h, &h->d_phi_all, all)) || (rc = dev_alloc(h, &h->d_mag_own, (size_t)h->Ksm)) ||
-      (rc = dev_alloc(h, &h->d_tot_own, (size_t)h->Ksm)) || (rc = dev_alloc(h, &h->d_n_k_own, (size_t)h->Ksm)))
-    return rc;
-  HIP_TRY(h, hipMemcpy(h->d_koff, koff.data(), sizeof(int64_t) * koff.size(), hipMemcpyHostToDevice));
-  HIP_TRY(h, hipMemset(h->d_cnt_send, 0, all * sizeof(int32_t)));
-  HIP_TRY(h, hipMemset(h->d_cnt_own, 0, slice * sizeof(int32_t)));
-  HIP_TRY(h, hipMemset(h->d_phi_own, 0, slice * sizeof(double)));
-  HIP_TRY(h, hipMemset(h->d_phi_all, 0, all * sizeof(double)));
+  auto fail = [&](int code) {                        // a half-built exchange must not stay attached
+    void *bufs[] = {h->d_koff, h->d_krank, h->d_kcol, h->d_cnt_send, h->d_cnt_own, h->d_phi_own, h->d_phi_all0, h->d_phi_all1, h->d_mag_own, h->d_n_k_own};
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    h->d_koff = nullptr; h->d_krank = h->d_kcol = nullptr; h->d_cnt_send = h->d_cnt_own = nullptr; h->d_phi_own = h->d_phi_all0 = h->d_phi_all1 = nullptr;
+    h->d_mag_own = nullptr; h->d_n_k_own = nullptr;
+    h->xg = nullptr; h->Ks = h->Ksm = h->K; h->k0 = 0;
+    exchange_free(x);
+    return code;
+  };
+  if ((rc = dev_alloc(h, &h->d_koff, (size_t)h->K)) || (rc = dev_alloc(h, &h->d_krank, (size_t)h->K)) || (rc = dev_alloc(h, &h->d_kcol, (size_t)h->K)) ||
+      (rc = dev_alloc(h, &h->d_cnt_send, all)) || (rc = dev_alloc(h, &h->d_cnt_own, slice)) || (rc = dev_alloc(h, &h->d_phi_own, slice + (size_t)h->Ksm)) ||
+      (rc = dev_alloc(h, &h->d_phi_all0, half0_elems(h) * (size_t)x->nranks)) || (rc = dev_alloc(h, &h->d_phi_all1, half1_elems(h) * (size_t)x->nranks)) ||
+      (rc = dev_alloc(h, &h->d_mag_own, (size_t)h->Ksm)) || (rc = dev_alloc(h, &h->d_n_k_own, (size_t)h->Ksm)))
+    return fail(rc);
+  if (hipMemcpy(h->d_koff, koff.data(), sizeof(int64_t) * koff.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(h->d_krank, krank.data(), sizeof(int32_t) * krank.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(h->d_kcol, kcol.data(), sizeof(int32_t) * kcol.size(), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemset(h->d_cnt_send, 0, all * sizeof(int32_t)) != hipSuccess || hipMemset(h->d_cnt_own, 0, slice * sizeof(int32_t)) != hipSuccess ||
+      hipMemset(h->d_phi_own, 0, (slice + (size_t)h->Ksm) * sizeof(double)) != hipSuccess ||
+      hipMemset(h->d_phi_all0, 0, std::max<size_t>(half0_elems(h) * (size_t)x->nranks, 1) * sizeof(double)) != hipSuccess ||
+      hipMemset(h->d_phi_all1, 0, half1_elems(h) * (size_t)x->nranks * sizeof(double)) != hipSuccess)
+    return fail(set_err(h, GGS_ERR_HIP, "exchange buffers: copy / memset failed"));
+  {
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (hipStreamCreateWithPriority(&h->comm_stream, hipStreamNonBlocking, hi) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_half_drawn, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_half_gathered, hipEventDisableTiming) != hipSuccess)
+      return fail(set_err(h, GGS_ERR_HIP, "exchange: communication stream / events"));
+  }
   if (!h->stream) {
     // Collectives are ordered by THIS stream alone: not the legacy default stream, whose implicit synchronisation with
     // other libraries' blocking streams is exactly the convention not to rely on.  HIGH priority: measured with RCCL
@@ -925,6 +1044,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     return bail(rc);
   if ((h->flags & GGS_FLAG_SAVE_PHI_MEAN) && (rc = dev_alloc(h, &h->d_phi_mean, kv))) return bail(rc);
   if (const char *e = std::getenv("GGS_DEBUG_CHAIN")) h->exact_sum = std::atoi(e) == 0;
+  if (const char *e = std::getenv("GGS_DEBUG_GUIDED")) h->sum_guided = std::atoi(e) != 0;
   h->sum_nseg = (h->V + kSumSegRows - 1) / kSumSegRows;
   if (h->exact_sum && ((rc = dev_alloc(h, &h->d_sum_pref, ((size_t)h->sum_nseg + 1) * h->K)) ||
                        (rc = dev_alloc(h, &h->d_sum_fn, (size_t)h->sum_nseg * h->K * 4))))
@@ -991,14 +1111,14 @@ void ggs_destroy(ggs_handle *h) {
                   h->d_phiT, h->d_mag, h->d_tot, h->d_phi_mean, h->d_n_wk, h->d_n_k, h->d_perm, h->d_inv_perm, h->d_zw, h->d_seg_word, h->d_seg_begin,
                   h->d_status, h->d_scratch, h->d_sum_pref, h->d_sum_fn, h->d_ct_tok, h->d_ct_idx, h->d_ct_ip, h->d_c_docs, h->d_hot_words, h->d_order,
                   h->d_test_ptr, h->d_test_tok, h->d_test_ll, h->d_test_docs, h->d_koff, h->d_cnt_send, h->d_cnt_own, h->d_cnt_all, h->d_n_k_own,
-                  h->d_phi_own, h->d_phi_all, h->d_mag_own, h->d_tot_own, h->d_lcg, h->d_chunk_doc1};
+                  h->d_phi_own, h->d_phi_all0, h->d_phi_all1, h->d_mag_own, h->d_krank, h->d_kcol, h->d_lcg, h->d_chunk_doc1};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
-  if (h->xg) {
-    if (h->xg->own_comm && h->xg->comm && h->xg->api) (void)h->xg->api->CommDestroy(h->xg->comm);
-    delete h->xg;
-  }
+  exchange_free(h->xg);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
+  if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+  if (h->ev_half_drawn) (void)hipEventDestroy(h->ev_half_drawn);
+  if (h->ev_half_gathered) (void)hipEventDestroy(h->ev_half_gathered);
   for (auto &e : h->ev_part)
     if (e) (void)hipEventDestroy(e);
   for (auto &E : h->evs) {
@@ -1389,7 +1509,8 @@ int ggs_set_global_token_count(ggs_handle *h, int64_t n_tokens) {
 
 // ---- multi-GPU: the exchange (include/ggs_hip.h) ------------------------------------------------------------------
 int ggs_attach_exchange(ggs_handle *h, int32_t rank, int32_t nranks, const ggs_exchange_ops *ops) {
-  if (!h) return GGS_ERR_BAD_ARG;
+  int rc = exchange_precheck(h, rank, nranks);
+  if (rc) return rc;
   if (!ops || ops->struct_size != (int32_t)sizeof(ggs_exchange_ops) || !ops->reduce_scatter_i32 || !ops->all_gather_f64 || !ops->all_gather_i32)
     return set_err(h, GGS_ERR_BAD_ARG, "ggs_exchange_ops: wrong struct_size or a null callback");
   auto *x = new (std::nothrow) Exchange();
@@ -1399,7 +1520,8 @@ int ggs_attach_exchange(ggs_handle *h, int32_t rank, int32_t nranks, const ggs_e
 }
 
 int ggs_attach_null_exchange(ggs_handle *h, int32_t rank, int32_t nranks) {
-  if (!h) return GGS_ERR_BAD_ARG;
+  int rc = exchange_precheck(h, rank, nranks);
+  if (rc) return rc;
   auto *x = new (std::nothrow) Exchange();
   if (!x) return GGS_ERR_HIP;
   x->rank = rank; x->nranks = nranks;
@@ -1424,9 +1546,8 @@ int ggs_rccl_unique_id(void *out_id) {
 
 int ggs_attach_rccl(ggs_handle *h, int32_t rank, int32_t nranks, const void *unique_id) {
   if (!h) return GGS_ERR_BAD_ARG;
-  if (!unique_id || nranks < 1 || rank < 0 || rank >= nranks) return set_err(h, GGS_ERR_BAD_ARG, "bad rank / nranks / unique id");
-  if (h->xg) return set_err(h, GGS_ERR_STATE, "an exchange is already attached");
-  int rc = bind_device(h);
+  if (!unique_id) return set_err(h, GGS_ERR_BAD_ARG, "null unique id");
+  int rc = exchange_precheck(h, rank, nranks);       // before the blocking collective below: a rejected call must not have joined it
   if (rc) return rc;
   Exchange *x = new_rccl_exchange(h, rank, nranks, &rc);
   if (!x) return rc;
@@ -1444,9 +1565,8 @@ int ggs_attach_rccl(ggs_handle *h, int32_t rank, int32_t nranks, const void *uni
 
 int ggs_attach_rccl_comm(ggs_handle *h, int32_t rank, int32_t nranks, void *nccl_comm) {
   if (!h) return GGS_ERR_BAD_ARG;
-  if (!nccl_comm || nranks < 1 || rank < 0 || rank >= nranks) return set_err(h, GGS_ERR_BAD_ARG, "bad rank / nranks / communicator");
-  if (h->xg) return set_err(h, GGS_ERR_STATE, "an exchange is already attached");
-  int rc = bind_device(h);
+  if (!nccl_comm) return set_err(h, GGS_ERR_BAD_ARG, "null communicator");
+  int rc = exchange_precheck(h, rank, nranks);
   if (rc) return rc;
   Exchange *x = new_rccl_exchange(h, rank, nranks, &rc);
   if (!x) return rc;
@@ -1498,11 +1618,22 @@ int group_phi(ggs_handle **hs, int32_t n, bool initial, bool in_sweep) {
     if (api->GroupEnd() != ncclSuccess && !r) r = set_err(hs[0], GGS_ERR_HIP, "ncclGroupEnd failed");
     return r;
   };
-  if ((rc = grouped([](ggs_handle *h, Events *E) { return phi_step_a(h, E); }))) return rc;
-  for (int32_t i = 0; i < n; ++i) {
-    if ((rc = bind_device(hs[i])) || (rc = phi_step_b_compute(hs[i], initial, in_sweep ? &hs[i]->evs[hs[i]->ev_head] : nullptr))) return rc;
-  }
-  if ((rc = grouped([](ggs_handle *h, Events *E) { return phi_step_b_gather(h, E); }))) return rc;
+  // a step for every handle; events are recorded AFTER a grouped step: inside ncclGroupStart/End the collectives are
+  // only collected, and an event recorded there would land on the stream before them
+  auto each = [&](auto step) {
+    int r = GGS_OK;
+    for (int32_t i = 0; i < n && !r; ++i)
+      if (!(r = bind_device(hs[i]))) r = step(hs[i], in_sweep ? &hs[i]->evs[hs[i]->ev_head] : nullptr);
+    return r;
+  };
+  auto record = [](ggs_handle *h, hipEvent_t ev) { return hipEventRecord(ev, h->stream) == hipSuccess ? GGS_OK : set_err(h, GGS_ERR_HIP, "hipEventRecord"); };
+  if ((rc = grouped([](ggs_handle *h, Events *) { return phi_step_a(h); })) ||
+      (rc = each([&](ggs_handle *h, Events *E) { int r = E ? record(h, E->x[0]) : GGS_OK; return r ? r : phi_step_b1(h, initial); })) ||
+      (rc = grouped([](ggs_handle *h, Events *) { return phi_step_g0(h); })) ||
+      (rc = each([&](ggs_handle *h, Events *E) { int r = phi_step_b2(h, initial); return r ? r : (E ? record(h, E->x[1]) : GGS_OK); })) ||
+      (rc = grouped([](ggs_handle *h, Events *) { return phi_step_g1(h); })) ||
+      (rc = each([&](ggs_handle *h, Events *E) { int r = phi_join_halves(h); return r ? r : (E ? record(h, E->x[2]) : GGS_OK); })))
+    return rc;
   for (int32_t i = 0; i < n; ++i) {
     ggs_handle *h = hs[i];
     if ((rc = bind_device(h)) || (rc = phi_step_c(h, acc[(size_t)i] != 0))) return rc;
@@ -2020,27 +2151,37 @@ int ggs_debug_draw(int32_t device_id, int32_t kind, uint64_t seed, uint32_t iter
   return GGS_OK;
 }
 
-int ggs_debug_column_sum(int32_t device_id, int32_t V, int32_t K, const double *x, const int32_t *counts, double beta, double *out) {
+int ggs_debug_column_sum_guided(int32_t device_id, int32_t V, int32_t K, const double *x, const int32_t *counts, double beta, const double *guess,
+                                double *out, double *pref_out, int32_t *n_k_out) {
   if (V <= 0 || K <= 0 || (!x == !counts) || !out || hipSetDevice(device_id) != hipSuccess) return GGS_ERR_BAD_ARG;
   TmpDev t;
   const size_t kv = (size_t)V * K;
   ggs_handle tmp;                                     // only the fields launch_column_sum reads
   tmp.K = K; tmp.V = V; tmp.beta = beta; tmp.stream = nullptr; tmp.exact_sum = true;
   tmp.sum_nseg = (V + kSumSegRows - 1) / kSumSegRows;
-  tmp.d_sum_pref = static_cast<double *>(t.get(((size_t)tmp.sum_nseg + 1) * K * 8));
+  const size_t pref_bytes = ((size_t)tmp.sum_nseg + 1) * K * 8;
+  tmp.d_sum_pref = static_cast<double *>(t.get(pref_bytes));
   tmp.d_sum_fn = static_cast<double *>(t.get((size_t)tmp.sum_nseg * K * 32));
   void *dsrc = t.get(kv * (x ? 8 : 4));
   auto *dou = static_cast<double *>(t.get((size_t)K * 8));
+  auto *dnk = static_cast<int32_t *>(t.get((size_t)K * 4));
   int rc = GGS_OK;
-  if (!tmp.d_sum_pref || !tmp.d_sum_fn || !dsrc || !dou) rc = GGS_ERR_HIP;
+  if (!tmp.d_sum_pref || !tmp.d_sum_fn || !dsrc || !dou || !dnk) rc = GGS_ERR_HIP;
   else if (hipMemcpy(dsrc, x ? (const void *)x : (const void *)counts, kv * (x ? 8 : 4), hipMemcpyHostToDevice) != hipSuccess) rc = GGS_ERR_HIP;
+  else if (guess && hipMemcpy(tmp.d_sum_pref, guess, pref_bytes, hipMemcpyHostToDevice) != hipSuccess) rc = GGS_ERR_HIP;
   else {
-    if (x) launch_column_sum<double, false>(&tmp, static_cast<const double *>(dsrc), K, K, dou);
-    else launch_column_sum<int32_t, true>(&tmp, static_cast<const int32_t *>(dsrc), K, K, dou);
+    if (x) launch_column_sum<double, false>(&tmp, static_cast<const double *>(dsrc), K, K, dou, nullptr, guess != nullptr, true);
+    else launch_column_sum<int32_t, true>(&tmp, static_cast<const int32_t *>(dsrc), K, K, dou, dnk, guess != nullptr, true);
     if (hipGetLastError() != hipSuccess || hipMemcpy(out, dou, (size_t)K * 8, hipMemcpyDeviceToHost) != hipSuccess) rc = GGS_ERR_HIP;
+    else if (pref_out && hipMemcpy(pref_out, tmp.d_sum_pref, pref_bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = GGS_ERR_HIP;
+    else if (n_k_out && counts && hipMemcpy(n_k_out, dnk, (size_t)K * 4, hipMemcpyDeviceToHost) != hipSuccess) rc = GGS_ERR_HIP;
   }
   tmp.d_sum_pref = nullptr; tmp.d_sum_fn = nullptr;   // owned by t
   return rc;
+}
+
+int ggs_debug_column_sum(int32_t device_id, int32_t V, int32_t K, const double *x, const int32_t *counts, double beta, double *out) {
+  return ggs_debug_column_sum_guided(device_id, V, K, x, counts, beta, nullptr, out, nullptr, nullptr);
 }
 
 }  // extern "C"

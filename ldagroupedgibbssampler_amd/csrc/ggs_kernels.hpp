@@ -31,6 +31,7 @@
 // token: identical counts, no hot-word serialisation.
 #pragma once
 #include "ggs_device_math.hpp"
+#include "ggs_exact_sum.hpp"
 
 namespace ggs {
 
@@ -349,21 +350,32 @@ struct PhiGammaParams {
   double beta;         // sweep draw: shape = ((beta+n)/mag)*mag
   double prior_pm;     // initial draw: partition*magnitude = (1.0/V)*(V*beta)
   int32_t initial;
-  int32_t tile;        // elements per workgroup and round: a multiple of 256, <= kPhiTile
+  int32_t kc, ncg;     // a tile = one 64-row segment x kc <= kPhiCols adjacent topics (ncg = ceil(K / kc) column groups)
+  int32_t seg_begin, seg_end;   // the segments this launch draws (with an exchange the draw is cut in two, the first
+                                // half's all-gather running under the second half's draw)
   int32_t queue_cap;   // <= kPhiQueue (smaller only in tests)
+  // the segment functions of the gammas' column sums (ggs_exact_sum.hpp), computed by the workgroup that drew the tile;
+  // guess = the EXACT running magnitude sums [nseg + 1][K] (E Gamma(a) = a).  Null: not wanted.
+  const double *guess;
+  double *fn;          // [nseg][K][4]
 };
 
-// A workgroup takes tiles of up to 2048 consecutive elements: the straight-line first try for all of them, then the general
-// rejection loops for the elements it left over (queued in LDS, so that they fill whole waves; drawn on the spot when
-// the queue is full).
-constexpr int kPhiTile = 2048, kPhiQueue = 640;
+// ONE WAVE per workgroup takes tiles of one 64-row segment x kc <= kPhiCols adjacent topics: the straight-line first try
+// for all of the tile's elements, then the general rejection loops for the elements it left over (queued in LDS, so that
+// they fill the wave: ~14 % of 64 * 6 elements is one round; drawn on the spot when the queue is full).  Every lane
+// that has a gamma in hand also adds its quantised value to the tile's segment functions (integer LDS atomics,
+// ggs_exact_sum.hpp): the column sums of the gammas need no pass of their own over the matrix.  Single waves because
+// they balance: a topic slice of one rank in eight is 391 segments x 3 column groups per launch.
+constexpr int kPhiCols = 6, kPhiQueue = 128;
 
-__global__ __launch_bounds__(256) void phi_gamma_kernel(PhiGammaParams p) {
+__global__ __launch_bounds__(64) void phi_gamma_kernel(PhiGammaParams p) {
+  __builtin_amdgcn_s_setprio(1);       // ahead of the theta draw on the side stream (it has the whole Phi phase to finish), behind the chain's short kernels
   __shared__ uint16_t queue[kPhiQueue];
   __shared__ int32_t qn;
-  const int tid = threadIdx.x;
-  const int64_t n = (int64_t)p.V * p.K;
-  const int64_t tiles = (n + p.tile - 1) / p.tile;
+  __shared__ long long acc_lo[kPhiCols], acc_hi[kPhiCols];
+  __shared__ int32_t e_los[kPhiCols], aheads[kPhiCols], flag_s[kPhiCols];
+  const int lane = threadIdx.x;
+  const int64_t tiles = (int64_t)(p.seg_end - p.seg_begin) * p.ncg;
   auto shape_of = [&](int v, int k) {
     const int32_t cnt = p.n_wk[(size_t)v * p.cnt_pitch + k];
     if (p.initial) return (cnt == 0) ? p.prior_pm : p.prior_pm + (double)cnt;   // MarsagliaSparseDirichlet.java:37-41
@@ -377,16 +389,34 @@ __global__ __launch_bounds__(256) void phi_gamma_kernel(PhiGammaParams p) {
     if (rs.exhausted) atomicOr(p.status, ST_RNG_EXHAUSTED);
     return g;
   };
-  const uint32_t m_K = udiv_magic((uint32_t)p.K);
+  const uint32_t m_ncg = udiv_magic((uint32_t)p.ncg);
   for (int64_t tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
-    const int64_t base = tile * p.tile;
-    const int v0 = (int)(base / p.K), k0 = (int)(base - (int64_t)v0 * p.K);   // once per tile; inside it (k0 + j) * K < 2^32
-    if (tid == 0) qn = 0;
+    const int si = udiv_small((int)tile, m_ncg), cg = (int)tile - si * p.ncg;     // tiles < 2^31 / ncg (V < 2^31)
+    const int seg = p.seg_begin + si, v0 = seg * 64, kb = cg * p.kc, kw = min(p.kc, p.K - kb);
+    const int rows = min(64, p.V - v0), n = rows * kw;
+    const uint32_t m_kw = udiv_magic((uint32_t)kw);
+    __syncthreads();                   // the previous tile's composition has read the accumulators
+    if (lane < kw) {
+      SegCand c{kSegNoGuess, true};
+      if (p.guess) c = seg_candidates(p.guess[(size_t)seg * p.K + kb + lane], p.guess[(size_t)(seg + 1) * p.K + kb + lane]);
+      e_los[lane] = c.e_lo; aheads[lane] = c.ahead ? 1 : 0; acc_lo[lane] = 0; acc_hi[lane] = 0; flag_s[lane] = 0;
+    }
+    if (lane == 0) qn = 0;
     __syncthreads();
+    auto emit = [&](int v, int c, double g) {                            // the gamma to memory, its quantised value to the segment functions
+      p.phiT[(size_t)v * p.Kp + kb + c] = g;
+      const int e_lo = e_los[c];
+      if (e_lo == kSegNoGuess) return;
+      long long q_lo, q_hi;
+      int fl;
+      seg_quantise(g, e_lo, q_lo, q_hi, fl);
+      if (q_lo) atomicAdd(reinterpret_cast<unsigned long long *>(&acc_lo[c]), (unsigned long long)q_lo);
+      if (q_hi) atomicAdd(reinterpret_cast<unsigned long long *>(&acc_hi[c]), (unsigned long long)q_hi);
+      if (fl) atomicOr(&flag_s[c], fl);
+    };
 #pragma unroll 1
-    for (int j = tid; j < p.tile; j += 256) {
-      if (base + j >= n) break;
-      const int dv = udiv_small(k0 + j, m_K), v = v0 + dv, k = k0 + j - dv * p.K;
+    for (int j = lane; j < n; j += 64) {
+      const int dv = udiv_small(j, m_kw), v = v0 + dv, c = j - dv * kw, k = kb + c;
       const double shape = shape_of(v, k);
       double g;
       if (shape > 0) {
@@ -399,14 +429,16 @@ __global__ __launch_bounds__(256) void phi_gamma_kernel(PhiGammaParams p) {
         g = __builtin_nan("");
         atomicOr(p.status, ST_BAD_SHAPE);
       }
-      p.phiT[(size_t)v * p.Kp + k] = g;
+      emit(v, c, g);
     }
     __syncthreads();
-    for (int q = tid, m = min(qn, p.queue_cap); q < m; q += 256) {
-      const int j = queue[q], dv = udiv_small(k0 + j, m_K), v = v0 + dv, k = k0 + j - dv * p.K;
-      p.phiT[(size_t)v * p.Kp + k] = draw_general(v, k, shape_of(v, k));
+    for (int q = lane, m = min(qn, p.queue_cap); q < m; q += 64) {
+      const int j = queue[q], dv = udiv_small(j, m_kw), v = v0 + dv, c = j - dv * kw;
+      emit(v, c, draw_general(v, kb + c, shape_of(v, kb + c)));
     }
     __syncthreads();
+    if (p.guess && lane < kw)
+      seg_compose(SegCand{e_los[lane], aheads[lane] != 0}, acc_lo[lane], acc_hi[lane], flag_s[lane], 0.0, p.fn + ((size_t)seg * p.K + kb + lane) * 4);
   }
 }
 
@@ -429,17 +461,34 @@ __global__ __launch_bounds__(256) void phi_normalise_kernel(double *phiT, const 
 }
 
 // ---- exchange layout <-> device layout (one GPU of several; see include/ggs_hip.h, "multi-GPU") ----
-// phi_all [nranks][V][Ksm] (the all-gathered slices) -> phiT [V][Kp]; the running phiMean += of GGS:193-197 rides along
-// (the value added is the normalised, clamped phi -- the same double the one-GPU normalise kernel adds).
-__global__ __launch_bounds__(256) void phi_unslice_kernel(const double *phi_all, const int64_t *koff, int32_t Ksm, double *phiT, int32_t K,
-                                                          int32_t Kp, int32_t V, double *phi_mean /* [V][K] or null */) {
-  const int64_t n = (int64_t)V * K;
+// The all-gathered UNNORMALISED gamma slices -> phiT [V][Kp], normalised on the way: rank r's slice arrives in two
+// halves, all0 [nranks][c0] = its rows below v_split ([v][Ksm]) and all1 [nranks][c1] = the rows from v_split on followed
+// by its Ksm column sums.  The division and the clamp are those of phi_normalise_kernel (ParallelDirichlet.java:60-66),
+// on the same operands: the same bits.  The running phiMean += of GGS:193-197 rides along.
+struct PhiRepackParams {
+  const double *all0, *all1;
+  const int32_t *krank, *kcol;   // [K] owner rank of topic k, its column in that rank's slice
+  double *phiT, *phi_mean;       // phi_mean [V][K] or null
+  int64_t c0, c1;
+  int32_t K, Kp, V, Ksm, v_split;
+};
+__global__ __launch_bounds__(256) void phi_repack_kernel(PhiRepackParams p) {
+  __builtin_amdgcn_s_setprio(3);
+  const int64_t n = (int64_t)p.V * p.K;
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  const int64_t tot_off = (int64_t)(p.V - p.v_split) * p.Ksm;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-    const int v = (int)(i / K), k = (int)(i - (int64_t)v * K);
-    const double x = phi_all[koff[k] + (int64_t)v * Ksm];
-    phiT[(size_t)v * Kp + k] = x;
-    if (phi_mean) phi_mean[i] += x;
+    const int v = (int)(i / p.K), k = (int)(i - (int64_t)v * p.K);
+    const int r = p.krank[k], j = p.kcol[k];
+    const double *h1 = p.all1 + (int64_t)r * p.c1;
+    double x = v < p.v_split ? p.all0[(int64_t)r * p.c0 + (int64_t)v * p.Ksm + j] : h1[(int64_t)(v - p.v_split) * p.Ksm + j];
+    const double s = h1[tot_off + j];
+    if (s != 0) {
+      x = x / s;
+      if (x <= 0) x = kJavaMinValue;
+    }
+    p.phiT[(size_t)v * p.Kp + k] = x;
+    if (p.phi_mean) p.phi_mean[i] += x;
   }
 }
 // cnt_all [nranks][V][Ksm] (the all-gathered count slices) -> n_wk [V][K]

@@ -388,3 +388,33 @@ def debug_column_sum(x=None, counts=None, beta=0.0, device_id=0):
     if rc:
         raise GGSError(rc, "ggs_debug_column_sum")
     return out
+
+
+def debug_column_sum_guided(x=None, counts=None, beta=0.0, guess=None, device_id=0):
+    """The same with the caller's guess [ceil(V/64) + 1][K] of the running sums at the segment starts (None: the kernels
+    make their own).  Returns (sums [K], the exact running sums the walk left [ceil(V/64) + 1][K], tokensPerTopic [K] or None)."""
+    L = _lib.load()
+    if (x is None) == (counts is None):
+        raise ValueError("exactly one of x / counts")
+    if x is not None:
+        x = np.ascontiguousarray(x, np.float64)
+        V, K = x.shape
+        xp, cp = _dp(x), None
+    else:
+        counts = np.ascontiguousarray(counts, np.int32)
+        V, K = counts.shape
+        xp, cp = None, _ip(counts)
+    nseg = (V + 63) // 64
+    gp = None
+    if guess is not None:
+        guess = np.ascontiguousarray(guess, np.float64)
+        if guess.shape != (nseg + 1, K):
+            raise ValueError("guess must be [ceil(V/64) + 1][K]")
+        gp = _dp(guess)
+    out = np.empty(K, np.float64)
+    pref = np.empty((nseg + 1, K), np.float64)
+    n_k = np.empty(K, np.int32)
+    rc = L.ggs_debug_column_sum_guided(device_id, V, K, xp, cp, float(beta), gp, _dp(out), _dp(pref), _ip(n_k) if counts is not None else None)
+    if rc:
+        raise GGSError(rc, "ggs_debug_column_sum_guided")
+    return out, pref, (n_k if counts is not None else None)

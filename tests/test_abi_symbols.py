@@ -53,9 +53,9 @@ def test_struct_layouts_match_header():
 #include <stddef.h>
 #include "ggs_hip.h"
 int main(void) {
-  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ggs_config), offsetof(ggs_config, alpha), offsetof(ggs_config, beta),
+  printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(ggs_config), offsetof(ggs_config, alpha), offsetof(ggs_config, beta),
          offsetof(ggs_config, seed), offsetof(ggs_config, flags), sizeof(ggs_timings), offsetof(ggs_timings, sweeps),
-         offsetof(ggs_timings, exchange_ms), sizeof(ggs_exchange_ops), offsetof(ggs_exchange_ops, ctx), offsetof(ggs_exchange_ops, all_gather_i32));
+         offsetof(ggs_timings, exchange_ms), offsetof(ggs_timings, exchange_ag_ms), sizeof(ggs_exchange_ops), offsetof(ggs_exchange_ops, ctx), offsetof(ggs_exchange_ops, all_gather_i32));
   return 0;
 }'''
     exe = os.path.join(ROOT, "tests", ".abi_layout_probe")
@@ -67,7 +67,7 @@ int main(void) {
             os.remove(exe)
     cfg, tm, ops = _lib.GGSConfig, _lib.GGSTimings, _lib.GGSExchangeOps
     assert got == [ctypes.sizeof(cfg), cfg.alpha.offset, cfg.beta.offset, cfg.seed.offset, cfg.flags.offset,
-                   ctypes.sizeof(tm), tm.sweeps.offset, tm.exchange_ms.offset, ctypes.sizeof(ops), ops.ctx.offset, ops.all_gather_i32.offset]
+                   ctypes.sizeof(tm), tm.sweeps.offset, tm.exchange_ms.offset, tm.exchange_ag_ms.offset, ctypes.sizeof(ops), ops.ctx.offset, ops.all_gather_i32.offset]
 
 
 def test_no_gpu_means_loud_failure_not_fallback():

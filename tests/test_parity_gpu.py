@@ -520,6 +520,60 @@ def test_exact_parallel_column_sum_adversarial(native):
 
 
 @pytest.mark.gpu
+def test_column_sum_guess_never_decides_the_result(native):
+    """The guided form of ggs_exact_sum.hpp: the magnitude sum of sweep t is guided by sweep t-1's exact running sums, the
+    gammas' sum by the magnitudes'.  Whatever the guess -- exact, stale by 30 %, a thousand times off, zero, NaN, negative,
+    decreasing -- the sums are the sequential ones; the walk leaves the exact running sums behind, and tokensPerTopic."""
+    rng = np.random.default_rng(23)
+    V, K = 20000, 11
+    n = ((rng.random((V, K)) < 0.2) * rng.integers(1, 60, (V, K))).astype(np.int32)
+    n[:, 3] = 0                                                          # a topic without tokens: s grows by beta alone
+    beta = 0.01
+    mag_addends = beta + n.astype(np.float64)
+    gam = rng.gamma(mag_addends)
+    gam[rng.integers(0, V, 40), rng.integers(0, K, 40)] = 0.0
+    nseg = (V + 63) // 64
+
+    def running(x):                                                      # sequential running sums at the segment starts
+        out = np.zeros((nseg + 1, x.shape[1]))
+        s = np.zeros(x.shape[1])
+        for v in range(x.shape[0]):
+            if v % 64 == 0:
+                out[v // 64] = s
+            s = s + x[v]
+        out[nseg] = s
+        return out
+
+    run_mag, run_gam = running(mag_addends), running(gam)
+    guesses = {"none (cold path)": None, "exact": run_mag, "30 % low": 0.7 * run_mag, "35 % high": 1.35 * run_mag, "x1000": 1000.0 * run_mag + 1.0,
+               "zero": np.zeros_like(run_mag), "nan": np.full_like(run_mag, np.nan), "negative": -run_mag, "decreasing": run_mag[::-1].copy(),
+               "inf": np.full_like(run_mag, np.inf), "another topic's": np.roll(run_mag, 3, axis=1)}
+    for tag, g in guesses.items():
+        out, pref, n_k = native.debug_column_sum_guided(counts=n, beta=beta, guess=g)
+        assert_bit_equal(out, run_mag[nseg], "magnitude, guess " + tag)
+        assert_bit_equal(pref, run_mag, "running magnitude sums, guess " + tag)
+        assert np.array_equal(n_k, n.sum(axis=0)), tag
+        out, pref, _ = native.debug_column_sum_guided(x=gam, guess=g)     # the magnitudes' sums guide the gammas'
+        assert_bit_equal(out, run_gam[nseg], "gamma sum, guess " + tag)
+        assert_bit_equal(pref, run_gam, "running gamma sums, guess " + tag)
+    # ties and forced crossings under an exact and a stale guess
+    x = rng.integers(0, 8, (5000, 16)) * 2.0 ** -40 + (rng.random((5000, 16)) < 0.2) * rng.integers(0, 3, (5000, 16)) * 2.0 ** -39
+    x[0] = 2.0 ** 13 + rng.integers(0, 1000, 16) * 2.0 ** -39
+    x[rng.integers(1, 5000, 20), rng.integers(0, 16, 20)] = 2.0 ** 13
+    want = _sequential_column_sum(x)
+    nsx = (5000 + 63) // 64
+    exact = np.zeros((nsx + 1, 16))
+    s = np.zeros(16)
+    for v in range(5000):
+        if v % 64 == 0:
+            exact[v // 64] = s
+        s = s + x[v]
+    exact[nsx] = s
+    for tag, g in (("exact", exact), ("stale", exact * 0.9), ("none", None)):
+        assert_bit_equal(native.debug_column_sum_guided(x=x, guess=g)[0], want, "ties, guess " + tag)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("beta", [0.01, 0.5])
 def test_long_vocabulary(native, oracle, beta):
     """V = 30000 (469 segments, 8 groups per topic in the normalisers) with few tokens: sparse n_wk, mostly tiny gammas."""

@@ -141,9 +141,9 @@ __global__ __launch_bounds__(64) void sum_prefix_kernel(SumParams p) {
 
 // ---- the segment function of one (segment, topic), element-parallel ----
 // Which lanes look at which of the 64 addends does not matter: D1(e) = u * sum of R_u(x) is a sum of INTEGERS
-// (x / u rounded to nearest), accumulated with integer atomics in LDS by whatever lanes hold the addends -- the lanes
+// (x / u rounded to nearest), accumulated with atomic adds in LDS by whatever lanes hold the addends -- the lanes
 // that have just drawn the gammas (phi_gamma_kernel), or the lanes of a streaming pass over the counts
-// (sum_segfn_kernel).  Per (segment, topic): the candidate binades from the guess, two int64 accumulators, flags.
+// (sum_segfn_kernel).  Per (segment, topic): the candidate binades from the guess, two accumulators, flags.
 constexpr int kSegNoGuess = -100000;       // e_lo marker: no usable guess, the walk takes the raw rows
 constexpr int kSegTieLo = 1, kSegTieHi = 2, kSegBad = 4;
 
@@ -161,37 +161,40 @@ __device__ __forceinline__ SegCand seg_candidates(double g0, double g1) {
   const bool lower_half = e1 == e0 && (hi32(g0) & 0x000fffff) < 0x6a09e;    // mantissa of sqrt(2) = 1.6a09e...
   return SegCand{lower_half ? e0 - 1 : e0, binade_of(g0 * (1.0 - 0x1p-13)) != binade_of(g1 * (1.0 + 0x1p-13))};
 }
-// R_u(x) / u for both candidates as integers; flags what makes a candidate unusable
-__device__ __forceinline__ void seg_quantise(double x, int e_lo, long long &q_lo, long long &q_hi, int &flags) {
-  q_lo = q_hi = 0; flags = 0;
+// R_u(x) / u for both candidates (integer-valued doubles); flags what makes a candidate unusable
+__device__ __forceinline__ void seg_quantise(double x, int e_lo, double &q_lo, double &q_hi, int &flags) {
+  q_lo = q_hi = 0.0; flags = 0;
   if (!(x >= 0.0)) { flags = kSegBad; return; }                 // negative or NaN: the monotonicity argument needs x >= 0
   const double y_lo = x * mk((1023 + 52 - e_lo) << 20, 0);      // exact (power of two): x / u
   const double y_hi = y_lo * 0.5;                                // ... for the binade above (exact: y_lo is far from subnormal, or 0)
-  if (y_lo < 0x1p53) {
-    const double f = floor(y_lo), r = y_lo - f;                  // exact
+  {
+    const double f = floor(y_lo), r = y_lo - f;                  // exact (an integer for y_lo >= 2^52: r = 0)
     if (r == 0.5) flags |= kSegTieLo;                            // a tie rounds to EVEN, which depends on the running sum
-    q_lo = (long long)(r > 0.5 ? f + 1.0 : f);
-  } else {
-    flags |= kSegTieLo;                                          // x >= 2^(e+1): such a step is never accepted anyway
+    q_lo = r > 0.5 ? f + 1.0 : f;
   }
-  if (y_hi < 0x1p53) {
+  {
     const double f = floor(y_hi), r = y_hi - f;
     if (r == 0.5) flags |= kSegTieHi;
-    q_hi = (long long)(r > 0.5 ? f + 1.0 : f);
-  } else {
-    flags |= kSegTieHi;
+    q_hi = r > 0.5 ? f + 1.0 : f;
   }
 }
+// The accumulators are doubles in LDS, added to with the LDS unit's fp64 atomic add: every addend is an integer, so as
+// long as the sum stays below 2^53 every add is exact and the order the lanes arrive in does not matter; a sum that
+// reaches 2^53 (it may have rounded on the way, but never back below 2^53: adds of non-negative values are monotone)
+// gives D1 >= 2^(e+1), which the walk's binade test rejects.
+__device__ __forceinline__ void seg_accumulate(double *acc_lo, double *acc_hi, int32_t *flag, double q_lo, double q_hi, int fl) {
+  if (q_lo != 0.0) __hip_atomic_fetch_add(acc_lo, q_lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (q_hi != 0.0) __hip_atomic_fetch_add(acc_hi, q_hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  if (fl) atomicOr(flag, fl);
+}
 // the four doubles the walk reads: e_lo (+ 0.5: fetch ahead), D1(e_lo), D1(e_lo + 1) (< 0: unusable), column count
-__device__ __forceinline__ void seg_compose(SegCand c, long long a_lo, long long a_hi, int flags, double count, double *fn) {
+__device__ __forceinline__ void seg_compose(SegCand c, double a_lo, double a_hi, int flags, double count, double *fn) {
   fn[3] = count;
   if (c.e_lo == kSegNoGuess || (flags & kSegBad)) { fn[0] = kSumDirty; fn[1] = fn[2] = -1.0; return; }
   // rows ahead also when a candidate is unusable (a tie: typically one addend as large as the running sum itself)
   fn[0] = (double)c.e_lo + ((c.ahead || (flags & (kSegTieLo | kSegTieHi))) ? 0.5 : 0.0);
-  // 64 addends below 2^53 each: the integer sum cannot wrap; a sum of 2^53 or more converts to a double >= 2^53 (the
-  // conversion rounds monotonically), i.e. D1 >= 2^(e+1): rejected by the walk's binade test
-  fn[1] = (flags & kSegTieLo) ? -1.0 : (double)a_lo * mk((1023 + c.e_lo - 52) << 20, 0);
-  fn[2] = (flags & kSegTieHi) ? -1.0 : (double)a_hi * mk((1023 + c.e_lo - 51) << 20, 0);
+  fn[1] = (flags & kSegTieLo) ? -1.0 : a_lo * mk((1023 + c.e_lo - 52) << 20, 0);
+  fn[2] = (flags & kSegTieHi) ? -1.0 : a_hi * mk((1023 + c.e_lo - 51) << 20, 0);
 }
 
 // A workgroup takes one 64-row segment x up to kSegFnCols adjacent topics and streams the cells with all lanes.
@@ -199,7 +202,7 @@ constexpr int kSegFnCols = 32;
 template <typename T, bool MAGNITUDE>
 __global__ __launch_bounds__(256) void sum_segfn_kernel(SumParams p) {
   chain_priority();
-  __shared__ long long acc_lo[kSegFnCols], acc_hi[kSegFnCols];
+  __shared__ double acc_lo[kSegFnCols], acc_hi[kSegFnCols];
   __shared__ int32_t e_los[kSegFnCols], aheads[kSegFnCols], flag_s[kSegFnCols], cnt_s[kSegFnCols];
   const int tid = threadIdx.x, seg = blockIdx.x, kb = blockIdx.y * kSegFnCols, kw = min(kSegFnCols, p.K - kb);
   const int v0 = seg * kSumSegRows, rows = min(kSumSegRows, p.V - v0);
@@ -216,12 +219,10 @@ __global__ __launch_bounds__(256) void sum_segfn_kernel(SumParams p) {
     if (MAGNITUDE && raw) atomicAdd(&cnt_s[c], (int32_t)raw);
     const int e_lo = e_los[c];
     if (e_lo == kSegNoGuess) continue;
-    long long q_lo, q_hi;
+    double q_lo, q_hi;
     int fl;
     seg_quantise(MAGNITUDE ? (p.beta + (double)raw) : (double)raw, e_lo, q_lo, q_hi, fl);   // GGS:188: beta + count, one rounding
-    if (q_lo) atomicAdd(reinterpret_cast<unsigned long long *>(&acc_lo[c]), (unsigned long long)q_lo);
-    if (q_hi) atomicAdd(reinterpret_cast<unsigned long long *>(&acc_hi[c]), (unsigned long long)q_hi);
-    if (fl) atomicOr(&flag_s[c], fl);
+    seg_accumulate(&acc_lo[c], &acc_hi[c], &flag_s[c], q_lo, q_hi, fl);
   }
   __syncthreads();
   if (tid < kw)

@@ -363,7 +363,7 @@ struct PhiGammaParams {
 // ONE WAVE per workgroup takes tiles of one 64-row segment x kc <= kPhiCols adjacent topics: the straight-line first try
 // for all of the tile's elements, then the general rejection loops for the elements it left over (queued in LDS, so that
 // they fill the wave: ~14 % of 64 * 6 elements is one round; drawn on the spot when the queue is full).  Every lane
-// that has a gamma in hand also adds its quantised value to the tile's segment functions (integer LDS atomics,
+// that has a gamma in hand also adds its quantised value to the tile's segment functions (LDS atomic adds of integers,
 // ggs_exact_sum.hpp): the column sums of the gammas need no pass of their own over the matrix.  Single waves because
 // they balance: a topic slice of one rank in eight is 391 segments x 3 column groups per launch.
 constexpr int kPhiCols = 6, kPhiQueue = 128;
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(64) void phi_gamma_kernel(PhiGammaParams p) {
   __builtin_amdgcn_s_setprio(1);       // ahead of the theta draw on the side stream (it has the whole Phi phase to finish), behind the chain's short kernels
   __shared__ uint16_t queue[kPhiQueue];
   __shared__ int32_t qn;
-  __shared__ long long acc_lo[kPhiCols], acc_hi[kPhiCols];
+  __shared__ double acc_lo[kPhiCols], acc_hi[kPhiCols];
   __shared__ int32_t e_los[kPhiCols], aheads[kPhiCols], flag_s[kPhiCols];
   const int lane = threadIdx.x;
   const int64_t tiles = (int64_t)(p.seg_end - p.seg_begin) * p.ncg;
@@ -407,12 +407,10 @@ __global__ __launch_bounds__(64) void phi_gamma_kernel(PhiGammaParams p) {
       p.phiT[(size_t)v * p.Kp + kb + c] = g;
       const int e_lo = e_los[c];
       if (e_lo == kSegNoGuess) return;
-      long long q_lo, q_hi;
+      double q_lo, q_hi;
       int fl;
       seg_quantise(g, e_lo, q_lo, q_hi, fl);
-      if (q_lo) atomicAdd(reinterpret_cast<unsigned long long *>(&acc_lo[c]), (unsigned long long)q_lo);
-      if (q_hi) atomicAdd(reinterpret_cast<unsigned long long *>(&acc_hi[c]), (unsigned long long)q_hi);
-      if (fl) atomicOr(&flag_s[c], fl);
+      seg_accumulate(&acc_lo[c], &acc_hi[c], &flag_s[c], q_lo, q_hi, fl);
     };
 #pragma unroll 1
     for (int j = lane; j < n; j += 64) {

@@ -66,11 +66,13 @@ enum {
                                      ADLDA is, and what a doc-sharded run exchanges is again the count buffer);
                                      ggs_collapsed_serial_sweep runs the reference's own serial chain.  ggs_get_phi returns
                                      the point estimate (beta + n_wk)/(betaSum + n_k); ggs_get_theta, ggs_log_posterior and
-                                     ggs_sample_z_given_phi do not apply.  Same K and document-length limits as pcgs. */
+                                     ggs_sample_z_given_phi do not apply.  K up to 4096, any document length (as pcgs). */
   GGS_FLAG_PCGS = 1 << 2          /* scheme=pcgs (LDAPartiallyCollapsedGibbsSampler): the z step is UPLDA:1466-1544,
                                      score = (n_dk + alpha_k)*phi[k][w], sequential inside a document; no theta draw;
-                                     counts, Phi draw and exchange exactly as for ggs.  Any K up to
-                                     ~450 (the per-document counts live in LDS) and documents shorter than 32768. */
+                                     counts, Phi draw and exchange exactly as for ggs.  Any K up to 4096 and any
+                                     document length: up to 192 topics one LANE owns a document (64 documents per
+                                     wave, int16 counts in LDS); above that, or when a document has 32768 tokens or
+                                     more, one WAVE owns a document (int32 counts, the topics spread over the lanes). */
 };
 
 /* RNG stream addressing.  The reference draws from ThreadLocalRandom and a

@@ -17,6 +17,7 @@
 #include "ggs_z_stream.hpp"
 #include "ggs_exact_sum.hpp"
 #include "ggs_z_pcgs.hpp"
+#include "ggs_z_pcgs_wave.hpp"
 #include "ggs_z_collapsed.hpp"
 #include "ggs_loglik.hpp"
 #include "ggs_heldout.hpp"
@@ -74,6 +75,9 @@ struct ggs_handle {
   int32_t pcgs_lds = 0, pcgs_waves_per_cu = 0, max_doc_len = 0;
   int64_t pcgs_order_len = 0;                          // entries of d_order (documents, or the padded two-round list)
   bool pcgs_sliced = false;                            // K <= 192: scores in registers, one pass over the rows per step
+  bool pcgs_wave = false;                              // wide rows or long documents: one wave per document (ggs_z_pcgs_wave.hpp)
+  bool pcgs_wave_forced = false;                       // ... because of K; otherwise decided per corpus (a document of 32 768 tokens or more)
+  int32_t pcgs_wave_nb = 0, pcgs_wave_lds = 0, pcgs_wave_waves_per_cu = 0;
   bool collapsed = false;                              // scheme=collapsed: the pcgs machinery over psi = (beta + n_wk)/(betaSum + n_k)
   uint64_t *d_lcg = nullptr;                           // ggs_collapsed_serial_sweep: the java.util.Random state
   bool lcg_ready = false;
@@ -485,6 +489,18 @@ const void *collapsed_kernel_for(int K) {
   }
 }
 
+// pcgs_wave_kernel<NB, COLLAPSED> for NB = blocks of 128 topics, rounded up to a power of two
+const void *pcgs_wave_kernel_for(int nb, bool collapsed) {
+#define GGS_WK(N) if (nb <= N) return collapsed ? reinterpret_cast<const void *>(pcgs_wave_kernel<N, true>) : reinterpret_cast<const void *>(pcgs_wave_kernel<N, false>);
+  GGS_WK(1) GGS_WK(2) GGS_WK(4) GGS_WK(8) GGS_WK(16)
+#undef GGS_WK
+  return collapsed ? reinterpret_cast<const void *>(pcgs_wave_kernel<32, true>) : reinterpret_cast<const void *>(pcgs_wave_kernel<32, false>);
+}
+constexpr int kPcgsWaveMaxTopics = 32 * 128;          // 4096: two rows of K/64 doubles per lane in registers
+// Above the score-register kernels' 192 topics the wave-per-document kernel takes over.  Measured on the benchmark corpus
+// (z step, ms): K = 160: 4.2 lane-per-document / 6.9 wave-per-document, 192: 6.0 / 7.0, 256: 16.5 (two-pass) / 7.3, 320: 20.1 / 10.5.
+constexpr int kPcgsWaveFromTopics = kSlicedMaxTopics;
+
 int launch_pcgs_z(ggs_handle *h) {
   if (h->N == 0) return GGS_OK;
   PcgsParams pp{};
@@ -494,6 +510,20 @@ int launch_pcgs_z(ggs_handle *h) {
   pp.K = h->K; pp.Kp = h->Kp;
   const int64_t groups = (h->pcgs_order_len + 63) / 64;
   const dim3 grid((unsigned)std::min<int64_t>(groups, (int64_t)h->num_cus * h->pcgs_waves_per_cu)), block(64);
+  if (h->pcgs_wave) {
+    // one wave per document: wide topic rows, or a document the lane-per-document kernels' int16 counts cannot hold
+    if (h->collapsed) {
+      int rc = launch_magnitude(h);
+      if (rc) return rc;
+      pp.n_wk = h->d_n_wk; pp.n_k = h->d_n_k; pp.beta = h->beta; pp.beta_sum = h->beta * (double)h->V;
+      hipLaunchKernelGGL(psi_kernel, dim3(grid_for((int64_t)h->K * h->V, 256, 2)), dim3(256), 0, h->stream, h->d_n_wk, h->d_n_k, pp.beta, pp.beta_sum, h->d_phiT,
+                         h->K, h->Kp, h->V);
+    }
+    const dim3 wgrid((unsigned)std::min<int64_t>(h->pcgs_order_len, (int64_t)h->num_cus * h->pcgs_wave_waves_per_cu));
+    void *args[] = {&pp, &h->margin_scale};
+    HIP_TRY(h, hipLaunchKernel(pcgs_wave_kernel_for(h->pcgs_wave_nb, h->collapsed), wgrid, block, args, (size_t)h->pcgs_wave_lds, h->stream));
+    return GGS_OK;
+  }
   if (h->collapsed) {
     // the sweep-start ratios (beta + n_wk)/(betaSum + n_k) of the corpus-wide counts, then the pcgs loop over them
     int rc = launch_magnitude(h);
@@ -925,7 +955,8 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       h->z_two_pass = mode == 3;
       if (h->z_sliced) h->z_stream = false;
     }
-    if (const char *e = std::getenv("GGS_DEBUG_MARGIN")) h->margin_scale = std::atof(e);
+    // only values above 1 are meaningful (they force the exact replay in tests); anything below would void the proof
+    if (const char *e = std::getenv("GGS_DEBUG_MARGIN")) h->margin_scale = std::max(1.0, std::atof(e));
     if (h->z_stream) {
       // 64-token chunks, a 2-slot slice ring + the theta row zero-padded to whole slices (one-pass kernel: to whole
       // checkpoint groups, plus a checkpoint per group and lane); no score registers, so 8 waves per CU fit the
@@ -1056,6 +1087,21 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       (h->d_phi_mean && hipMemset(h->d_phi_mean, 0, sizeof(double) * kv) != hipSuccess))
     return bail(GGS_ERR_HIP);
   if (h->flags & GGS_FLAG_PCGS) {
+    // the wave-per-document kernel: any K up to 4096, any document length
+    if (h->K <= kPcgsWaveMaxTopics) {
+      int nb = 1;
+      while (nb * 128 < h->Kp) nb *= 2;
+      h->pcgs_wave_nb = nb;
+      h->pcgs_wave_lds = nb * 128 * 20;
+      // waves per CU: what LDS allows, and what the kernel's registers allow (8, 8, 7, 4, 2, 1 waves per SIMD for NB = 1 .. 32)
+      const int per_simd = nb <= 2 ? 8 : nb == 4 ? 7 : nb == 8 ? 4 : nb == 16 ? 2 : 1;
+      h->pcgs_wave_waves_per_cu = std::max(1, std::min(4 * per_simd, (kMaxLdsBytes - 2048) / ((h->pcgs_wave_lds + 2047) / 2048 * 2048)));
+    }
+    h->pcgs_wave_forced = h->K > kPcgsWaveFromTopics;
+    if (const char *e = std::getenv("GGS_DEBUG_PCGS_WAVE")) h->pcgs_wave_forced = std::atoi(e) != 0;
+    if (h->pcgs_wave_forced && !h->pcgs_wave_nb) return bail(GGS_ERR_UNSUPPORTED);   // more than 4096 topics
+    if (h->pcgs_wave_nb && hipFuncSetAttribute(pcgs_wave_kernel_for(h->pcgs_wave_nb, h->collapsed), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess)
+      return bail(GGS_ERR_HIP);
     // pcgs_z_kernel: slice ring + alpha row + int16 [KT][64] document counts per single-wave workgroup
     const int ns = std::max(kPcgsRingSlots - 1, (h->K + kSliceTopics - 1) / kSliceTopics), kt = ns * kSliceTopics;
     h->pcgs_sliced = h->K <= kSlicedMaxTopics;
@@ -1066,9 +1112,10 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     } else {
       h->pcgs_lds = kPcgsRingSlots * kSliceBytes + kt * 8 + kt * 128;
     }
-    if (h->pcgs_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);
+    if (h->pcgs_lds > kMaxLdsBytes && !h->pcgs_wave_forced) return bail(GGS_ERR_UNSUPPORTED);
     h->pcgs_waves_per_cu = std::max(1, std::min(8, (kMaxLdsBytes - 2048) / ((h->pcgs_lds + 2047) / 2048 * 2048)));   // never a CU filled to the last granule (see z_waves_per_cu)
-    if (hipFuncSetAttribute(h->pcgs_sliced ? (h->collapsed ? collapsed_kernel_for(h->K) : pcgs_kernel_for(h->K))
+    if (!h->pcgs_wave_forced &&
+        hipFuncSetAttribute(h->pcgs_sliced ? (h->collapsed ? collapsed_kernel_for(h->K) : pcgs_kernel_for(h->K))
                                            : h->collapsed ? reinterpret_cast<const void *>(pcgs_z_kernel<true>) : reinterpret_cast<const void *>(pcgs_z_kernel<false>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess)
       return bail(GGS_ERR_HIP);
@@ -1226,7 +1273,9 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
     std::vector<int32_t> order((size_t)D);
     int64_t longest = 0;
     for (int64_t d = 0; d < D; ++d) { order[(size_t)d] = (int32_t)d; longest = std::max(longest, doc_ptr[d + 1] - doc_ptr[d]); }
-    if (longest > kPcgsMaxDocLen) return set_err(h, GGS_ERR_UNSUPPORTED, "scheme=pcgs keeps per-document counts as int16: documents must be shorter than 32768 tokens");
+    // the lane-per-document kernels keep the counts as int16: a longer document sends the corpus to the wave-per-document kernel
+    h->pcgs_wave = h->pcgs_wave_forced || longest > kPcgsMaxDocLen;
+    if (h->pcgs_wave && !h->pcgs_wave_nb) return set_err(h, GGS_ERR_UNSUPPORTED, "scheme=pcgs: a document of 32768 tokens or more with more than 4096 topics");
     std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return doc_ptr[a + 1] - doc_ptr[a] > doc_ptr[b + 1] - doc_ptr[b]; });
     // A wave takes the groups w, w + W, ... of this list (W = the resident waves).  With between one and two rounds of
     // groups (the benchmark corpus: 1 563 groups for 1 024 waves) the plain order would give the waves of the 539

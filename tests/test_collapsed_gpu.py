@@ -90,6 +90,21 @@ def test_parallel_schedule_matches_its_restatement(native, oracle, cats, K, alph
     assert e.value.code == native.ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("K,force", [(500, False), (1024, False), (2049, False), (20, True), (130, True)])
+def test_parallel_schedule_wide_topic_rows(native, oracle, monkeypatch, K, force):
+    """The count-form conditional (MSLDA:158-226) in the parallel schedule above 320 topics, and with a document of more
+    than 32 767 tokens: the wave-per-document kernel (ggs_z_pcgs_wave.hpp) over psi, the own-topic entry recomputed."""
+    if force:
+        monkeypatch.setenv("GGS_DEBUG_PCGS_WAVE", "1")
+    c = random_corpus(120, 400, 80, seed=K, empty_every=7)
+    g, o = pair(native, oracle, c, K, 0.1, 0.01, 4 + K, K)
+    monkeypatch.delenv("GGS_DEBUG_PCGS_WAVE", raising=False)
+    for it in range(2):
+        g.sweep(1)
+        o.collapsed_parallel_sweep(1)
+        same_counts(g, o, "parallel wide K=%d sweep %d" % (K, it + 1))
+
+
 def _shard_rank(native, tr, rank, world, whole, K, zseed, sweeps, out, errs):
     import torch
     from ldagroupedgibbssampler_amd.sharded import _DevPtr, java_lcg_initial_z

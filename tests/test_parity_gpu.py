@@ -383,14 +383,13 @@ def test_error_behaviour(native):
         g.sweep(1)
     assert e.value.code == native.ERR_INVALID_TOPIC
     assert "Topic sampled is invalid" in str(e.value)
-    # scheme=pcgs limits: the per-document counts live in LDS as int16
+    # scheme=pcgs limits: 4096 topics (two phiT rows of K/64 doubles per lane live in registers); no limit on the document length
     with pytest.raises(native.GGSError) as e:
-        native.GGSHandle(1100, 10, 0.1, 0.1, 1, flags=native.FLAG_PCGS)
+        native.GGSHandle(4097, 10, 0.1, 0.1, 1, flags=native.FLAG_PCGS)
     assert e.value.code == native.ERR_UNSUPPORTED
+    native.GGSHandle(1100, 10, 0.1, 0.1, 1, flags=native.FLAG_PCGS).close()
     p = native.GGSHandle(4, 20, 0.1, 0.1, 1, flags=native.FLAG_PCGS)
-    with pytest.raises(native.GGSError) as e:
-        p.set_corpus(np.array([0, 40000], np.int64), np.zeros(40000, np.int32))
-    assert e.value.code == native.ERR_UNSUPPORTED and "32768" in str(e.value)
+    p.set_corpus(np.array([0, 40000], np.int64), np.zeros(40000, np.int32))      # was refused (int16 counts): now the wave-per-document kernel
     p.set_corpus(c.doc_ptr, c.tokens)
     p.init_z_java_lcg(1)
     p.init_phi()
@@ -603,6 +602,78 @@ def test_pcgs_matches_oracle(native, oracle, K, alpha, beta):
         g.sweep(1)
         o.sweep(1)
         compare_state(g, o, "pcgs K=%d sweep %d" % (K, it + 1), theta=False)
+
+
+def _pcgs_pair(native, oracle, c, K, alpha, beta, seed, zseed, flags=0):
+    g = native.GGSHandle(K, c.num_types, alpha, beta, seed, flags=native.FLAG_PARANOID | native.FLAG_PCGS | flags)
+    o = oracle.OracleSampler(K, c.num_types, alpha, beta, seed, threads=8)
+    o.set_scheme("pcgs")
+    for s in (g, o):
+        s.set_corpus(c.doc_ptr, c.tokens)
+        s.init_z_java_lcg(zseed)
+        s.init_phi()
+    return g, o
+
+
+@pytest.mark.parametrize("K,alpha,beta", [(321, 0.1, 0.01), (500, 0.1, 0.01), (1024, 0.05, 0.01), (2049, 0.1, 0.01), (4096, 0.02, 0.05)])
+def test_pcgs_wide_topic_rows(native, oracle, K, alpha, beta):
+    """BASELINE's K = 500 and K = 1024 under scheme=pcgs: above 320 topics one WAVE owns a document (ggs_z_pcgs_wave.hpp;
+    the lane-per-document kernels' int16 [K][64] counts no longer fit LDS).  The wave's reduction / scan only proposes a
+    topic; the margin argument proves it is the Java walk's -- the oracle's bits either way.  UPLDA:1466-1545."""
+    c = random_corpus(140, 600, 90, seed=K, empty_every=11)
+    g, o = _pcgs_pair(native, oracle, c, K, alpha, beta, 5 + K, K)
+    compare_state(g, o, "pcgs K=%d init" % K, theta=False)
+    for it in range(2):
+        g.sweep(1)
+        o.sweep(1)
+        compare_state(g, o, "pcgs K=%d sweep %d" % (K, it + 1), theta=False)
+
+
+@pytest.mark.parametrize("K", [3, 64, 129, 200, 1024])
+@pytest.mark.parametrize("margin", ["1", "1e9", "1e300"])
+def test_pcgs_wave_kernel_forced_and_its_exact_replay(native, oracle, monkeypatch, K, margin):
+    """The wave-per-document kernel at any K (GGS_DEBUG_PCGS_WAVE=1), with its certainty margin scaled up so that most
+    (1e9) or all (1e300) tokens take the element-by-element replay: the same bits every way."""
+    monkeypatch.setenv("GGS_DEBUG_PCGS_WAVE", "1")
+    monkeypatch.setenv("GGS_DEBUG_MARGIN", margin)
+    c = random_corpus(70, 300, 60, seed=K + 1, empty_every=9)
+    g, o = _pcgs_pair(native, oracle, c, K, 0.1, 0.01, 11, K)
+    monkeypatch.delenv("GGS_DEBUG_PCGS_WAVE")
+    monkeypatch.delenv("GGS_DEBUG_MARGIN")
+    g.sweep(2)
+    o.sweep(2)
+    compare_state(g, o, "pcgs wave kernel K=%d margin x%s" % (K, margin), theta=False)
+
+
+def test_pcgs_document_of_forty_thousand_tokens(native, oracle):
+    """The lane-per-document kernels count a document's topics in int16: a document of 32 768 tokens or more used to be
+    refused.  Such a corpus now goes to the wave-per-document kernel (int32 counts), whatever K."""
+    rng = np.random.default_rng(3)
+    lens = np.array([40000, 0, 7, 33000, 120, 1], np.int64)
+    doc_ptr = np.concatenate([[0], np.cumsum(lens)])
+    V = 500
+    tokens = rng.zipf(1.3, int(doc_ptr[-1])).astype(np.int64) % V
+    from ldagroupedgibbssampler_amd.corpus import Corpus
+    c = Corpus(doc_ptr, tokens.astype(np.int32), V)
+    for K in (20, 400):
+        g, o = _pcgs_pair(native, oracle, c, K, 0.1, 0.01, 9, 4)
+        g.sweep(2)
+        o.sweep(2)
+        compare_state(g, o, "pcgs long documents K=%d" % K, theta=False)
+        assert g.get_doc_topic_counts(0, 1).sum() == 40000
+
+
+def test_pcgs_wave_kernel_raises_what_java_raises(native):
+    """UPLDA:1529-1531 through the wave kernel's replay path: an all-zero Phi makes every score 0."""
+    c = random_corpus(10, 20, 30, seed=1)
+    p = native.GGSHandle(400, 20, 0.1, 0.01, 1, flags=native.FLAG_PCGS)
+    p.set_corpus(c.doc_ptr, c.tokens)
+    p.init_z_java_lcg(1)
+    p.init_phi()
+    p.set_phi(np.zeros((400, 20)))
+    with pytest.raises(native.GGSError) as e:
+        p.sweep(1)
+    assert e.value.code == native.ERR_INVALID_TOPIC
 
 
 def test_pcgs_two_pass_kernel_below_193_topics(native, oracle, monkeypatch):

@@ -293,12 +293,15 @@ int ggs_model_log_likelihood(ggs_handle *h, double *doc_side, double *topic_side
  * step used (thetaMatrix); topic_side = (beta - 1) sum_{k,v} log(phi[k][v] + 1e-12); the value is the sum over the
  * shards' doc_side plus one topic_side.  (The Java loop fills a dense K x V matrix per document -- D*K*V operations
  * -- to compute what is a sum over tokens.)  Same accuracy contract as ggs_model_log_likelihood.
- * GGS_ERR_UNSUPPORTED for scheme pcgs, whose diagnostic theta is a fresh random draw (UPLDA:712-714). */
+ * Scheme pcgs keeps no thetaMatrix: the reference draws theta_d ~ Dirichlet(n_d. + alpha) afresh for this diagnostic
+ * (UPLDA:710-714, LDAUtils.drawDirichlets) from a clock-seeded MALLET generator; here that draw is the one of GGS:57-72
+ * under the Philox stream GGS_PURPOSE_THETA at the current iteration (reproducible; ggs_get_theta returns it afterwards).
+ * GGS_ERR_UNSUPPORTED for scheme collapsed (no Phi). */
 int ggs_log_posterior(ggs_handle *h, double *doc_side, double *topic_side);
 /* replaces: addTestInstances (UPLDA:340-343; the test set of the held-out estimator).  CSR like ggs_set_corpus; token
  * ids are indices of the TRAINING alphabet, ids >= num_types are out of vocabulary and skipped as at MPE:341-345.
  * doc_base = global index of the first test document (RNG element ids only; for a sharded test set).  Documents longer
- * than 2*GGS_MAX_BLOCKS tokens: GGS_ERR_UNSUPPORTED. */
+ * than 2^25 tokens (the 24-bit block field of a particle's Philox stream, two uniforms per block): GGS_ERR_UNSUPPORTED. */
 int ggs_set_test_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr /*D+1*/, const int32_t *tokens, int64_t doc_base);
 /* replaces: new MarginalProbEstimatorPlain(numTopics, alpha, alphaSum, beta, typeTopicCounts, tokensPerTopic)
  * .evaluateLeftToRight(testSet, numParticles, null) (MPE:51-121,123-519; call sites UPLDA:604-622,677-682,840-844 with
@@ -307,8 +310,10 @@ int ggs_set_test_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr /*D+1*/
  * = the per-document values (what Java prints to docProbabilityStream); *total = their sum in document order.
  * Bit-identical to the oracle's restatement under the Philox stream GGS_PURPOSE_HELDOUT (the reference's Randoms is
  * clock-seeded).  The estimator's IllegalStateException ("Sampled invalid topic") -> GGS_ERR_INVALID_TOPIC.
- * GGS_ERR_UNSUPPORTED when the per-particle topic counts do not fit LDS: more than 1704 topics, or more than 1024 with
- * a test document longer than 255 tokens. */
+ * The per-particle topic counts (1, 2 or 4 bytes each by the length of the test document) live in LDS where K * 64 of
+ * them fit beside the tables -- up to 1704 topics with test documents of at most 255 tokens, 1024 with longer ones --
+ * and in global memory otherwise (same arithmetic, slower).  GGS_ERR_UNSUPPORTED only when the estimator's tables
+ * themselves do not fit LDS (about 6000 topics). */
 int ggs_heldout_log_likelihood(ggs_handle *h, int32_t num_particles, double *doc_ll, double *total);
 /* out[k] = x[0][k] + x[1][k] + ... in index order (exactly one of x / counts given; with counts the addends are
  * beta + counts[v][k]): the Phi normalisers' exact parallel column sum on its own, for adversarial inputs */

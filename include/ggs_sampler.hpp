@@ -253,7 +253,7 @@ class LDAGroupedGibbsSampler {
   std::vector<double> loglikelihood, heldOutLoglikelihood, logPosterior;    // MSLDA:114-115; UPLDA:591,843,849
   void diagnostics(int iteration) {
     const bool files = !config_.log_dir.empty();
-    if (config_.start_diagnostic > 0 && iteration >= config_.start_diagnostic && !config_.pcgs && !config_.collapsed) {
+    if (config_.start_diagnostic > 0 && iteration >= config_.start_diagnostic && !config_.collapsed) {   // pcgs: with a fresh theta, UPLDA:710-714
       const double lp = computeLogPosterior();                              // UPLDA:818-821
       logPosterior.push_back(lp);
       if (files)

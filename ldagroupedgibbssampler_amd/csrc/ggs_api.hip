@@ -113,8 +113,10 @@ struct ggs_handle {
   uint32_t *d_status = nullptr;
   // test set of the held-out estimator (ggs_heldout.hpp)
   int64_t *d_test_ptr = nullptr;
-  int32_t *d_test_tok = nullptr, *d_test_docs = nullptr;       // d_test_docs: ids of the documents of <= 255 tokens, then of the longer ones
-  std::vector<int32_t> test_short, test_long;
+  int32_t *d_test_tok = nullptr, *d_test_docs = nullptr;       // d_test_docs: ids of the documents of <= 255 tokens, then of those up to 65 535, then of the longer ones
+  std::vector<int32_t> test_short, test_long, test_huge;
+  void *d_heldout_spill = nullptr;
+  size_t heldout_spill_bytes = 0;
   double *d_test_ll = nullptr;
   std::vector<int64_t> test_ptr;
   int64_t test_doc_base = 0;
@@ -1158,7 +1160,7 @@ void ggs_destroy(ggs_handle *h) {
                   h->d_phiT, h->d_mag, h->d_tot, h->d_phi_mean, h->d_n_wk, h->d_n_k, h->d_perm, h->d_inv_perm, h->d_zw, h->d_seg_word, h->d_seg_begin,
                   h->d_status, h->d_scratch, h->d_sum_pref, h->d_sum_fn, h->d_ct_tok, h->d_ct_idx, h->d_ct_ip, h->d_c_docs, h->d_hot_words, h->d_order,
                   h->d_test_ptr, h->d_test_tok, h->d_test_ll, h->d_test_docs, h->d_koff, h->d_cnt_send, h->d_cnt_own, h->d_cnt_all, h->d_n_k_own,
-                  h->d_phi_own, h->d_phi_all0, h->d_phi_all1, h->d_mag_own, h->d_krank, h->d_kcol, h->d_lcg, h->d_chunk_doc1};
+                  h->d_heldout_spill, h->d_phi_own, h->d_phi_all0, h->d_phi_all1, h->d_mag_own, h->d_krank, h->d_kcol, h->d_lcg, h->d_chunk_doc1};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   exchange_free(h->xg);
@@ -1441,6 +1443,7 @@ int ggs_set_z(ggs_handle *h, const int32_t *z, int32_t redraw_phi) {
   for (int64_t i = 0; i < h->N; ++i)
     if (z[i] < 0 || z[i] >= h->K) return set_err(h, GGS_ERR_BAD_ARG, "topic indicator outside [0, num_topics)");
   if ((rc = drop_theta_ahead(h))) return rc;
+  h->lcg_ready = false;                                // a restored z is not the state any java.util.Random stream left: the serial chain starts a new Random(java_seed)
   if (h->N) HIP_TRY(h, hipMemcpyAsync(h->d_z, z, sizeof(int32_t) * (size_t)h->N, hipMemcpyHostToDevice, h->stream));
   if ((rc = launch_permute_z(h))) return rc;
   if ((rc = launch_count_rebuild(h))) return rc;
@@ -1941,7 +1944,12 @@ int ggs_log_posterior(ggs_handle *h, double *doc_side, double *topic_side) {
   int rc = require_ready(h, true);
   if (rc) return rc;
   if (!doc_side || !topic_side) return set_err(h, GGS_ERR_BAD_ARG, "null output");
-  if (h->flags & GGS_FLAG_PCGS) return set_err(h, GGS_ERR_UNSUPPORTED, "scheme=pcgs draws its diagnostic theta afresh (UPLDA:712-714); only ggs keeps thetaMatrix");
+  if (h->collapsed) return set_err(h, GGS_ERR_UNSUPPORTED, "scheme=collapsed has no Phi: the log posterior of UPLDA:1573-1634 does not apply");
+  if (h->flags & GGS_FLAG_PCGS) {
+    // UPLDA:710-714: every scheme but ggs draws theta_d ~ Dir(n_d. + alpha) afresh for the diagnostics
+    // (LDAUtils.drawDirichlets); here: the theta draw of GGS:57-72 under the stream GGS_PURPOSE_THETA at the current iteration
+    if ((rc = drop_theta_ahead(h)) || (rc = launch_theta(h, h->stream, h->d_theta, h->iteration))) return rc;
+  }
   const int K = h->K;
   const int64_t doc_blocks = (h->D + kLLBlock / 64 - 1) / (kLLBlock / 64), phi_blocks = 1024;
   const size_t bytes = 32 + sizeof(double) * (size_t)(doc_blocks + phi_blocks);
@@ -1964,8 +1972,8 @@ int ggs_set_test_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const 
   if (doc_ptr[0] != 0) return set_err(h, GGS_ERR_BAD_ARG, "doc_ptr[0] must be 0");
   for (int64_t d = 0; d < D; ++d) {
     if (doc_ptr[d + 1] < doc_ptr[d]) return set_err(h, GGS_ERR_BAD_ARG, "doc_ptr must be non-decreasing");
-    if (doc_ptr[d + 1] - doc_ptr[d] > 2 * (int64_t)GGS_MAX_BLOCKS)
-      return set_err(h, GGS_ERR_UNSUPPORTED, "a test document has more than 2*GGS_MAX_BLOCKS tokens (one Philox stream per particle)");
+    if (doc_ptr[d + 1] - doc_ptr[d] > ((int64_t)1 << 25))
+      return set_err(h, GGS_ERR_UNSUPPORTED, "a test document has more than 2^25 tokens (one Philox stream per particle: 2^24 blocks of two uniforms)");
   }
   const int64_t N = doc_ptr[D];
   if (N > 0 && !tokens) return set_err(h, GGS_ERR_BAD_ARG, "tokens is null");
@@ -1978,12 +1986,20 @@ int ggs_set_test_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const 
   HIP_TRY(h, hipMemcpy(h->d_test_ptr, doc_ptr, sizeof(int64_t) * (size_t)(D + 1), hipMemcpyHostToDevice));
   if (N) HIP_TRY(h, hipMemcpy(h->d_test_tok, tokens, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice));
   h->test_ptr.assign(doc_ptr, doc_ptr + D + 1);
-  h->test_short.clear(); h->test_long.clear();
-  for (int64_t d = 0; d < D; ++d) (doc_ptr[d + 1] - doc_ptr[d] <= 255 ? h->test_short : h->test_long).push_back((int32_t)d);
+  // by the width a particle's per-topic counts need: one byte (documents of at most 255 tokens), two (65 535), four
+  h->test_short.clear(); h->test_long.clear(); h->test_huge.clear();
+  for (int64_t d = 0; d < D; ++d) {
+    const int64_t len = doc_ptr[d + 1] - doc_ptr[d];
+    (len <= 255 ? h->test_short : len <= 65535 ? h->test_long : h->test_huge).push_back((int32_t)d);
+  }
   if ((rc = dev_alloc(h, &h->d_test_docs, (size_t)D))) return rc;
-  if (!h->test_short.empty()) HIP_TRY(h, hipMemcpy(h->d_test_docs, h->test_short.data(), sizeof(int32_t) * h->test_short.size(), hipMemcpyHostToDevice));
-  if (!h->test_long.empty())
-    HIP_TRY(h, hipMemcpy(h->d_test_docs + h->test_short.size(), h->test_long.data(), sizeof(int32_t) * h->test_long.size(), hipMemcpyHostToDevice));
+  {
+    size_t at = 0;
+    for (const std::vector<int32_t> *ids : {&h->test_short, &h->test_long, &h->test_huge}) {
+      if (!ids->empty()) HIP_TRY(h, hipMemcpy(h->d_test_docs + at, ids->data(), sizeof(int32_t) * ids->size(), hipMemcpyHostToDevice));
+      at += ids->size();
+    }
+  }
   h->test_doc_base = doc_base;
   h->have_test = true;
   return GGS_OK;
@@ -2021,14 +2037,26 @@ int ggs_heldout_log_likelihood(ggs_handle *h, int32_t num_particles, double *doc
     }
     return floor;
   };
-  const Shape shape8 = best_shape(1), shape16 = best_shape(2);
-  if ((!h->test_short.empty() && !shape8.waves) || (!h->test_long.empty() && !shape16.waves))
-    return set_err(h, GGS_ERR_UNSUPPORTED, "num_topics too large for the held-out estimator's per-particle counts in LDS "
-                                           "(up to 1704 topics with test documents of at most 255 tokens, 1024 with longer ones)");
-  if (shape8.waves)
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel<uint8_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
-  if (shape16.waves)
-    HIP_TRY(h, hipFuncSetAttribute(reinterpret_cast<const void *>(heldout_particles_kernel<uint16_t>), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
+  // a class of documents whose per-particle counts do not fit LDS (more than 1704 topics with one-byte counts, 1024 with
+  // two; four-byte counts always) keeps them in global memory: the LDS then holds the tables and the cell lists only
+  const Shape shape8 = best_shape(1), shape16 = best_shape(2), shape_spill = best_shape(0);
+  const bool spill8 = !h->test_short.empty() && !shape8.waves, spill16 = !h->test_long.empty() && !shape16.waves, spill32 = !h->test_huge.empty();
+  if ((spill8 || spill16 || spill32) && !shape_spill.waves)
+    return set_err(h, GGS_ERR_UNSUPPORTED, "num_topics too large for the held-out estimator's tables in LDS (about 6000 topics)");
+  const int64_t spill_blocks = (int64_t)h->num_cus * std::max(1, shape_spill.waves ? shape_spill.per_cu / shape_spill.waves : 1);   // a persistent grid: what is resident
+  if (spill8 || spill16 || spill32) {
+    const size_t need = (size_t)spill_blocks * shape_spill.waves * (size_t)K * 64 * (spill32 ? 4 : spill16 ? 2 : 1);
+    if (h->heldout_spill_bytes < need) {
+      if (h->d_heldout_spill) (void)hipFree(h->d_heldout_spill);
+      h->d_heldout_spill = nullptr; h->heldout_spill_bytes = 0;
+      HIP_TRY(h, hipMalloc(&h->d_heldout_spill, need));
+      h->heldout_spill_bytes = need;
+    }
+  }
+  const void *kernels[] = {reinterpret_cast<const void *>(heldout_particles_kernel<uint8_t, false>), reinterpret_cast<const void *>(heldout_particles_kernel<uint16_t, false>),
+                           reinterpret_cast<const void *>(heldout_particles_kernel<uint8_t, true>), reinterpret_cast<const void *>(heldout_particles_kernel<uint16_t, true>),
+                           reinterpret_cast<const void *>(heldout_particles_kernel<uint32_t, true>)};
+  for (const void *f : kernels) HIP_TRY(h, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes));
   // wordProbabilities of a batch of documents: tokens x particles doubles, at most ~4 GiB at a time (one launch for
   // the 2 M-token test set of the benchmark: every extra launch has its own tail of half-empty CUs)
   int64_t want_cells = (int64_t)1 << 29;
@@ -2066,20 +2094,23 @@ int ggs_heldout_log_likelihood(ggs_handle *h, int32_t num_particles, double *doc
       lo = std::lower_bound(ids.begin(), ids.end(), (int32_t)hp.d0) - ids.begin();
       hi = std::lower_bound(ids.begin(), ids.end(), (int32_t)hp.d1) - ids.begin();
     };
-    size_t lo, hi;
-    range(h->test_short, lo, hi);
-    if (hi > lo) {
-      hp.docs = h->d_test_docs + lo; hp.n_docs = (int64_t)(hi - lo); hp.waves = shape8.waves; hp.cap = shape8.cap;
-      const int64_t units = hp.n_docs * hp.blocks_per_doc;
-      hipLaunchKernelGGL(heldout_particles_kernel<uint8_t>, dim3((unsigned)((units + hp.waves - 1) / hp.waves)), dim3(hp.waves * 64),
-                         lds_of(hp.waves, 1, hp.cap), h->stream, hp);
-    }
-    range(h->test_long, lo, hi);
-    if (hi > lo) {
-      hp.docs = h->d_test_docs + h->test_short.size() + lo; hp.n_docs = (int64_t)(hi - lo); hp.waves = shape16.waves; hp.cap = shape16.cap;
-      const int64_t units = hp.n_docs * hp.blocks_per_doc;
-      hipLaunchKernelGGL(heldout_particles_kernel<uint16_t>, dim3((unsigned)((units + hp.waves - 1) / hp.waves)), dim3(hp.waves * 64),
-                         lds_of(hp.waves, 2, hp.cap), h->stream, hp);
+    // one launch per class of documents present in the batch: counts in LDS where they fit, in global memory otherwise
+    struct Class { const std::vector<int32_t> *ids; size_t offset; int bytes; bool spill; Shape shape; };
+    const Class classes[] = {{&h->test_short, 0, 1, spill8, spill8 ? shape_spill : shape8},
+                             {&h->test_long, h->test_short.size(), 2, spill16, spill16 ? shape_spill : shape16},
+                             {&h->test_huge, h->test_short.size() + h->test_long.size(), 4, true, shape_spill}};
+    for (const Class &c : classes) {
+      size_t lo, hi;
+      range(*c.ids, lo, hi);
+      if (hi <= lo) continue;
+      hp.docs = h->d_test_docs + c.offset + lo; hp.n_docs = (int64_t)(hi - lo); hp.waves = c.shape.waves; hp.cap = c.shape.cap;
+      hp.cnt_spill = c.spill ? h->d_heldout_spill : nullptr;
+      const int64_t units = hp.n_docs * hp.blocks_per_doc, blocks = (units + hp.waves - 1) / hp.waves;
+      const dim3 grid((unsigned)(c.spill ? std::min(blocks, spill_blocks) : blocks)), block((unsigned)(hp.waves * 64));
+      const size_t lds = lds_of(hp.waves, c.spill ? 0 : c.bytes, hp.cap);
+      const void *f = c.spill ? (c.bytes == 1 ? kernels[2] : c.bytes == 2 ? kernels[3] : kernels[4]) : (c.bytes == 1 ? kernels[0] : kernels[1]);
+      void *args[] = {&hp};
+      HIP_TRY(h, hipLaunchKernel(f, grid, block, args, lds, h->stream));
     }
     hipLaunchKernelGGL(heldout_reduce_kernel, dim3((unsigned)((hp.d1 - hp.d0 + 3) / 4)), dim3(256), 0, h->stream, hp);
   }

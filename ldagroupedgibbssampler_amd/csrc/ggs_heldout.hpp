@@ -37,6 +37,7 @@ struct HeldoutParams {
   int64_t d0, d1, doc_base; // this batch covers test documents [d0, d1); the reduce kernel takes all of them
   int32_t K, V, P, blocks_per_doc, waves;
   int32_t cap;              // counts below cap take their coefficient from the LDS table [K][cap]
+  void *cnt_spill;          // SPILL: the per-particle topic counts [resident wave][K][64] in global memory
 };
 
 constexpr int kHeldoutMaxWaves = 16;
@@ -59,10 +60,12 @@ __global__ void heldout_setup_kernel(const double *alpha, const int32_t *n_k, do
   tab[0] = smoothing;
 }
 
-// CntT: the particle's per-topic counts -- one byte each for documents of at most 255 tokens, two beyond.  The kernel
-// is bound by instruction issue (one instruction per ~8 cycles and wave), so what matters is how many waves share a
-// SIMD, and that is set by these counts' LDS footprint.
-template <typename CntT>
+// CntT: the particle's per-topic counts -- one byte each for documents of at most 255 tokens, two up to 65 535, four
+// beyond.  The kernel is bound by instruction issue (one instruction per ~8 cycles and wave), so what matters is how many
+// waves share a SIMD, and that is set by these counts' LDS footprint.  SPILL: where K * 64 counts per wave do not fit LDS
+// at all (more than 1704 topics, or more than 1024 with two-byte counts) they live in global memory instead, one
+// [K][64] block per RESIDENT wave (the grid is then persistent and a wave strides over its units); same arithmetic.
+template <typename CntT, bool SPILL = false>
 __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kernel(HeldoutParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   const int K = p.K;
@@ -81,7 +84,8 @@ __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kerne
   const int Kpad = (K + 63) & ~63;
   // the current word's non-zero (topic, count) cells, compacted in topic order: what both passes iterate
   int2 *list_s = reinterpret_cast<int2 *>(coef_s + (size_t)K * cap) + (size_t)wave * Kpad;
-  CntT *cnt_s = reinterpret_cast<CntT *>(reinterpret_cast<int2 *>(coef_s + (size_t)K * cap) + (size_t)p.waves * Kpad) + (size_t)wave * K * 64;
+  CntT *cnt_s = SPILL ? static_cast<CntT *>(p.cnt_spill) + ((size_t)blockIdx.x * p.waves + wave) * (size_t)K * 64
+                      : reinterpret_cast<CntT *>(reinterpret_cast<int2 *>(coef_s + (size_t)K * cap) + (size_t)p.waves * Kpad) + (size_t)wave * K * 64;
   // The score loops are bound by instruction issue (a wave issues one instruction per ~8 cycles; SQ counters in
   // profiles/): the cells are compacted once per word so that the loops index them by a counter instead of peeling
   // bits off a ballot mask, and are taken kHeldoutBatch at a time -- all counts, then all coefficients, then the
@@ -110,8 +114,9 @@ __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kerne
         if (__ballot(n[j] >= cap)) cf[j] = (alpha_s[kk[j]] + (double)n[j]) / denom_s[kk[j]];
     }
   };
-  const int64_t unit = (int64_t)blockIdx.x * p.waves + wave;
-  if (unit / p.blocks_per_doc >= p.n_docs) return;                      // no block-wide barrier below
+  const int64_t unit0 = (int64_t)blockIdx.x * p.waves + wave, n_units = p.n_docs * p.blocks_per_doc;
+  // no block-wide barrier below: a wave simply leaves when it has no unit (left)
+  for (int64_t unit = unit0; unit < n_units; unit += SPILL ? (int64_t)gridDim.x * p.waves : n_units) {
   const int64_t d = p.docs[unit / p.blocks_per_doc];
   const int particle = (int)(unit % p.blocks_per_doc) * 64 + lane;
   const bool live = particle < p.P;                                     // dead lanes compute along, store nothing
@@ -216,6 +221,7 @@ __global__ __launch_bounds__(kHeldoutMaxWaves * 64) void heldout_particles_kerne
     beta_mass += beta * (double)(n_old + 1) / denom_s[newTopic];        // MPE:506-507
   }
   if (bad && live) atomicOr(p.status, ST_INVALID_TOPIC);
+  }
 }
 
 // MPE:102-116: per position the sum over the particles in particle order, log, minus log(numParticles); per document

@@ -208,11 +208,11 @@ class LDAGroupedGibbsSampler:
 
     def _diagnostics(self, iteration):
         """The per-iteration diagnostics of UPLDA:695-905 that have a device implementation, in the Java order: log
-        posterior (ggs, from start_diagnostic on), held-out and model log likelihood (compute_likelihood), topic
+        posterior (ggs and pcgs, from start_diagnostic on), held-out and model log likelihood (compute_likelihood), topic
         indicators; each value is kept in the Java-named list and, with a log_dir, appended in the Java file format."""
         cfg = self.config
         from . import formats as F
-        if cfg.start_diagnostic > 0 and iteration >= cfg.start_diagnostic and not (self._scheme_flags & (native.FLAG_PCGS | native.FLAG_COLLAPSED)):
+        if cfg.start_diagnostic > 0 and iteration >= cfg.start_diagnostic and not (self._scheme_flags & native.FLAG_COLLAPSED):   # pcgs: with a fresh theta, UPLDA:710-714
             lp = self.computeLogPosterior()                               # UPLDA:818-821
             self.logPosterior.append(lp)
             if cfg.log_dir:

@@ -343,6 +343,8 @@ typedef struct {
   int have_next_gaussian;
   double next_gaussian;
   int exhausted;
+  uint32_t max_blocks;  /* ORC_MAX_BLOCKS for a draw (a runaway rejection loop); the held-out stream of a long test document may use
+                           the whole 24-bit block field of the counter */
 } draw_rng;
 
 static void draw_init(draw_rng *r, uint64_t seed, uint32_t iter, uint32_t purpose, uint64_t elem) {
@@ -351,10 +353,11 @@ static void draw_init(draw_rng *r, uint64_t seed, uint32_t iter, uint32_t purpos
   r->ctr2_base = purpose << 24; r->ctr3 = iter;
   r->pos = 0; r->cached_block = -1; r->have_next_gaussian = 0; r->next_gaussian = 0.0;
   r->exhausted = 0;
+  r->max_blocks = ORC_MAX_BLOCKS;
 }
 static double draw_next_double(draw_rng *r) {
   uint32_t blk = r->pos >> 1;
-  if (blk >= ORC_MAX_BLOCKS) { r->exhausted = 1; return 0.5; }
+  if (blk >= r->max_blocks) { r->exhausted = 1; return 0.5; }
   if ((int32_t)blk != r->cached_block) {
     uint32_t c[4] = {r->ctr0, r->ctr1, r->ctr2_base | blk, r->ctr3}, o[4];
     orc_philox4x32_10(c, r->key, o);
@@ -1101,6 +1104,29 @@ void orc_model_log_likelihood(const orc_state *s, double *doc_side, double *topi
   free(topicCounts); free(topicLogGammas);
 }
 
+/* UPLDA:710-714: for every scheme but "ggs" the sampling loop draws a fresh theta for its diagnostics from the
+ * document-topic counts, theta_d ~ Dirichlet(n_d. + alpha) (LDAUtils.getDocumentTopicCounts + LDAUtils.drawDirichlets,
+ * util/LDAUtils.java:1662-1673).  The reference draws it from MALLET's Dirichlet / Randoms (third-party, clock-seeded
+ * gammas); here it is the draw of GGS:57-72 under the same Philox stream ORC_PURPOSE_THETA at the current iteration --
+ * the same distribution, reproducible.  Fills s->theta. */
+int orc_draw_diagnostic_theta(orc_state *s) {
+  const int32_t K = s->K;
+  int err = ORC_OK;
+  int32_t *cnt = malloc(sizeof(int32_t) * (size_t)K);
+  double *par = malloc(sizeof(double) * (size_t)K);
+  for (int64_t d = 0; d < s->D && !err; d++) {
+    const int64_t b = s->doc_ptr[d], e = s->doc_ptr[d + 1];
+    if (e == b) continue;                                     /* an empty document keeps its (zero) row, as in the z step */
+    memset(cnt, 0, sizeof(int32_t) * (size_t)K);
+    for (int64_t i = b; i < e; i++) cnt[s->z[i]]++;
+    for (int32_t k = 0; k < K; k++) par[k] = cnt[k] + s->alpha[k];
+    err = orc_dirichlet(s->seed, (uint32_t)s->iteration, ORC_PURPOSE_THETA, (uint64_t)(s->doc_base + d) * (uint64_t)K, K, par,
+                        s->theta + (size_t)d * K);
+  }
+  free(cnt); free(par);
+  return err ? fail(s, err, "diagnostic theta draw failed") : ORC_OK;
+}
+
 /* UPLDA:1573-1634 computeLogPosterior in the Java loop order (Math.log restated with the fdlibm log).  The
  * dense per-document K x V matrix m_djt is kept as the sorted list of the document's (topic, type) pairs: the Java
  * loop visits k then v ascending and adds count * logPhi for every non-zero cell, and so does this. */
@@ -1158,6 +1184,7 @@ static int left_to_right(orc_state *s, const int32_t *tok, int64_t docLength, ui
   int tokensSoFar = 0, nonZeroTopics = 0, denseIndex;
   double topicBetaMass = 0.0, topicTermMass;
   draw_rng r; draw_init(&r, s->seed, (uint32_t)s->iteration, ORC_PURPOSE_HELDOUT, elem);
+  r.max_blocks = 1u << 24;                                                /* one uniform per token: the block field's 24 bits = 2^25 tokens */
   memset(localTopicCounts, 0, sizeof(int32_t) * (size_t)numTopics);
   for (int64_t limit = 0; limit < docLength; limit++) wordProbabilities[limit] = 0.0;
   for (int64_t limit = 0; limit < docLength; limit++) {
@@ -1203,7 +1230,7 @@ static int left_to_right(orc_state *s, const int32_t *tok, int64_t docLength, ui
         }
       }
     }
-    if (r.exhausted) { rc = fail(s, ORC_ERR_RNG_EXHAUSTED, "held-out stream: document longer than 2*ORC_MAX_BLOCKS tokens"); break; }
+    if (r.exhausted) { rc = fail(s, ORC_ERR_RNG_EXHAUSTED, "held-out stream: document longer than 2^25 tokens"); break; }
     if (newTopic < 0 || newTopic >= numTopics) {                          /* MPE:416,447,455,464-469: IllegalStateException */
       rc = fail(s, ORC_ERR_INVALID_TOPIC, "Sampled invalid topic");
       break;

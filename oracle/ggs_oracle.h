@@ -96,6 +96,7 @@ int orc_init_phi(orc_state *s);                        /* UPLDA:1287-1294       
 void orc_set_phi_mean_gating(orc_state *s, int save, int burn_in, int thin);
 /* UPLDA:1573-1634 computeLogPosterior in the Java loop order; the value is doc_side + topic_side */
 void orc_log_posterior(const orc_state *s, double *doc_side, double *topic_side);
+int orc_draw_diagnostic_theta(orc_state *s);   /* UPLDA:710-714, the non-ggs schemes' theta for the diagnostics */
 /* UPLDA:1644-1758 modelLogLikelihood in the Java loop order; the model's value is doc_side + topic_side */
 void orc_model_log_likelihood(const orc_state *s, double *doc_side, double *topic_side);
 /* MarginalProbEstimatorPlain.evaluateLeftToRight (MPE:85-121) on the state's current counts; doc_ll[D] is required */

@@ -64,6 +64,7 @@ def lib():
         "orc_set_scheme": (None, [vp, C.c_int]),
         "orc_model_log_likelihood": (None, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "orc_log_posterior": (None, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+        "orc_draw_diagnostic_theta": (C.c_int, [vp]),
         "orc_heldout_log_likelihood": (C.c_int, [vp, C.c_int64, lp, ip, C.c_int64, C.c_int32, dp, C.POINTER(C.c_double)]),
         "orc_set_iteration": (None, [vp, C.c_int32]),
         "orc_get_iteration": (C.c_int32, [vp]),
@@ -246,6 +247,10 @@ class OracleSampler:
         a, b = C.c_double(), C.c_double()
         lib().orc_model_log_likelihood(self._h, C.byref(a), C.byref(b))
         return a.value, b.value
+
+    def draw_diagnostic_theta(self):
+        """UPLDA:710-714: the non-ggs schemes draw theta ~ Dir(n_d + alpha) afresh for the diagnostics (fills get_theta())."""
+        self._chk(lib().orc_draw_diagnostic_theta(self._h))
 
     def log_posterior(self):
         """(document side, topic side) of UPLDA:1573-1634; their sum is the log posterior."""

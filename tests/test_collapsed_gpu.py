@@ -73,6 +73,24 @@ def test_serial_chain_on_ragged_corpora(native, oracle, K, alpha, beta):
     same_counts(g2, o2, "ragged K=%d serial after set_z" % K)
 
 
+def test_set_z_after_the_seeded_start_begins_a_new_random_stream(native, oracle):
+    """include/ggs_hip.h: after ggs_set_z the serial chain creates a new Random(java_seed) at its first call -- also when
+    the handle had been started with ggs_init_z_java_lcg before (the stale stream of the seeded start must not go on)."""
+    c = random_corpus(40, 120, 30, seed=2, empty_every=6)
+    K = 9
+    g, o = pair(native, oracle, c, K, 0.3, 0.05, 21, 5)          # init_z_java_lcg(5): the handle owns a stream now
+    g.collapsed_serial_sweep(5, 1)
+    o.collapsed_sweep(5, 1)
+    z = np.random.default_rng(0).integers(0, K, c.num_tokens).astype(np.int32)
+    g.set_z(z, redraw_phi=True)
+    o2 = oracle.OracleSampler(K, c.num_types, 0.3, 0.05, 21)
+    o2.set_corpus(c.doc_ptr, c.tokens)
+    o2.set_z(z, redraw_phi=True)
+    g.collapsed_serial_sweep(123, 2)                             # java_seed 123 is looked at: a fresh Random(123)
+    o2.collapsed_sweep(123, 2)
+    same_counts(g, o2, "serial chain after set_z on a seeded handle")
+
+
 @pytest.mark.parametrize("K,alpha,beta", [(3, 5.0, 7.0), (7, 0.1, 0.01), (20, 5.0, 7.0), (64, 0.05, 0.01), (100, 0.1, 0.01), (200, 0.1, 0.01), (333, 0.1, 0.01)])
 def test_parallel_schedule_matches_its_restatement(native, oracle, cats, K, alpha, beta):
     c = cats if K in (3, 20) else random_corpus(301, 500, 150, seed=K, empty_every=7)

@@ -146,8 +146,7 @@ def test_heldout_edge_cases(native, oracle, cats):
     g2.init_z_java_lcg(1)
     with pytest.raises(native.GGSError):
         g2.heldout_log_likelihood(100)                                   # no test set
-    with pytest.raises(native.GGSError):
-        g2.set_test_corpus(np.array([0, 8193 * 2], np.int64), np.zeros(8193 * 2, np.int32))   # longer than one particle's stream
+    g2.set_test_corpus(np.array([0, 8193 * 2], np.int64), np.zeros(8193 * 2, np.int32))   # was refused (2 * GGS_MAX_BLOCKS uniforms per particle): the stream now has the counter's whole 24-bit block field
     with pytest.raises(native.GGSError):
         g2.set_test_corpus(np.array([0, 1], np.int64), np.array([-1], np.int32))
     g2.set_test_corpus(np.array([0, 2], np.int64), np.array([0, 1], np.int32))
@@ -199,7 +198,8 @@ def test_heldout_medium_slice(native, oracle):
 @pytest.mark.gpu
 def test_heldout_wide_topic_rows(native, oracle):
     """K = 1024 (BASELINE config 3's width): the per-particle counts still fit LDS with a shallower coefficient table,
-    for short and for long test documents; beyond 1024 topics only documents of at most 255 tokens do."""
+    for short and for long test documents; beyond 1024 topics only documents of at most 255 tokens do -- the longer ones,
+    and everything beyond 1704 topics, keep the counts in global memory (heldout_particles_kernel<.., SPILL>)."""
     rng = np.random.default_rng(9)
     c = random_corpus(120, 400, 100, seed=61, empty_every=13)
     rows = [list(rng.integers(0, 400, int(n))) for n in (3, 40, 255, 256, 300, 0, 120)]
@@ -208,9 +208,21 @@ def test_heldout_wide_topic_rows(native, oracle):
     _same(g, o, test, 100)
     g, o = _pair(native, oracle, c, 1100, 0.05, 0.01, 18, 1)
     _same(g, o, _docs([r for r in rows if len(r) <= 255], c.num_types), 70)
-    g.set_test_corpus(test.doc_ptr, test.tokens)
-    with pytest.raises(native.GGSError):
-        g.heldout_log_likelihood(70)                                     # a 256-token document needs two-byte counts: too wide
+    _same(g, o, test, 70)                                               # a 256-token document needs two-byte counts: too wide for LDS at K = 1100, spilled
+    g, o = _pair(native, oracle, c, 2049, 0.05, 0.01, 19, 1)           # beyond 1704 topics every class is spilled
+    _same(g, o, test, 40)
+
+
+@pytest.mark.gpu
+def test_heldout_long_test_documents(native, oracle):
+    """Test documents beyond 8192 tokens (the old cap: 2 * GGS_MAX_BLOCKS uniforms of a particle's stream; now the
+    counter's whole 24-bit block field) and beyond 65 535 (four-byte counts, in global memory)."""
+    rng = np.random.default_rng(4)
+    c = random_corpus(150, 200, 60, seed=3, empty_every=11)
+    rows = [list(rng.integers(0, 200, int(n))) for n in (9000, 12, 70000, 0, 300)]
+    test = _docs(rows, c.num_types)
+    g, o = _pair(native, oracle, c, 12, 0.1, 0.02, 5, 1)
+    _same(g, o, test, 6)
 
 
 @pytest.mark.gpu

@@ -756,12 +756,30 @@ def test_log_posterior_on_device(native, oracle, cats):
         direct = (np.log(phi[z, corpus.tokens] + 1e-12).sum() + ((n_dk + alpha - 1.0) * np.log(theta + 1e-12)).sum()
                   + (beta - 1.0) * np.log(phi + 1e-12).sum())
         assert doc_of.size == z.size and abs((gd + gt) - direct) <= 1e-9 * abs(direct)
-    p = native.GGSHandle(4, cats.num_types, 0.1, 0.1, 1, flags=native.FLAG_PCGS)
-    p.set_corpus(cats.doc_ptr, cats.tokens)
-    p.init_z_java_lcg(1)
-    p.init_phi()
+    # scheme=pcgs keeps no thetaMatrix: its diagnostic theta is a fresh Dir(n_d + alpha) draw (UPLDA:710-714), here from the Philox stream
+    for K in (4, 300):
+        p = native.GGSHandle(K, cats.num_types, 0.1, 0.1, 1, flags=native.FLAG_PCGS)
+        o = oracle.OracleSampler(K, cats.num_types, 0.1, 0.1, 1)
+        o.set_scheme("pcgs")
+        for s in (p, o):
+            s.set_corpus(cats.doc_ptr, cats.tokens)
+            s.init_z_java_lcg(1)
+            s.init_phi()
+            s.sweep(2)
+        o.draw_diagnostic_theta()
+        od, ot = o.log_posterior()
+        gd, gt = p.log_posterior()
+        assert abs(gd - od) <= 1e-11 * abs(od) and abs(gt - ot) <= 1e-11 * abs(ot), (K, gd, od, gt, ot)
+        assert_bit_equal(p.get_theta(), o.get_theta(), "pcgs diagnostic theta K=%d" % K)
+        p.sweep(1)
+        o.sweep(1)
+        compare_state(p, o, "pcgs after the diagnostic", theta=False)      # the diagnostic does not disturb the chain
+    c = native.GGSHandle(4, cats.num_types, 0.1, 0.1, 1, flags=native.FLAG_COLLAPSED)
+    c.set_corpus(cats.doc_ptr, cats.tokens)
+    c.init_z_java_lcg(1)
+    c.init_phi()
     with pytest.raises(native.GGSError) as e:
-        p.log_posterior()
+        c.log_posterior()
     assert e.value.code == native.ERR_UNSUPPORTED
 
 

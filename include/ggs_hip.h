@@ -224,7 +224,11 @@ typedef struct ggs_exchange_ops {
 int ggs_attach_exchange(ggs_handle *h, int32_t rank, int32_t nranks, const ggs_exchange_ops *ops);
 /* RCCL, one process per GPU: rank 0 calls ggs_rccl_unique_id and hands the 128 bytes to every rank (any channel);
  * every rank then calls ggs_attach_rccl, which is ncclCommInitRank on the handle's device (collective, blocking).
- * librccl is dlopen'ed on first use (librccl.so.1: the copy already in the process if there is one). */
+ * librccl is dlopen'ed on first use (librccl.so.1: the copy already in the process if there is one).
+ * ONE RCCL per process: a host that later maps a SECOND copy of librccl (measured: PyTorch's wheel brings its own; loaded
+ * after this library had dlopen'ed ROCm's, the process aborted at exit with "double free or corruption" in the two
+ * copies' teardown) must load its copy first, so that this dlopen resolves to it -- ldagroupedgibbssampler_amd/_lib.py
+ * imports torch before the first exchange for exactly that reason; a JVM host has only the one copy. */
 #define GGS_RCCL_UNIQUE_ID_BYTES 128
 int ggs_rccl_unique_id(void *out_id /* GGS_RCCL_UNIQUE_ID_BYTES */);
 int ggs_attach_rccl(ggs_handle *h, int32_t rank, int32_t nranks, const void *unique_id);
@@ -237,6 +241,13 @@ int ggs_group_create(const ggs_config *cfg, int32_t n, const int32_t *device_ids
 void ggs_group_destroy(ggs_handle **handles, int32_t n);
 int ggs_group_set_z(ggs_handle **handles, int32_t n, const int32_t *const *z /* n pointers, each shard's N */, int32_t redraw_phi);
 int ggs_group_sweep(ggs_handle **handles, int32_t n, int32_t n_sweeps);
+/* The same group entry points over a CALLER-SUPPLIED transport (a JVM with collectives of its own): handles 0..n-1, each
+ * created by ggs_create and joined with ggs_attach_exchange(h_i, i, n, ops_i), are adopted as a one-process group.  The
+ * library then issues every collective step for handle 0, 1, .. n-1 in turn before any handle goes on to the next step
+ * -- the order ncclGroupStart/End gives the RCCL group -- so a transport that completes a collective only when all n
+ * handles have called it is never kept waiting by the calling thread (tests/test_native_exchange_gpu.py drives two
+ * handles from ONE thread this way). */
+int ggs_group_adopt(ggs_handle **handles, int32_t n);
 /* Corpus-wide counts onto every handle of the group.  The per-handle getters that need them (ggs_get_type_topic_counts,
  * ggs_get_topic_totals, ggs_check_invariants, the log likelihoods) would each start a collective of their own --
  * from one thread, for one device at a time, that cannot complete -- so a one-process driver calls this first; the

@@ -112,6 +112,7 @@ SIGNATURES = {
     "ggs_attach_rccl_comm": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),
     "ggs_group_create": (C.c_int, [C.POINTER(GGSConfig), C.c_int32, _ip, C.POINTER(_vp)]),
     "ggs_group_destroy": (None, [C.POINTER(_vp), C.c_int32]),
+    "ggs_group_adopt": (C.c_int, [C.POINTER(_vp), C.c_int32]),
     "ggs_group_set_z": (C.c_int, [C.POINTER(_vp), C.c_int32, C.POINTER(_ip), C.c_int32]),
     "ggs_group_sweep": (C.c_int, [C.POINTER(_vp), C.c_int32, C.c_int32]),
     "ggs_group_gather_counts": (C.c_int, [C.POINTER(_vp), C.c_int32]),

@@ -894,6 +894,19 @@ Exchange *new_rccl_exchange(ggs_handle *h, int32_t rank, int32_t nranks, int *rc
   return x;
 }
 
+// a collective step for every handle of the group: inside ncclGroupStart/End for RCCL; an adopted group (the caller's
+// transport) simply gets the calls one after the other, rank 0 first
+template <typename Step>
+int group_collective(ggs_handle **hs, int32_t n, Step step) {
+  RcclApi *api = hs[0]->xg->api;
+  int r = GGS_OK;
+  if (api) api->GroupStart();
+  for (int32_t i = 0; i < n && !r; ++i)
+    if (!(r = bind_device(hs[i]))) r = step(hs[i]);
+  if (api && api->GroupEnd() != ncclSuccess && !r) r = set_err(hs[0], GGS_ERR_HIP, "ncclGroupEnd failed");
+  return r;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1640,12 +1653,12 @@ namespace {
 bool is_group(ggs_handle **hs, int32_t n) {
   if (!hs || n < 1 || !hs[0] || (int32_t)hs[0]->group.size() != n) return false;
   for (int32_t i = 0; i < n; ++i)
-    if (hs[i] != hs[0]->group[(size_t)i] || !hs[i]->xg || !hs[i]->xg->api) return false;
+    if (hs[i] != hs[0]->group[(size_t)i] || !hs[i]->xg || hs[i]->xg->api != hs[0]->xg->api) return false;   // all RCCL, or all the caller's transport
   return true;
 }
+
 // the Phi phase for every handle of the group: each collective step for all devices inside ncclGroupStart/End
 int group_phi(ggs_handle **hs, int32_t n, bool initial, bool in_sweep) {
-  RcclApi *api = hs[0]->xg->api;
   std::vector<char> acc((size_t)n, 0);
   int rc = GGS_OK;
   for (int32_t i = 0; i < n && !rc; ++i) {
@@ -1659,17 +1672,7 @@ int group_phi(ggs_handle **hs, int32_t n, bool initial, bool in_sweep) {
     }
   }
   if (rc) return rc;
-  auto grouped = [&](auto step) {
-    int r = GGS_OK;
-    api->GroupStart();
-    for (int32_t i = 0; i < n && !r; ++i) {
-      ggs_handle *h = hs[i];
-      if ((r = bind_device(h))) break;
-      r = step(h, in_sweep ? &h->evs[h->ev_head] : nullptr);
-    }
-    if (api->GroupEnd() != ncclSuccess && !r) r = set_err(hs[0], GGS_ERR_HIP, "ncclGroupEnd failed");
-    return r;
-  };
+  auto grouped = [&](auto step) { return group_collective(hs, n, [&](ggs_handle *h) { return step(h, in_sweep ? &h->evs[h->ev_head] : nullptr); }); };
   // a step for every handle; events are recorded AFTER a grouped step: inside ncclGroupStart/End the collectives are
   // only collected, and an event recorded there would land on the stream before them
   auto each = [&](auto step) {
@@ -1702,20 +1705,9 @@ int group_phi(ggs_handle **hs, int32_t n, bool initial, bool in_sweep) {
 namespace {
 // corpus-wide counts on every handle of the group: the two collectives of ensure_global_counts, each grouped
 int group_gather_counts(ggs_handle **hs, int32_t n) {
-  RcclApi *api = hs[0]->xg->api;
-  auto grouped = [&](auto step) {
-    int r = GGS_OK;
-    api->GroupStart();
-    for (int32_t i = 0; i < n && !r; ++i) {
-      if ((r = bind_device(hs[i]))) break;
-      if (!hs[i]->counts_global) r = step(hs[i]);
-    }
-    if (api->GroupEnd() != ncclSuccess && !r) r = set_err(hs[0], GGS_ERR_HIP, "ncclGroupEnd failed");
-    return r;
-  };
   int rc;
-  if ((rc = grouped([](ggs_handle *h) { return exchange_reduce_scatter(h); }))) return rc;
-  if ((rc = grouped([](ggs_handle *h) { return gather_counts_step_gather(h); }))) return rc;
+  if ((rc = group_collective(hs, n, [](ggs_handle *h) { return h->counts_global ? GGS_OK : exchange_reduce_scatter(h); }))) return rc;
+  if ((rc = group_collective(hs, n, [](ggs_handle *h) { return h->counts_global ? GGS_OK : gather_counts_step_gather(h); }))) return rc;
   for (int32_t i = 0; i < n; ++i)
     if (!hs[i]->counts_global && ((rc = bind_device(hs[i])) || (rc = gather_counts_step_unslice(hs[i])))) return rc;
   return GGS_OK;
@@ -1753,6 +1745,17 @@ int ggs_group_create(const ggs_config *cfg, int32_t n, const int32_t *device_ids
     return rc;
   }
   out[0]->group.assign(out, out + n);
+  return GGS_OK;
+}
+
+int ggs_group_adopt(ggs_handle **hs, int32_t n) {
+  if (!hs || n < 1) return GGS_ERR_BAD_ARG;
+  for (int32_t i = 0; i < n; ++i) {
+    if (!hs[i]) return GGS_ERR_BAD_ARG;
+    if (!hs[i]->xg || hs[i]->xg->api) return set_err(hs[i], GGS_ERR_STATE, "ggs_group_adopt takes handles with a caller-supplied exchange (ggs_attach_exchange)");
+    if (hs[i]->xg->rank != i || hs[i]->xg->nranks != n) return set_err(hs[i], GGS_ERR_BAD_ARG, "ggs_group_adopt: handle i must be rank i of n");
+  }
+  hs[0]->group.assign(hs, hs + n);
   return GGS_OK;
 }
 

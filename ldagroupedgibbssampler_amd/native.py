@@ -289,8 +289,21 @@ class GGSGroup:
     """ONE process driving several GPUs (ggs_group_create): the handles of the group in rank order, joined by
     ncclCommInitAll; sweeps are issued for all devices from the calling thread."""
 
+    @classmethod
+    def adopt(cls, handles):
+        """ggs_group_adopt: handles 0..n-1, each already joined by attach_exchange(i, n, ...), driven as one group over
+        the caller's transport.  The group does not own the handles (close() leaves them alone)."""
+        self = cls.__new__(cls)
+        self._L = _lib.load()
+        n = len(handles)
+        self._arr = (C.c_void_p * n)(*[h._h for h in handles])
+        self.handles, self._owns = list(handles), False
+        self._chk(self._L.ggs_group_adopt(self._arr, n))
+        return self
+
     def __init__(self, num_topics, num_types, alpha, beta, seed, device_ids, flags=0, phi_burn_in=0, phi_mean_thin=1):
         self._L = _lib.load()
+        self._owns = True
         _lib.share_rccl_with_torch()
         cfg, keep = _make_config(num_topics, num_types, alpha, beta, seed, 0, flags, phi_burn_in, phi_mean_thin)
         n = len(device_ids)
@@ -320,9 +333,10 @@ class GGSGroup:
 
     def close(self):
         if getattr(self, "handles", None):
-            for h in self.handles:
-                h._h = None
-            self._L.ggs_group_destroy(self._arr, len(self.handles))
+            if getattr(self, "_owns", True):
+                for h in self.handles:
+                    h._h = None
+                self._L.ggs_group_destroy(self._arr, len(self.handles))
             self.handles = []
 
     def __del__(self):

@@ -883,6 +883,74 @@ static int tuned_doc_step(orc_state *s, int64_t d, int32_t *localTopicCounts, do
   }
   return ORC_OK;
 }
+/* The Phi draw of the tuned variant: the K * V gamma variates spread over all threads in (topic, 1024-type tile) units
+ * instead of one topic per thread (GGS:139-171 hands whole topics to `topic_batches` threads: at K = 100 at most 100 of
+ * the host's threads ever work).  Each topic's two V-long sums stay ONE sequential chain in index order (the magnitude of
+ * Dirichlet(double[]), ParallelDirichlet.java:53-57), so the result is orc_sample_phi's bit for bit. */
+static int tuned_sample_phi(orc_state *s) {
+  const int32_t K = s->K, V = s->V;
+  const int accumulate = s->save_phi_mean && sample_phi_this_iteration(s);
+  int err = ORC_OK;
+  double *magnitude = malloc(sizeof(double) * (size_t)K), *sum = malloc(sizeof(double) * (size_t)K);
+  const int32_t tile = 1024, ntiles = (V + tile - 1) / tile;
+#pragma omp parallel num_threads(s->threads)
+  {
+#pragma omp for schedule(static)
+    for (int32_t k = 0; k < K; k++) {
+      double m = 0;
+      const int32_t *c = s->n_kw + (size_t)k * V;
+      for (int32_t v = 0; v < V; v++) m += s->beta + c[v];
+      magnitude[k] = m;
+    }
+#pragma omp for schedule(dynamic, 4) collapse(2)
+    for (int32_t k = 0; k < K; k++)
+      for (int32_t t = 0; t < ntiles; t++) {
+        const int32_t v1 = (t + 1) * tile < V ? (t + 1) * tile : V;
+        for (int32_t v = t * tile; v < v1; v++) {
+          const double p = s->beta + s->n_kw[(size_t)k * V + v];
+          const double a = (p / magnitude[k]) * magnitude[k];
+          double *out = s->phi + (size_t)k * V + v;
+          if (!(a > 0)) {
+            *out = NAN;
+#pragma omp atomic write
+            err = ORC_ERR_BAD_ARG;
+            continue;
+          }
+          draw_rng r; draw_init(&r, s->seed, (uint32_t)s->iteration, ORC_PURPOSE_PHI, (uint64_t)k * V + (uint64_t)v);
+          *out = rgamma(&r, a);
+          if (r.exhausted) {
+#pragma omp atomic write
+            err = ORC_ERR_RNG_EXHAUSTED;
+          }
+        }
+      }
+#pragma omp for schedule(static)
+    for (int32_t k = 0; k < K; k++) {
+      double t = 0;
+      const double *g = s->phi + (size_t)k * V;
+      for (int32_t v = 0; v < V; v++) t += g[v];
+      sum[k] = t;
+    }
+#pragma omp for schedule(static) collapse(2)
+    for (int32_t k = 0; k < K; k++)
+      for (int32_t t = 0; t < ntiles; t++) {
+        const int32_t v1 = (t + 1) * tile < V ? (t + 1) * tile : V;
+        double *g = s->phi + (size_t)k * V;
+        for (int32_t v = t * tile; v < v1; v++) {
+          if (sum[k] != 0) {
+            g[v] /= sum[k];
+            if (g[v] <= 0) g[v] = 4.9e-324;          /* Double.MIN_VALUE */
+          }
+          if (accumulate) s->phi_mean[(size_t)k * V + v] += g[v];
+        }
+      }
+  }
+  free(magnitude); free(sum);
+  if (err) return fail(s, err, "phi draw failed");
+  if (accumulate) s->n_sampled_phi++;                                          /* GGS:168-170 */
+  return ORC_OK;
+}
+
 int orc_sweep_tuned(orc_state *s, int32_t n_sweeps) {
   s->err[0] = 0;
   if (s->scheme != 0) return fail(s, ORC_ERR_BAD_ARG, "orc_sweep_tuned: scheme ggs only");
@@ -932,7 +1000,7 @@ int orc_sweep_tuned(orc_state *s, int32_t n_sweeps) {
       }
     }
     if (err) return err;
-    int e = orc_sample_phi(s); if (e) return e;
+    int e = tuned_sample_phi(s); if (e) return e;
   }
   return ORC_OK;
 }

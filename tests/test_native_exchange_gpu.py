@@ -295,6 +295,97 @@ def test_one_process_group_api(native, oracle):
     g.close()
 
 
+class OneThreadTransport:
+    """A transport that completes a collective only when ALL n ranks have called it -- and is driven from ONE thread, the
+    way a JVM drives ggs_group_*: a call of rank i returns at once (nothing moved yet), the n-th call moves the data for
+    everybody.  A library that let one handle run ahead to a later step while another had not yet made this one would
+    find its step mismatched here (asserted), or wait for ever in a real transport."""
+
+    def __init__(self, n):
+        import torch
+        self.torch, self.n, self.dev = torch, n, torch.device("cuda", 0)
+        self.pending, self.kind, self.log = {}, None, []
+
+    def _view(self, ptr, count, typestr):
+        from ldagroupedgibbssampler_amd.sharded import _DevPtr
+        return self.torch.as_tensor(_DevPtr(ptr, count, typestr), device=self.dev)
+
+    def _arrive(self, kind, rank, send, recv, count):
+        assert self.kind in (None, kind), "rank %d calls %s while %s is still open" % (rank, kind, self.kind)
+        assert rank not in self.pending, "rank %d calls %s twice before its peers called it once" % (rank, kind)
+        assert rank == len(self.pending), "handles are issued in rank order"
+        self.kind = kind
+        self.pending[rank] = (send, recv, count)
+        if len(self.pending) < self.n:
+            return 0
+        self.torch.cuda.synchronize()
+        counts = {c for _, _, c in self.pending.values()}
+        assert len(counts) == 1
+        count = counts.pop()
+        typestr = "<f8" if kind == "ag64" else "<i4"
+        if kind == "rs":
+            total = sum(self._view(s_, count * self.n, typestr).clone() for s_, _, _ in self.pending.values())
+            for r, (_, recv_, _) in self.pending.items():
+                self._view(recv_, count, typestr).copy_(total[r * count:(r + 1) * count])
+        else:
+            parts = self.torch.cat([self._view(s_, count, typestr).clone() for _, (s_, _, _) in sorted(self.pending.items())])
+            for _, recv_, _ in self.pending.values():
+                self._view(recv_, count * self.n, typestr).copy_(parts)
+        self.torch.cuda.synchronize()
+        self.log.append(kind)
+        self.pending, self.kind = {}, None
+        return 0
+
+    def callbacks(self, rank):
+        return (lambda s_, r_, c, st: self._arrive("rs", rank, s_, r_, c), lambda s_, r_, c, st: self._arrive("ag64", rank, s_, r_, c),
+                lambda s_, r_, c, st: self._arrive("ag32", rank, s_, r_, c))
+
+
+@pytest.mark.parametrize("scheme", ["ggs", "pcgs", "collapsed"])
+def test_group_entry_points_from_one_thread_over_a_deferred_transport(native, oracle, scheme):
+    """ggs_group_adopt + ggs_group_set_z / ggs_group_sweep / ggs_group_gather_counts with TWO handles driven from one
+    thread -- the call order a JVM would use -- over a transport that moves data only when both handles have made the
+    call: every collective step is issued for all handles before any handle goes on, so nothing waits on a call that
+    the same thread has yet to make.  Results: the one-handle run's, bit for bit."""
+    c = random_corpus(170, 260, 70, seed=12, empty_every=7)
+    K, n = 13, 2
+    flags = {"ggs": 0, "pcgs": native.FLAG_PCGS, "collapsed": native.FLAG_COLLAPSED}[scheme]
+    tr = OneThreadTransport(n)
+    bounds = even_split(c.num_docs, n)
+    z0 = java_lcg_initial_z(c.num_tokens, K, 5)
+    hs, zs = [], []
+    for r in range(n):
+        h = native.GGSHandle(K, c.num_types, 0.1, 0.01, 606, flags=flags)
+        h.attach_exchange(r, n, *tr.callbacks(r))
+        sub, doc_base, tok_base = c.shard(bounds[r], bounds[r + 1])
+        h.set_corpus(sub.doc_ptr, sub.tokens, doc_base, tok_base)
+        h.set_global_token_count(c.num_tokens)
+        zs.append(z0[tok_base:tok_base + sub.num_tokens])
+        hs.append(h)
+    g = native.GGSGroup.adopt(hs)
+    g.set_z(zs, redraw_phi=True)
+    g.sweep(3)
+    g.gather_counts()
+    if scheme == "collapsed":
+        o = oracle.OracleSampler(K, c.num_types, 0.1, 0.01, 606, threads=2)
+        o.set_corpus(c.doc_ptr, c.tokens)
+        o.set_z(z0, redraw_phi=True)
+        # the doc-sharded parallel schedule is AD-LDA with a merge per sweep: the single-handle restatement of the same
+        # schedule sees the same sweep-start counts
+        o.collapsed_parallel_sweep(3)
+    else:
+        o = reference_run(oracle, c, K, 0.1, 0.01, 606, 5, 3, scheme)
+    assert_bit_equal(np.concatenate([h.get_z() for h in hs]), o.get_z(), scheme + " z")
+    for h in hs:
+        assert_bit_equal(h.get_type_topic_counts(), o.get_type_topic_counts(), scheme + " n_wk")
+        if scheme != "collapsed":
+            assert_bit_equal(h.get_phi(), o.get_phi(), scheme + " phi")
+    assert tr.log.count("rs") >= 4 and not tr.pending
+    g.close()
+    for h in hs:
+        h.close()
+
+
 def test_attach_order_and_errors(native):
     c = random_corpus(20, 50, 30, seed=1)
     h = native.GGSHandle(5, c.num_types, 0.1, 0.01, 1)

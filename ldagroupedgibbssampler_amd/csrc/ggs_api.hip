@@ -344,6 +344,7 @@ int phi_slice_gamma(ggs_handle *h, bool initial, const int32_t *cnt, int32_t cnt
   gp.ncg = (Ks + gp.kc - 1) / gp.kc;
   gp.seg_begin = seg0; gp.seg_end = seg1;
   gp.queue_cap = std::min(kPhiQueue, h->gamma_queue_cap);
+  gp.prio = h->xg ? 1 : 0;
   gp.guess = h->exact_sum ? h->d_sum_pref : nullptr; gp.fn = h->d_sum_fn;
   const int64_t tiles = (int64_t)(seg1 - seg0) * gp.ncg;
   // single-wave workgroups; a grid of at most 32 per CU, the rest by striding
@@ -382,7 +383,7 @@ int launch_phi_slice(ggs_handle *h, bool initial, const int32_t *cnt, int32_t cn
 //   B1    this rank's slice: magnitudes, the gammas of the first half of the vocabulary
 //   G0    all-gather of that half on the communication stream -- it runs UNDER step B2
 //   B2    the gammas of the second half, then the walk of the column sums (it needs every gamma of the slice)
-//   G1    all-gather of the second half with the Ksm column sums behind it, on the main stream
+//   G1    all-gather of the second half with the Ksm column sums behind it, on the main stream, issued behind G0
 //   C     repack [nranks][..] -> phiT [V][Kp], dividing by the owner's column sum on the way (the same IEEE division
 //         the one-GPU normalise kernel does: bit-identical) (+ the running phi mean)
 // What travels is therefore the UNNORMALISED gammas: the division does not have to wait for the slice to be complete
@@ -438,7 +439,9 @@ int launch_phi(ggs_handle *h, bool initial, bool accumulate_mean, Events *E = nu
     if (E) HIP_TRY(h, hipEventRecord(E->x[0], h->stream));
     if ((rc = phi_step_b1(h, initial)) || (rc = phi_step_g0(h)) || (rc = phi_step_b2(h, initial))) return rc;
     if (E) HIP_TRY(h, hipEventRecord(E->x[1], h->stream));
-    if ((rc = phi_step_g1(h)) || (rc = phi_join_halves(h))) return rc;
+    // the second all-gather is issued only behind the first: no two collectives of one communicator are ever in flight
+    // on different streams at once (they could not share the links anyway), whatever the transport does about that itself
+    if ((rc = phi_join_halves(h)) || (rc = phi_step_g1(h))) return rc;
     if (E) HIP_TRY(h, hipEventRecord(E->x[2], h->stream));
     return phi_step_c(h, accumulate_mean);
   }
@@ -1685,9 +1688,9 @@ int group_phi(ggs_handle **hs, int32_t n, bool initial, bool in_sweep) {
   if ((rc = grouped([](ggs_handle *h, Events *) { return phi_step_a(h); })) ||
       (rc = each([&](ggs_handle *h, Events *E) { int r = E ? record(h, E->x[0]) : GGS_OK; return r ? r : phi_step_b1(h, initial); })) ||
       (rc = grouped([](ggs_handle *h, Events *) { return phi_step_g0(h); })) ||
-      (rc = each([&](ggs_handle *h, Events *E) { int r = phi_step_b2(h, initial); return r ? r : (E ? record(h, E->x[1]) : GGS_OK); })) ||
+      (rc = each([&](ggs_handle *h, Events *E) { int r = phi_step_b2(h, initial); if (!r && E) r = record(h, E->x[1]); return r ? r : phi_join_halves(h); })) ||
       (rc = grouped([](ggs_handle *h, Events *) { return phi_step_g1(h); })) ||
-      (rc = each([&](ggs_handle *h, Events *E) { int r = phi_join_halves(h); return r ? r : (E ? record(h, E->x[2]) : GGS_OK); })))
+      (rc = each([&](ggs_handle *h, Events *E) { return E ? record(h, E->x[2]) : GGS_OK; })))
     return rc;
   for (int32_t i = 0; i < n; ++i) {
     ggs_handle *h = hs[i];

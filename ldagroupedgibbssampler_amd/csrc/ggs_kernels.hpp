@@ -354,6 +354,7 @@ struct PhiGammaParams {
   int32_t seg_begin, seg_end;   // the segments this launch draws (with an exchange the draw is cut in two, the first
                                 // half's all-gather running under the second half's draw)
   int32_t queue_cap;   // <= kPhiQueue (smaller only in tests)
+  int32_t prio;        // 1: ask for instruction issue ahead of the theta draw beside it
   // the segment functions of the gammas' column sums (ggs_exact_sum.hpp), computed by the workgroup that drew the tile;
   // guess = the EXACT running magnitude sums [nseg + 1][K] (E Gamma(a) = a).  Null: not wanted.
   const double *guess;
@@ -369,7 +370,11 @@ struct PhiGammaParams {
 constexpr int kPhiCols = 6, kPhiQueue = 128;
 
 __global__ __launch_bounds__(64) void phi_gamma_kernel(PhiGammaParams p) {
-  __builtin_amdgcn_s_setprio(1);       // ahead of the theta draw on the side stream (it has the whole Phi phase to finish), behind the chain's short kernels
+  // With an exchange the slice's draw is on the critical path and the next theta has the whole Phi phase to finish: issue
+  // ahead of the theta draw on the side stream (behind the chain's short kernels).  One GPU: the next z step waits for
+  // both draws, which share the VALUs -- no priority, so that they end together (with it the theta draw ended 0.17 ms
+  // after the Phi chain and the sweep was 0.02 ms longer).
+  if (p.prio) __builtin_amdgcn_s_setprio(1);
   __shared__ uint16_t queue[kPhiQueue];
   __shared__ int32_t qn;
   __shared__ double acc_lo[kPhiCols], acc_hi[kPhiCols];

@@ -1,7 +1,8 @@
 // walk_probe -- the exact column sums of ggs_exact_sum.hpp on their own (no theta draw beside them): kernel times by
 // hipEvent and, for the wave of topic 0, 100 MHz timestamps at the walk's phases + how its steps split into accepted
 // runs / element-path segments with rows fetched ahead / fetched on the spot.
-//   hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -DGGS_WALK_TRACE -I ldagroupedgibbssampler_amd/csrc -o walk_probe scripts/probes/walk_probe.hip
+//   hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -DGGS_WALK_TRACE=1 -I ldagroupedgibbssampler_amd/csrc -o scripts/bin/walk_probe scripts/probes/walk_probe.hip
+//   (-DGGS_WALK_TRACE=2 adds the step counters)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -49,10 +50,13 @@ int main(int argc, char **argv) {
   unsigned long long tr[128]; hipMemcpyFromSymbol(tr, HIP_SYMBOL(g_walk_trace), sizeof tr);
   printf("topic 0, last launch (us since kernel entry): prologue done %.2f", (tr[1] - tr[0]) / 100.0);
   for (int it = 0; it * kWalkSuper < nseg && it < 18; ++it) printf(" | sg%d walked %.2f staged %.2f", it, (tr[2 + 2 * it] - tr[0]) / 100.0, (tr[3 + 2 * it] - tr[0]) / 100.0);
-  printf("\nsteps over 11 launches: %llu accepted runs, %llu element-path segments with rows ahead, %llu fetched on the spot\n", tr[40], tr[41], tr[42]);
+  printf("\n");
+#if GGS_WALK_TRACE > 1   // the step counters are global read-modify-writes: they distort the times above, so they are a build of their own
+  printf("steps over 11 launches: %llu accepted runs, %llu element-path segments with rows ahead, %llu fetched on the spot\n", tr[40], tr[41], tr[42]);
   printf("per super-group (runs/rows ahead/on the spot):");
   for (int it = 0; it * kWalkSuper < nseg && it < 16; ++it) printf(" sg%d %llu/%llu/%llu", it, tr[64 + it], tr[80 + it], tr[96 + it]);
   printf("\n");
+#endif
   std::vector<double> out(K); hipMemcpy(out.data(), d_out, K * 8, hipMemcpyDeviceToHost);
   int bad = 0;
   for (int k = 0; k < K; ++k) {

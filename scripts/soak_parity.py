@@ -30,7 +30,7 @@ def main():
     test, _, _ = c.shard(cut, args.docs)
     K = args.topics
     g = native.GGSHandle(K, c.num_types, 0.1, 0.01, 2019, flags=native.FLAG_PCGS if args.scheme == "pcgs" else 0)
-    o = O.OracleSampler(K, c.num_types, 0.1, 0.01, 2019, threads=os.cpu_count() or 1)
+    o = O.OracleSampler(K, c.num_types, 0.1, 0.01, 2019, threads=min(32, os.cpu_count() or 1))   # the GPU box gives a process a fraction of its 256 hardware threads: more are slower
     o.set_scheme(args.scheme)
     for s in (g, o):
         s.set_corpus(train.doc_ptr, train.tokens)

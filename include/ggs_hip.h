@@ -16,6 +16,8 @@
  * handle is driven by ONE coordinator thread (as the Java sampler is,
  * UPLDA:552-943).  Host layouts mirror the Java getters: counts are
  * int32 [V][K] (getTypeTopicMatrix), Phi is double [K][V] (getPhi).
+ * The library reads no environment variable in normal use; its GGS_DEBUG_* knobs (kernel selection, proof margins,
+ * overlaps: tests and experiments) are honoured only when GGS_DEBUG=1 is set as well.
  *
  * One handle = one GPU.  Several live handles on the SAME device in one process are correct but slow: each brings
  * three streams and the runtime multiplexes all of them onto the device's few hardware queues (measured: a second

@@ -27,6 +27,13 @@ using namespace ggs;
 
 namespace {
 
+// The GGS_DEBUG_* variables select kernels, scale proof margins and switch overlaps off: experiments and tests.  A
+// production process must not pick one up by accident, so they are only read when GGS_DEBUG=1 is set as well.
+const char *debug_env(const char *name) {
+  static const bool enabled = [] { const char *e = std::getenv("GGS_DEBUG"); return e && std::atoi(e) == 1; }();
+  return enabled ? std::getenv(name) : nullptr;
+}
+
 constexpr int kThetaBlock = 256;
 constexpr int kMaxLdsBytes = 160 * 1024;
 
@@ -338,7 +345,7 @@ int phi_slice_gamma(ggs_handle *h, bool initial, const int32_t *cnt, int32_t cnt
   // is a thinner leftover queue per tile (the general rejection loops then run with fewer lanes in use).
   const int64_t want_tiles = (int64_t)h->num_cus * 4 * 4;
   int kc_cap = (int)std::min<int64_t>(kPhiCols, std::max<int64_t>(2, (int64_t)Ks * (seg1 - seg0) / want_tiles));
-  if (const char *e = std::getenv("GGS_DEBUG_PHICOLS")) kc_cap = std::max(1, std::min(kPhiCols, std::atoi(e)));
+  if (const char *e = debug_env("GGS_DEBUG_PHICOLS")) kc_cap = std::max(1, std::min(kPhiCols, std::atoi(e)));
   gp.ncg = (Ks + kc_cap - 1) / kc_cap;
   gp.kc = (Ks + gp.ncg - 1) / gp.ncg;
   gp.ncg = (Ks + gp.kc - 1) / gp.kc;
@@ -589,7 +596,7 @@ int launch_z(ggs_handle *h, bool force_fused = false, int64_t c0 = 0, int64_t c1
       HIP_TRY(h, hipEventRecord(h->ev_hot_fork, h->stream));
       HIP_TRY(h, hipStreamWaitEvent(h->side_hot, h->ev_hot_fork, 0));
       zp.num_chunks = h->Cc; zp.num_hot = 0;
-      static const int only = std::getenv("GGS_DEBUG_ONLY") ? std::atoi(std::getenv("GGS_DEBUG_ONLY")) : 0;   // timing experiments: 1 cold only, 2 hot only
+      static const int only = debug_env("GGS_DEBUG_ONLY") ? std::atoi(debug_env("GGS_DEBUG_ONLY")) : 0;   // timing experiments: 1 cold only, 2 hot only
       if (only != 2) HIP_TRY(h, hipLaunchKernel(sliced_kernel_for(h->K), grid_of(h->Cc), sblock, args, (size_t)(kSlicedWaves * h->wave_lds), h->stream));
       if (only != 1) HIP_TRY(h, hipLaunchKernel(hot_kernel_for(h->K), grid_of(h->Cs - h->Cc), sblock, hargs, (size_t)(hp.hot_off + h->num_hot * h->hot_pitch), h->side_hot));
       HIP_TRY(h, hipEventRecord(h->ev_hot_join, h->side_hot));
@@ -831,7 +838,7 @@ int setup_exchange(ggs_handle *h, Exchange *x) {
   // the all-gather of the gammas in two halves of the vocabulary (whole 64-row segments: the draw's tiles); a short
   // vocabulary goes in one
   h->seg_split = h->sum_nseg >= 16 ? h->sum_nseg / 2 : 0;
-  if (const char *e = std::getenv("GGS_DEBUG_AGSPLIT")) h->seg_split = std::max(0, std::min(h->sum_nseg - 1, std::atoi(e)));
+  if (const char *e = debug_env("GGS_DEBUG_AGSPLIT")) h->seg_split = std::max(0, std::min(h->sum_nseg - 1, std::atoi(e)));
   h->v_split = h->seg_split * kSumSegRows;
   const size_t slice = (size_t)h->V * h->Ksm, all = slice * (size_t)x->nranks;
   auto fail = [&](int code) {                        // a half-built exchange must not stay attached
@@ -869,7 +876,7 @@ int setup_exchange(ggs_handle *h, Exchange *x) {
     // other libraries' blocking streams is exactly the convention not to rely on.  HIGH priority: measured with RCCL
     // and a torch process group in the process, a normal-priority stream shares its hardware queue with theirs and the
     // sweep's phases stretch (one rank: 2.59 ms per sweep against 1.93 on a high-priority stream or the null stream).
-    static const bool stay = std::getenv("GGS_DEBUG_OWN_STREAM") && std::atoi(std::getenv("GGS_DEBUG_OWN_STREAM")) == 0;   // experiments
+    static const bool stay = debug_env("GGS_DEBUG_OWN_STREAM") && std::atoi(debug_env("GGS_DEBUG_OWN_STREAM")) == 0;   // experiments
     if (!stay) {
       int lo = 0, hi = 0;
       (void)hipDeviceGetStreamPriorityRange(&lo, &hi);
@@ -934,7 +941,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
   h->beta = cfg->beta; h->seed = cfg->seed; h->flags = cfg->flags;
   if (h->flags & GGS_FLAG_COLLAPSED) { h->collapsed = true; h->flags |= GGS_FLAG_PCGS; }   // the lane-per-document z loop, a different matrix
   h->phi_burn_in = cfg->phi_burn_in; h->phi_thin = cfg->phi_mean_thin > 0 ? cfg->phi_mean_thin : 1;
-  if (const char *ab = std::getenv("GGS_DEBUG_ABLATE")) h->ablate = std::atoi(ab);
+  if (const char *ab = debug_env("GGS_DEBUG_ABLATE")) h->ablate = std::atoi(ab);
   h->alpha.assign(h->K, cfg->alpha_scalar);
   if (cfg->alpha) std::copy(cfg->alpha, cfg->alpha + h->K, h->alpha.begin());
   for (double a : h->alpha)
@@ -966,7 +973,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     const bool sliced_ok = h->K <= kSlicedMaxTopics && h->V < (1 << kSlotShift);
     h->z_sliced = sliced_ok && h->K <= 184;
     h->z_stream = !h->z_sliced && h->K > 2 * kSliceTopics;
-    if (const char *e = std::getenv("GGS_DEBUG_ZKERNEL")) {          // 0: whole-row tile kernel, 1: sliced where possible, 2: streaming kernel where it applies, 3: its two-pass form
+    if (const char *e = debug_env("GGS_DEBUG_ZKERNEL")) {          // 0: whole-row tile kernel, 1: sliced where possible, 2: streaming kernel where it applies, 3: its two-pass form
       const int mode = std::atoi(e);
       h->z_sliced = sliced_ok && mode == 1;
       h->z_stream = (mode == 2 || mode == 3) ? h->K > 2 * kSliceTopics : (h->z_stream && mode != 0);
@@ -974,7 +981,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       if (h->z_sliced) h->z_stream = false;
     }
     // only values above 1 are meaningful (they force the exact replay in tests); anything below would void the proof
-    if (const char *e = std::getenv("GGS_DEBUG_MARGIN")) h->margin_scale = std::max(1.0, std::atof(e));
+    if (const char *e = debug_env("GGS_DEBUG_MARGIN")) h->margin_scale = std::max(1.0, std::atof(e));
     if (h->z_stream) {
       // 64-token chunks, a 2-slot slice ring + the theta row zero-padded to whole slices (one-pass kernel: to whole
       // checkpoint groups, plus a checkpoint per group and lane); no score registers, so 8 waves per CU fit the
@@ -983,17 +990,17 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       const int ns = (h->K + kSliceTopics - 1) / kSliceTopics;
       // checkpoint group: the smallest that keeps the checkpoints in registers (K <= 256: one slice, <= 512: two, <= 1024: four); beyond, four slices and LDS
       h->z_group = ns <= kRegCheckpoints ? 1 : ns <= 2 * kRegCheckpoints ? 2 : 4;
-      if (const char *e = std::getenv("GGS_DEBUG_GROUP")) { const int gq = std::atoi(e); if (gq == 1 || gq == 2 || gq == 4) h->z_group = gq; }
+      if (const char *e = debug_env("GGS_DEBUG_GROUP")) { const int gq = std::atoi(e); if (gq == 1 || gq == 2 || gq == 4) h->z_group = gq; }
       const int ng = (ns + h->z_group - 1) / h->z_group;
       h->z_regck = !h->z_two_pass && ng <= kRegCheckpoints;          // checkpoints in registers or in LDS
-      if (const char *e = std::getenv("GGS_DEBUG_REGCK")) h->z_regck = h->z_regck && std::atoi(e) != 0;
+      if (const char *e = debug_env("GGS_DEBUG_REGCK")) h->z_regck = h->z_regck && std::atoi(e) != 0;
       if (!h->z_regck) h->z_group = 4;                               // the LDS-checkpoint kernel is instantiated for groups of four
       const int ngl = (ns + h->z_group - 1) / h->z_group;
       // Chunks of 64 consecutive tokens across ONE document boundary (two theta rows per wave) instead of near-equal
       // cuts of single documents: 98 % of the lanes busy instead of 78 % at 200-token documents.  Where the second row
       // would cost resident waves (K > 512: 8 KiB at K = 1024) the single-document chunks stay.
       h->z_two_rows = !h->z_two_pass && h->K <= 512;
-      if (const char *e = std::getenv("GGS_DEBUG_TWOROWS")) h->z_two_rows = !h->z_two_pass && std::atoi(e) != 0;
+      if (const char *e = debug_env("GGS_DEBUG_TWOROWS")) h->z_two_rows = !h->z_two_pass && std::atoi(e) != 0;
       h->z_lds = h->z_two_pass ? kStreamRingSlots * kSliceBytes + ns * kSliceTopics * 8
                                : kStream1RingSlots * kSliceBytes + (h->z_two_rows ? 2 : 1) * ngl * h->z_group * kSliceTopics * 8 + (h->z_regck ? 0 : ngl * 64 * 8);
       if (h->z_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);   // K > ~16000: the theta row itself would need slicing
@@ -1001,7 +1008,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       // to the last granule: measured, 5 x 32 KiB and 4 x 40 KiB leave one workgroup waiting for a second round
       // (z at K = 1024: 18.6 ms with 5 waves of 32 KiB requested, 12.7 ms with 4)
       h->z_waves_per_cu = std::max(1, std::min(8, (kMaxLdsBytes - kGranule) / alloc_of(h->z_lds)));
-      if (const char *e = std::getenv("GGS_DEBUG_WPC")) h->z_waves_per_cu = std::max(1, std::atoi(e));
+      if (const char *e = debug_env("GGS_DEBUG_WPC")) h->z_waves_per_cu = std::max(1, std::atoi(e));
     } else if (h->z_sliced) {
       // 64-token chunks, per wave the two theta rows and the slice ring, per workgroup (4 waves, one per SIMD) the hot-word table
       // (the score registers take most of the 512-entry file)
@@ -1012,25 +1019,25 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       h->ring_base = (std::max(kChunkDocs * kmax * 8, ns * 128) + 255) / 256 * 256;
       h->wave_lds = h->ring_base + kRingSlots * kSliceBytes;
       h->hot_pitch = ((h->K + 7) / 8) * 64 + 16;                     // KMAX doubles + one unit: an odd number of 16-byte units
-      if (const char *e = std::getenv("GGS_DEBUG_SPLIT")) h->z_split = std::atoi(e) != 0;
+      if (const char *e = debug_env("GGS_DEBUG_SPLIT")) h->z_split = std::atoi(e) != 0;
       h->z_split_allowed = h->z_split;
       h->hot_wave_lds = (kChunkDocs * kmax * 8 + 255) / 256 * 256;   // z_hot_kernel: two theta rows per wave, then the table
       // split: the two workgroups must fit one CU together, each request rounded up to the LDS allocation granule
       h->hot_cap = h->z_split ? (kMaxLdsBytes - alloc_of(kSlicedWaves * h->wave_lds) - kSlicedWaves * h->hot_wave_lds) / kGranule * kGranule / h->hot_pitch
                               : (kMaxLdsBytes - kSlicedWaves * h->wave_lds) / h->hot_pitch;
       h->hot_cap = std::max(0, std::min(255, h->hot_cap));
-      if (const char *e = std::getenv("GGS_DEBUG_HOT")) h->hot_cap = std::max(0, std::min(h->hot_cap, std::atoi(e)));
+      if (const char *e = debug_env("GGS_DEBUG_HOT")) h->hot_cap = std::max(0, std::min(h->hot_cap, std::atoi(e)));
       h->z_lds = kSlicedWaves * h->wave_lds + h->hot_cap * h->hot_pitch;
       h->z_waves_per_cu = kSlicedWaves;
     } else {
     int T = (kMaxLdsBytes / 6 / kGranule * kGranule - thbytes) / pitch;
-    if (const char *e = std::getenv("GGS_DEBUG_TILE")) T = std::atoi(e);
+    if (const char *e = debug_env("GGS_DEBUG_TILE")) T = std::atoi(e);
     T = std::max(8, std::min(64, T));
     h->z_tile_tokens = T;
     h->z_lds = T * pitch + thbytes;
     if (h->z_lds > kMaxLdsBytes) return bail(GGS_ERR_UNSUPPORTED);   // K > ~2400 needs a K-sliced kernel (not in this round)
     h->z_waves_per_cu = std::max(1, std::min(8, (kMaxLdsBytes - kGranule) / alloc_of(h->z_lds)));
-    if (const char *e = std::getenv("GGS_DEBUG_WPC")) h->z_waves_per_cu = std::max(1, std::atoi(e));
+    if (const char *e = debug_env("GGS_DEBUG_WPC")) h->z_waves_per_cu = std::max(1, std::atoi(e));
     }
   }
   {
@@ -1049,11 +1056,11 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     // K > 192 (one-pass streaming z kernel): theta workgroups small enough to sit BESIDE the z waves -- three of
     // them, on the LDS the z waves give up -- so that the next theta of a part of the documents is drawn while the
     // following parts are sampled (z_phase).  The padded request caps them at three per CU while z runs.
-    if (const char *e = std::getenv("GGS_DEBUG_ZPARTS")) h->z_parts = std::max(1, std::min(8, std::atoi(e)));
+    if (const char *e = debug_env("GGS_DEBUG_ZPARTS")) h->z_parts = std::max(1, std::min(8, std::atoi(e)));
     else h->z_parts = (h->z_stream && !h->z_two_pass && !(h->flags & GGS_FLAG_PCGS)) ? 8 : 1;   // measured at K = 1024: 1 part 18.4 ms per sweep, 2: 18.1, 4: 16.5, 8: 15.9
     if (h->z_parts > 1 && h->z_stream && !h->z_two_pass) {
       constexpr int kGranule = 2048;
-      const int kBeside = std::getenv("GGS_DEBUG_BESIDE") ? std::max(1, std::atoi(std::getenv("GGS_DEBUG_BESIDE"))) : 4;   // measured at K = 1024 (sweep): 2 -> 16.9 ms, 3 -> 16.1, 4 -> 15.0, 5 -> 15.0
+      const int kBeside = debug_env("GGS_DEBUG_BESIDE") ? std::max(1, std::atoi(debug_env("GGS_DEBUG_BESIDE"))) : 4;   // measured at K = 1024 (sweep): 2 -> 16.9 ms, 3 -> 16.1, 4 -> 15.0, 5 -> 15.0
       auto alloc_of = [&](int bytes) { return (bytes + kGranule - 1) / kGranule * kGranule; };
       int Bt = 64;
       while (Bt > 1 && lds_of(Bt) > 10 * 1024) Bt >>= 1;
@@ -1092,8 +1099,8 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       (rc = dev_alloc(h, &h->d_n_k, h->K)) || (rc = dev_alloc(h, &h->d_status, 4)))
     return bail(rc);
   if ((h->flags & GGS_FLAG_SAVE_PHI_MEAN) && (rc = dev_alloc(h, &h->d_phi_mean, kv))) return bail(rc);
-  if (const char *e = std::getenv("GGS_DEBUG_CHAIN")) h->exact_sum = std::atoi(e) == 0;
-  if (const char *e = std::getenv("GGS_DEBUG_GUIDED")) h->sum_guided = std::atoi(e) != 0;
+  if (const char *e = debug_env("GGS_DEBUG_CHAIN")) h->exact_sum = std::atoi(e) == 0;
+  if (const char *e = debug_env("GGS_DEBUG_GUIDED")) h->sum_guided = std::atoi(e) != 0;
   h->sum_nseg = (h->V + kSumSegRows - 1) / kSumSegRows;
   if (h->exact_sum && ((rc = dev_alloc(h, &h->d_sum_pref, ((size_t)h->sum_nseg + 1) * h->K)) ||
                        (rc = dev_alloc(h, &h->d_sum_fn, (size_t)h->sum_nseg * h->K * 4))))
@@ -1116,14 +1123,14 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       h->pcgs_wave_waves_per_cu = std::max(1, std::min(4 * per_simd, (kMaxLdsBytes - 2048) / ((h->pcgs_wave_lds + 2047) / 2048 * 2048)));
     }
     h->pcgs_wave_forced = h->K > kPcgsWaveFromTopics;
-    if (const char *e = std::getenv("GGS_DEBUG_PCGS_WAVE")) h->pcgs_wave_forced = std::atoi(e) != 0;
+    if (const char *e = debug_env("GGS_DEBUG_PCGS_WAVE")) h->pcgs_wave_forced = std::atoi(e) != 0;
     if (h->pcgs_wave_forced && !h->pcgs_wave_nb) return bail(GGS_ERR_UNSUPPORTED);   // more than 4096 topics
     if (h->pcgs_wave_nb && hipFuncSetAttribute(pcgs_wave_kernel_for(h->pcgs_wave_nb, h->collapsed), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess)
       return bail(GGS_ERR_HIP);
     // pcgs_z_kernel: slice ring + alpha row + int16 [KT][64] document counts per single-wave workgroup
     const int ns = std::max(kPcgsRingSlots - 1, (h->K + kSliceTopics - 1) / kSliceTopics), kt = ns * kSliceTopics;
     h->pcgs_sliced = h->K <= kSlicedMaxTopics;
-    if (const char *e = std::getenv("GGS_DEBUG_PCGS_STREAM")) h->pcgs_sliced = h->pcgs_sliced && std::atoi(e) == 0;
+    if (const char *e = debug_env("GGS_DEBUG_PCGS_STREAM")) h->pcgs_sliced = h->pcgs_sliced && std::atoi(e) == 0;
     if (h->pcgs_sliced) {
       const int kmax = ((h->K + 7) / 8) * 8;                       // alpha row + counts below the ring (pcgs_sliced_kernel's kHead)
       h->pcgs_lds = (kmax * 8 + kmax * 128 + 255) / 256 * 256 + kPcgsRingSlots * kSliceBytes;
@@ -1150,8 +1157,8 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       if (hipEventCreate(&e) != hipSuccess) return bail(GGS_ERR_HIP);
     if (hipEventCreate(&E.th0) != hipSuccess || hipEventCreate(&E.th1) != hipSuccess) return bail(GGS_ERR_HIP);
   }
-  if (const char *e = std::getenv("GGS_DEBUG_NO_OVERLAP")) h->overlap_theta = std::atoi(e) == 0;
-  if (const char *e = std::getenv("GGS_DEBUG_GAMMA_QUEUE")) h->gamma_queue_cap = std::max(0, std::atoi(e));
+  if (const char *e = debug_env("GGS_DEBUG_NO_OVERLAP")) h->overlap_theta = std::atoi(e) == 0;
+  if (const char *e = debug_env("GGS_DEBUG_GAMMA_QUEUE")) h->gamma_queue_cap = std::max(0, std::atoi(e));
   {
     // lowest priority: the theta draw fills whatever the Phi phase (on the caller's stream) leaves idle
     int lo = 0, hi = 0;
@@ -2066,7 +2073,7 @@ int ggs_heldout_log_likelihood(ggs_handle *h, int32_t num_particles, double *doc
   // wordProbabilities of a batch of documents: tokens x particles doubles, at most ~4 GiB at a time (one launch for
   // the 2 M-token test set of the benchmark: every extra launch has its own tail of half-empty CUs)
   int64_t want_cells = (int64_t)1 << 29;
-  if (const char *e = std::getenv("GGS_DEBUG_HELDOUT_CELLS")) want_cells = std::max<int64_t>(1, std::atoll(e));   // tests: force several batches
+  if (const char *e = debug_env("GGS_DEBUG_HELDOUT_CELLS")) want_cells = std::max<int64_t>(1, std::atoll(e));   // tests: force several batches
   int64_t longest = 1;
   for (int64_t d = 0; d < D; ++d) longest = std::max(longest, h->test_ptr[d + 1] - h->test_ptr[d]);
   const int64_t cap_cells = std::max<int64_t>(want_cells, longest * num_particles);                                 // a document is never split

@@ -1,3 +1,4 @@
+export GGS_DEBUG=1   # the library reads GGS_DEBUG_* only with this opt-in
 # timing-only compile-time ablations of z_sliced_kernel (scripts/bin/libggs_abl<N>.so built with -DGGS_ABL=N:
 # 1 no DMA, 2 no walk, 4 no score pass); results are wrong on purpose
 mkdir -p gpurun_out

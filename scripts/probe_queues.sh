@@ -1,4 +1,5 @@
 #!/bin/bash
+export GGS_DEBUG=1   # the library reads GGS_DEBUG_* only with this opt-in
 # How the phases of a one-rank RCCL run (bench.py --force-sharded) react to the stream / hardware-queue settings
 cd $GRAFT_REPO_ROOT; out=gpurun_out/probe_queues; mkdir -p $out
 run() { tag=$1; shift; timeout -k 10 300 env "$@" python3 bench.py --force-sharded --no-cpu-baseline --steps 10 $EXTRA > $out/$tag.json 2> $out/$tag.err || { tail -3 $out/$tag.err; return; }

@@ -1,4 +1,5 @@
 #!/bin/bash
+export GGS_DEBUG=1   # the library reads GGS_DEBUG_* only with this opt-in
 # z_stream1_kernel ring depth (scripts/bin/libggs_ring<R>.so built with -DGGS_STREAM1_RING=R) at K=1024 / 500 / 200
 cd $GRAFT_REPO_ROOT
 for r in ${RINGS:-2 3 4}; do

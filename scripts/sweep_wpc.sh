@@ -1,4 +1,5 @@
 #!/bin/bash
+export GGS_DEBUG=1   # the library reads GGS_DEBUG_* only with this opt-in
 # waves per CU x ring depth of z_stream1_kernel
 cd $GRAFT_REPO_ROOT
 while read r k w; do

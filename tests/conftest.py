@@ -10,6 +10,8 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # the library reads its GGS_DEBUG_* knobs (kernel selection, proof margins: what several tests force) only with this opt-in
+    os.environ["GGS_DEBUG"] = "1"
 
 
 @pytest.fixture(scope="session")

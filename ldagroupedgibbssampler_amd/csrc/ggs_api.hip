@@ -1117,10 +1117,12 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       int nb = 1;
       while (nb * 128 < h->Kp) nb *= 2;
       h->pcgs_wave_nb = nb;
-      h->pcgs_wave_lds = nb * 128 * 20;
-      // waves per CU: what LDS allows, and what the kernel's registers allow (8, 8, 7, 4, 2, 1 waves per SIMD for NB = 1 .. 32)
-      const int per_simd = nb <= 2 ? 8 : nb == 4 ? 7 : nb == 8 ? 4 : nb == 16 ? 2 : 1;
-      h->pcgs_wave_waves_per_cu = std::max(1, std::min(4 * per_simd, (kMaxLdsBytes - 2048) / ((h->pcgs_wave_lds + 2047) / 2048 * 2048)));
+      h->pcgs_wave_lds = nb * 128 * 12;                        // counts int32 + alpha fp64
+      // waves per CU (the grid is persistent: exactly what is resident): what the kernel's registers allow (asked of the
+      // runtime) and what LDS allows (computed here: the runtime's answer ignores the 2 KiB allocation granule)
+      int by_regs = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&by_regs, pcgs_wave_kernel_for(nb, h->collapsed), 64, (size_t)h->pcgs_wave_lds) != hipSuccess || by_regs < 1) by_regs = 1;
+      h->pcgs_wave_waves_per_cu = std::max(1, std::min(std::min(by_regs, 32), (kMaxLdsBytes - 2048) / ((h->pcgs_wave_lds + 2047) / 2048 * 2048)));
     }
     h->pcgs_wave_forced = h->K > kPcgsWaveFromTopics;
     if (const char *e = debug_env("GGS_DEBUG_PCGS_WAVE")) h->pcgs_wave_forced = std::atoi(e) != 0;

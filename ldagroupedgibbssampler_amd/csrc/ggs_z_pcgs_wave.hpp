@@ -21,14 +21,14 @@
 //   so the first k with d_k < -delta is Java's topic provided d_{k-1} > delta.
 // A token is undecided only if U * S falls within delta of one of the K prefixes (probability ~ K^2 * 2^-50); such a
 // token, one whose U * sum is 0 and one whose walk would leave [0, K) are replayed exactly as Java does it, element by
-// element over the scores (kept in LDS), and raise what Java raises.  GGS_DEBUG_MARGIN scales delta up: the tests send
+// element over the scores (read lane by lane out of the registers that hold them), and raise what Java raises.  GGS_DEBUG_MARGIN scales delta up: the tests send
 // nearly every token through the replay, and both ways give the oracle's bits.
 // The scores themselves, ((double)n_dk + alpha_k) * phi[k][w], are the same two roundings as in Java, per element.
 //
 // Layout: a lane owns the 16-byte units u = lane + 64 j (topics 2u, 2u + 1) of a row, j < NB: every load instruction of
 // the wave reads 1 KiB of consecutive bytes of the row, and block j (topics 128 j .. 128 j + 127) is in lane order.
 // The next token's row is loaded into a second register set while the current token is computed.
-// LDS per wave: counts int32 [128 NB], alpha and the scores fp64 [128 NB] each: 20 KiB at K = 1024.
+// LDS per wave: counts int32 [128 NB] and alpha fp64 [128 NB]: 12 KiB at K = 1024.
 #pragma once
 #include "ggs_z_pcgs.hpp"
 
@@ -40,7 +40,6 @@ __global__ __launch_bounds__(64) void pcgs_wave_kernel(PcgsParams p, double marg
   extern __shared__ __align__(16) unsigned char smem[];
   int32_t *cnt = reinterpret_cast<int32_t *>(smem);                        // [KT]
   double *alb = reinterpret_cast<double *>(smem + (size_t)KT * 4);         // [KT] alpha, zero padded
-  double *scs = alb + KT;                                                  // [KT] the current token's scores
   const int lane = threadIdx.x, K = p.K;
   const int units = p.Kp / 2;                                              // 16-byte units per phiT row (Kp is even; a padding column holds 0)
 
@@ -101,18 +100,24 @@ __global__ __launch_bounds__(64) void pcgs_wave_kernel(PcgsParams p, double marg
       if (lane == 0) cnt[zold] -= 1;                                       // UPLDA:1494
       __syncthreads();
 
-      // scores of this lane's topics (UPLDA:1509-1513 / MSLDA:196-203), block sums in any order: a proposal only
-      double tot[NB];                                                      // wave-uniform (scalar registers)
-#pragma unroll
-      for (int j = 0; j < NB; ++j) {
+      // scores of this lane's two topics of block j (UPLDA:1509-1513 / MSLDA:196-203): the same two roundings as in Java.
+      // They are recomputed where they are needed again (the deciding block; the replay): keeping K doubles per wave in
+      // LDS for that cost half of the resident waves, and waves in flight are what this kernel's row traffic lives on
+      // (K = 1024: 27.0 ms per z step with 7 waves per CU, 20.2 with 12).
+      auto scores = [&](int j, double pa, double pb, double &qa, double &qb) {
         const int k = 2 * (lane + 64 * j);
         const int2 n = *reinterpret_cast<const int2 *>(&cnt[k]);
         const double2 al = *reinterpret_cast<const double2 *>(&alb[k]);
-        double pa = cur.a[j], pb = cur.b[j];
         if (COLLAPSED) { if (k == zold) pa = own; if (k + 1 == zold) pb = own; }
-        const double qa = k < K ? ((double)n.x + al.x) * pa : 0.0;
-        const double qb = k + 1 < K ? ((double)n.y + al.y) * pb : 0.0;
-        *reinterpret_cast<double2 *>(&scs[k]) = double2{qa, qb};
+        qa = k < K ? ((double)n.x + al.x) * pa : 0.0;
+        qb = k + 1 < K ? ((double)n.y + al.y) * pb : 0.0;
+      };
+      // block sums in any order: a proposal only
+      double tot[NB];                                                      // wave-uniform (scalar registers)
+#pragma unroll
+      for (int j = 0; j < NB; ++j) {
+        double qa, qb;
+        scores(j, cur.a[j], cur.b[j], qa, qb);
         tot[j] = read_lane(wave_inclusive_scan(qa + qb), 63);
       }
       double s_hat = 0.0;
@@ -133,8 +138,12 @@ __global__ __launch_bounds__(64) void pcgs_wave_kernel(PcgsParams p, double marg
             else before += tot[j];
           }
         if (js >= 0) {
-          const double2 ab = *reinterpret_cast<const double2 *>(&scs[2 * (lane + 64 * js)]);   // this lane's own two scores of the block
-          const double a = ab.x, b = ab.y;
+          double pa = 0.0, pb = 0.0;                                       // this lane's row entries of block js (a static select: registers are not indexable)
+#pragma unroll
+          for (int j = 0; j < NB; ++j)
+            if (j == js) { pa = cur.a[j]; pb = cur.b[j]; }
+          double a, b;
+          scores(js, pa, pb, a, b);
           const double c_ab = before + wave_inclusive_scan(a + b), c_a = c_ab - b;   // prefixes after this lane's first / second topic
           const double d_a = T - c_a, d_ab = T - c_ab;
           const unsigned long long m_a = __ballot(d_a < -delta), m_ab = __ballot(d_ab < -delta);
@@ -151,14 +160,32 @@ __global__ __launch_bounds__(64) void pcgs_wave_kernel(PcgsParams p, double marg
       }
       if (new_topic < 0) {
         // undecided (or Java would throw): replay the token as Java runs it, UPLDA:1509-1531 (negated walk in counting form,
-        // see ggs_z_sliced.hpp); every lane walks the same LDS cells
+        // see ggs_z_sliced.hpp): the scores in k order -- block by block, lane by lane, first then second topic -- read
+        // out of the lanes that hold them; every lane runs the same two chains.  (As a function of its own, reading the
+        // row from memory again so that the main path need not keep it for this: measured slower, 32.7 ms against 20.2
+        // at K = 1024 -- the compiler then holds the kernel at 128 registers and spills scalars in the token loop.)
         double sum = 0.0;
-        for (int k = 0; k < K; ++k) sum += scs[k];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          double qa, qb;
+          scores(j, cur.a[j], cur.b[j], qa, qb);
+#pragma unroll 8
+          for (int l = 0; l < 64; ++l) { sum += read_lane(qa, l); sum += read_lane(qb, l); }   // topics past K score 0: + 0.0
+        }
         double tt = 0.0 - U * sum;
         int newc = 0;
-        for (int k = 0; k < K; ++k) {
-          newc += hi32(tt) < 0 ? 1 : 0;
-          tt += scs[k];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          double qa, qb;
+          scores(j, cur.a[j], cur.b[j], qa, qb);
+#pragma unroll 8
+          for (int l = 0; l < 64; ++l) {
+            const bool ina = 128 * j + 2 * l < K, inb = 128 * j + 2 * l + 1 < K;   // the walk's counting form stops at K
+            newc += (ina && hi32(tt) < 0) ? 1 : 0;
+            tt += read_lane(qa, l);
+            newc += (inb && hi32(tt) < 0) ? 1 : 0;
+            tt += read_lane(qb, l);
+          }
         }
         new_topic = newc - 1;
         if (new_topic < 0 || hi32(tt) < 0) {                               // UPLDA:1529-1531
@@ -166,7 +193,7 @@ __global__ __launch_bounds__(64) void pcgs_wave_kernel(PcgsParams p, double marg
           new_topic = new_topic < 0 ? 0 : K - 1;
         }
       }
-      __syncthreads();                                                     // every lane has read the counts and the scores
+      __syncthreads();                                                     // every lane has read the counts
       if (lane == 0) {
         cnt[new_topic] += 1;                                               // UPLDA:1535
         p.z[beg + t] = new_topic;

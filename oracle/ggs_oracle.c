@@ -600,6 +600,40 @@ int orc_init_phi_range(orc_state *s, int32_t k0, int32_t k1) {
   return ORC_OK;
 }
 
+/* The gamma draws of a topic batch WITHOUT the normalisation (GGS:182-191 / UPLDA:1287-1294 up to ParallelDirichlet.java:57):
+ * gam [(k1 - k0)][V] and their index-order sums -- what a rank of the multi-GPU exchange puts on the wire (the division of
+ * ParallelDirichlet.java:60-66 is done by the receiver: the same IEEE division on the same operands).  s->phi is not
+ * touched.  For tests/test_distributed_gloo.py, which restates that protocol over gloo. */
+int orc_phi_gammas_range(orc_state *s, int32_t initial, int32_t k0, int32_t k1, double *gam, double *sums) {
+  s->err[0] = 0;
+  int err = ORC_OK;
+  const int32_t V = s->V;
+  if (k0 < 0 || k1 > s->K || k0 > k1) return fail(s, ORC_ERR_BAD_ARG, "bad topic range");
+#pragma omp parallel for num_threads(s->threads) schedule(static)
+  for (int32_t k = k0; k < k1; k++) {
+    const int32_t *cnt = s->n_kw + (size_t)k * V;
+    double *row = gam + (size_t)(k - k0) * V;
+    double magnitude = 0;
+    if (!initial)
+      for (int32_t v = 0; v < V; v++) magnitude += s->beta + cnt[v];        /* Dirichlet(double[]): magnitude in index order */
+    const double pm = (1.0 / (double)V) * ((double)V * s->beta);             /* Dirichlet(int, double): partition * magnitude */
+    double sum = 0;
+    for (int32_t v = 0; v < V; v++) {
+      const double a = initial ? ((cnt[v] == 0) ? pm : pm + cnt[v]) : (((s->beta + cnt[v]) / magnitude) * magnitude);
+      draw_rng r; draw_init(&r, s->seed, (uint32_t)s->iteration, initial ? ORC_PURPOSE_INIT_PHI : ORC_PURPOSE_PHI, (uint64_t)k * V + v);
+      row[v] = (a > 0) ? rgamma(&r, a) : NAN;
+      if (r.exhausted || !(a > 0)) {
+#pragma omp atomic write
+        err = ORC_ERR_RNG_EXHAUSTED;
+      }
+      sum += row[v];
+    }
+    sums[k - k0] = sum;
+  }
+  if (err) return fail(s, err, "gamma draw failed");
+  return ORC_OK;
+}
+
 /* UPLDA:398-406,458-460: z0 = Randoms(seed).nextInt(K) in (doc, position) order */
 int orc_init_z_java_lcg(orc_state *s, int32_t seed) {
   s->err[0] = 0;

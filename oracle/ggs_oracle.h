@@ -113,6 +113,7 @@ int orc_sweep(orc_state *s, int32_t n_sweeps);
 int orc_sample_phi_range(orc_state *s, int32_t k0, int32_t k1);   /* GGS:182-198 loopOverTopics for one topic batch */
 int orc_init_phi_range(orc_state *s, int32_t k0, int32_t k1);     /* UPLDA:1287-1294 for one topic batch */
 void orc_set_phi_rows(orc_state *s, int32_t k0, int32_t k1, const double *rows);
+int orc_phi_gammas_range(orc_state *s, int32_t initial, int32_t k0, int32_t k1, double *gam, double *sums);   /* the batch's unnormalised gammas + their sums */
 void orc_set_counts(orc_state *s, const int32_t *n_wk /* [V][K] */);
 /* the same sweep, bit for bit, with CPU-friendly memory behaviour (transposed Phi, no atomics): bench.py's cpu_tuned_mt */
 int orc_sweep_tuned(orc_state *s, int32_t n_sweeps);

@@ -73,6 +73,7 @@ def lib():
         "orc_sample_phi_range": (C.c_int, [vp, C.c_int32, C.c_int32]),
         "orc_init_phi_range": (C.c_int, [vp, C.c_int32, C.c_int32]),
         "orc_set_phi_rows": (None, [vp, C.c_int32, C.c_int32, dp]),
+        "orc_phi_gammas_range": (C.c_int, [vp, C.c_int32, C.c_int32, C.c_int32, dp, dp]),
         "orc_set_counts": (None, [vp, ip]),
         "orc_z_step": (C.c_int, [vp]),
         "orc_update_counts": (C.c_int, [vp]),
@@ -288,6 +289,13 @@ class OracleSampler:
 
     def init_phi_range(self, k0, k1):
         self._chk(lib().orc_init_phi_range(self._h, int(k0), int(k1)))
+
+    def phi_gammas_range(self, k0, k1, initial=False):
+        """The topic batch's gamma draws before the normalisation and their index-order sums: (gam [k1-k0][V], sums [k1-k0])."""
+        gam = np.empty((int(k1) - int(k0), self.V), np.float64)
+        sums = np.empty(int(k1) - int(k0), np.float64)
+        self._chk(lib().orc_phi_gammas_range(self._h, int(bool(initial)), int(k0), int(k1), _dp(gam), _dp(sums)))
+        return gam, sums
 
     def set_phi_rows(self, k0, rows):
         rows = np.ascontiguousarray(rows, np.float64)

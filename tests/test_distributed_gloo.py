@@ -254,10 +254,27 @@ class OracleSlicedEngine:
         own = self.tr.reduce_scatter(self.lay.pack(self._local_histogram()))          # [V][Ksm]: corpus-wide counts of my topics
         self.o.set_counts(self.lay.unpack(self.tr.all_gather(own)))                  # (the product gathers these lazily)
 
-    def _exchange_phi(self):
+    def _exchange_phi(self, initial):
+        """What travels since round 3: the rank's UNNORMALISED gammas [V][Ksm] in two halves of the vocabulary (whole 64-row
+        segments), the Ksm column sums behind the second; the receiver divides (ParallelDirichlet.java:60-66: the same
+        IEEE division, the clamp to Double.MIN_VALUE) -- csrc/ggs_api.hip phi_step_b1 .. phi_step_c, phi_repack_kernel."""
+        n = self.k1 - self.k0
+        gam, sums = self.o.phi_gammas_range(self.k0, self.k1, initial)
         mine = np.zeros((self.V, self.lay.Ksm))
-        mine[:, :self.k1 - self.k0] = self.o.get_phi()[self.k0:self.k1].T
-        self.o.set_phi_rows(0, np.ascontiguousarray(self.lay.unpack(self.tr.all_gather(mine)).T))
+        mine[:, :n] = gam.T
+        own_sums = np.zeros(self.lay.Ksm)
+        own_sums[:n] = sums
+        nseg = (self.V + 63) // 64
+        v_split = (nseg // 2) * 64 if nseg >= 16 else 0
+        half0 = self.tr.all_gather(mine[:v_split].reshape(-1)).reshape(self.lay.n, v_split, self.lay.Ksm) if v_split else None
+        half1 = self.tr.all_gather(np.concatenate([mine[v_split:].reshape(-1), own_sums]))
+        body = half1[:, :-self.lay.Ksm].reshape(self.lay.n, self.V - v_split, self.lay.Ksm)
+        tot = half1[:, -self.lay.Ksm:]                                               # [nranks][Ksm]
+        g = body if half0 is None else np.concatenate([half0, body], axis=1)       # [nranks][V][Ksm]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            x = np.where(tot[:, None, :] != 0, g / tot[:, None, :], g)
+        x = np.where((tot[:, None, :] != 0) & (x <= 0), 4.9e-324, x)
+        self.o.set_phi_rows(0, np.ascontiguousarray(self.lay.unpack(x).T))
 
     def set_z(self, z, redraw_phi=True):
         assert not redraw_phi
@@ -265,8 +282,7 @@ class OracleSlicedEngine:
 
     def init_phi(self):
         self._exchange_counts()
-        self.o.init_phi_range(self.k0, self.k1)
-        self._exchange_phi()
+        self._exchange_phi(initial=True)
 
     def sweep_begin(self):
         self.o.set_iteration(self.o.iteration + 1)
@@ -274,8 +290,7 @@ class OracleSlicedEngine:
 
     def sweep_end(self):
         self._exchange_counts()
-        self.o.sample_phi_range(self.k0, self.k1)
-        self._exchange_phi()
+        self._exchange_phi(initial=False)
 
     def set_test_corpus(self, doc_ptr, tokens, doc_base=0):
         self._test = (doc_ptr, tokens, doc_base)
@@ -293,7 +308,7 @@ def _worker_sliced(rank, world, port, out_dir, scheme, K):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    c = random_corpus(157, 120, 60, seed=17, empty_every=10)
+    c = random_corpus(157, 1100, 60, seed=17, empty_every=10)          # 18 segments of 64 types: the gammas travel in two halves
     eng = OracleSlicedEngine(O, K, c.num_types, 0.1, 0.01, 4242, rank, world, GlooSliceTransport(rank, world), scheme)
     sh = ShardedGGS(eng, NativeExchange, c, rank, world)
     sh.set_z_global(java_lcg_initial_z(c.num_tokens, K, 77))
@@ -307,8 +322,9 @@ def _worker_sliced(rank, world, port, out_dir, scheme, K):
 
 @pytest.mark.parametrize("scheme,K", [("ggs", 9), ("pcgs", 9), ("ggs", 1)])
 def test_two_rank_topic_sliced_exchange_equals_unsharded(oracle, tmp_path, scheme, K):
-    """The topic-sliced exchange (reduce-scatter of counts, per-rank Phi batch, all-gather of Phi) over gloo, two real
-    processes: bit-identical to the unsharded oracle.  K = 9 over 2 ranks has unequal slices (5, 4); K = 1 leaves rank 1
+    """The topic-sliced exchange (reduce-scatter of counts, per-rank Phi batch, all-gather of the unnormalised gammas in
+    two halves with the column sums behind the second, division on arrival) over gloo, two real processes:
+    bit-identical to the unsharded oracle.  K = 9 over 2 ranks has unequal slices (5, 4); K = 1 leaves rank 1
     without a topic."""
     import torch.multiprocessing as mp
     from ldagroupedgibbssampler_amd.corpus import random_corpus
@@ -319,7 +335,7 @@ def test_two_rank_topic_sliced_exchange_equals_unsharded(oracle, tmp_path, schem
     s.close()
     world = 2
     mp.spawn(_worker_sliced, args=(world, port, str(tmp_path), scheme, K), nprocs=world, join=True)
-    c = random_corpus(157, 120, 60, seed=17, empty_every=10)
+    c = random_corpus(157, 1100, 60, seed=17, empty_every=10)
     ref = oracle.OracleSampler(K, c.num_types, 0.1, 0.01, 4242)
     ref.set_scheme(scheme)
     ref.set_corpus(c.doc_ptr, c.tokens)

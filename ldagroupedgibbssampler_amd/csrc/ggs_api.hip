@@ -98,7 +98,7 @@ struct ggs_handle {
   hipStream_t side_hot = nullptr;                      // z_hot_kernel runs here, beside z_sliced_kernel on the main stream
   hipEvent_t ev_hot_fork = nullptr, ev_hot_join = nullptr;
   bool z_split = true;                                 // GGS_DEBUG_SPLIT=0: one kernel takes cold and hot chunks in turn
-  bool z_split_allowed = true, z_split_tried = false;  // the first z step of a corpus times both forms and keeps the faster
+  bool z_split_allowed = true, z_split_forced = false, z_split_tried = false;  // the first z step of a corpus times both forms and keeps the faster
   int32_t hot_wave_lds = 0;
   bool overlap_theta = true;
   // K > 192: the z step is cut into parts of consecutive documents and the NEXT iteration's theta of a part is drawn
@@ -598,7 +598,7 @@ int launch_z(ggs_handle *h, bool force_fused = false, int64_t c0 = 0, int64_t c1
       zp.num_chunks = h->Cc; zp.num_hot = 0;
       static const int only = debug_env("GGS_DEBUG_ONLY") ? std::atoi(debug_env("GGS_DEBUG_ONLY")) : 0;   // timing experiments: 1 cold only, 2 hot only
       if (only != 2) HIP_TRY(h, hipLaunchKernel(sliced_kernel_for(h->K), grid_of(h->Cc), sblock, args, (size_t)(kSlicedWaves * h->wave_lds), h->stream));
-      if (only != 1) HIP_TRY(h, hipLaunchKernel(hot_kernel_for(h->K), grid_of(h->Cs - h->Cc), sblock, hargs, (size_t)(hp.hot_off + h->num_hot * h->hot_pitch), h->side_hot));
+      if (only != 1) HIP_TRY(h, hipLaunchKernel(hot_kernel_for(h->K), grid_of(h->Cs - h->Cc), sblock, hargs, (size_t)(hp.hot_off + h->num_hot * h->hot_pitch + kHotTailBytes), h->side_hot));
       HIP_TRY(h, hipEventRecord(h->ev_hot_join, h->side_hot));
       HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_hot_join, 0));
     } else {
@@ -1019,11 +1019,11 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       h->ring_base = (std::max(kChunkDocs * kmax * 8, ns * 128) + 255) / 256 * 256;
       h->wave_lds = h->ring_base + kRingSlots * kSliceBytes;
       h->hot_pitch = ((h->K + 7) / 8) * 64 + 16;                     // KMAX doubles + one unit: an odd number of 16-byte units
-      if (const char *e = debug_env("GGS_DEBUG_SPLIT")) h->z_split = std::atoi(e) != 0;
+      if (const char *e = debug_env("GGS_DEBUG_SPLIT")) { h->z_split = std::atoi(e) != 0; h->z_split_forced = std::atoi(e) == 2; }   // 2: the split form without the timed comparison
       h->z_split_allowed = h->z_split;
-      h->hot_wave_lds = (kChunkDocs * kmax * 8 + 255) / 256 * 256;   // z_hot_kernel: two theta rows per wave, then the table
+      h->hot_wave_lds = (kChunkDocs * ns * kSliceTopics * 8 + 255) / 256 * 256;   // z_hot_kernel: two theta rows per wave (whole slices), then the table and its zeroed tail
       // split: the two workgroups must fit one CU together, each request rounded up to the LDS allocation granule
-      h->hot_cap = h->z_split ? (kMaxLdsBytes - alloc_of(kSlicedWaves * h->wave_lds) - kSlicedWaves * h->hot_wave_lds) / kGranule * kGranule / h->hot_pitch
+      h->hot_cap = h->z_split ? ((kMaxLdsBytes - alloc_of(kSlicedWaves * h->wave_lds) - kSlicedWaves * h->hot_wave_lds) / kGranule * kGranule - kHotTailBytes) / h->hot_pitch
                               : (kMaxLdsBytes - kSlicedWaves * h->wave_lds) / h->hot_pitch;
       h->hot_cap = std::max(0, std::min(255, h->hot_cap));
       if (const char *e = debug_env("GGS_DEBUG_HOT")) h->hot_cap = std::max(0, std::min(h->hot_cap, std::atoi(e)));
@@ -1435,7 +1435,7 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
   }
   HIP_TRY(h, hipDeviceSynchronize());   // the uploads and memsets above ran on the null stream; the handle's stream may not synchronise with it
   h->have_corpus = true; h->have_phi = false; h->in_sweep = false; h->global_tokens = -1; h->lcg_ready = false;
-  h->z_split = h->z_split_allowed; h->z_split_tried = false;
+  h->z_split = h->z_split_allowed; h->z_split_tried = h->z_split_forced;
   h->counts_global = h->xg == nullptr; h->cnt_own_valid = false; h->n_k_valid = false;
   return GGS_OK;
 }

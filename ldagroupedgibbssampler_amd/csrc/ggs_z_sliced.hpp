@@ -66,6 +66,7 @@ constexpr int kSlicedMaxTopics = 192;     // 384 score registers (VGPR + AGPR) +
 constexpr int kPhiTailPadBytes = 1024;    // zeroed bytes after the last phiT row (see above; the pcgs kernel pads K to 48, the one-pass stream kernel to a multiple of 64)
 constexpr int kSlicedWaves = 4;           // waves per workgroup (one per SIMD), sharing the hot-word table
 constexpr int kChunkDocs = 2;             // documents a chunk may draw tokens from
+constexpr int kHotTailBytes = 64;          // zeroed bytes after z_hot_kernel's table: what a lane refining the last slice reads past the last row
 constexpr int kSlotShift = 30;            // chunk token word: value | (which of the chunk's documents) << 30
 
 template <int S, int N, class F>
@@ -359,17 +360,22 @@ __global__ __launch_bounds__(kSlicedWaves * 64) void z_sliced_kernel(ZParams p) 
 // z_hot_kernel: the hot chunks on their own, launched on a second stream BESIDE z_sliced_kernel (which
 // then takes the cold chunks only).  A lone wave issues one VALU instruction per ~8 cycles and sits out
 // its own DMA issue; a second wave on the SIMD fills those slots (two waves per SIMD get 1.7x the issue
-// rate of one).  The cold kernel's waves hold 352 of a SIMD's 512 registers, so the guest must live in
-// <= 128 (amdgpu_waves_per_eu(4)): it keeps no score registers and reads its phi rows from the LDS table
-// twice -- pass 1 sums, pass 2 re-multiplies (the same single IEEE product) and walks.  One 4-wave
-// workgroup per CU; its LDS (the table + 2 theta rows per wave) is what the cold kernel's rings leave.
+// rate of one).  The cold kernel's waves hold most of a SIMD's 512 registers, so the guest must live in
+// <= 128 (amdgpu_waves_per_eu(4)): it keeps no score registers.  Pass 1 sums a token's K products from the
+// LDS table (GGS:96-101) and keeps the chain at every slice boundary (NS <= 12 checkpoints); where the walk of
+// GGS:108-113 stops is then DECIDED from that chain by the margin argument of z_stream1_kernel (ggs_z_stream.hpp:
+// the same delta, the same test; the slice the draw falls into is walked once more from the table, continuing
+// the chain from its checkpoint -- the same additions in the same order), and the token in 10^10 that is too
+// close to call replays the Java walk element by element.  One 4-wave workgroup per CU; its LDS (the table + 2
+// theta rows per wave) is what the cold kernel's rings leave.  Theta rows are zero-padded to whole slices and
+// 64 zero bytes follow the table, so a lane refining the last slice multiplies finite bytes by 0.
 // If the two kernels happen not to share the CUs the results are the same and the hot chunks simply run
 // before or after the cold ones.
 template <int KMAX>
 __global__ __launch_bounds__(kSlicedWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void z_hot_kernel(ZParams p) {
   constexpr int NS = (KMAX + kSliceTopics - 1) / kSliceTopics;
   constexpr int NT = (KMAX + 63) / 64;
-  constexpr int kThetaRow = KMAX * 8;
+  constexpr int kThetaRow = NS * kSliceTopics * 8;                 // zero-padded to whole slices
   extern __shared__ __align__(16) unsigned char smem[];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int K = p.K;
@@ -380,12 +386,13 @@ __global__ __launch_bounds__(kSlicedWaves * 64) __attribute__((amdgpu_waves_per_
   const int64_t stride = (int64_t)gridDim.x * kSlicedWaves;
   const int64_t C = p.num_chunks;
   {
-    constexpr int upr = KMAX / 2;
+    constexpr int upr = KMAX / 2 + 1;                              // a row's units and the pad unit behind it (hot_pitch), zeroed
     for (int i = threadIdx.x; i < p.num_hot * upr; i += kSlicedWaves * 64) {
       const int r = i / upr, u = i - r * upr;
       *reinterpret_cast<D2 *>(smem + p.hot_off + r * p.hot_pitch + u * 16) =
-          *reinterpret_cast<const D2 *>(phib + (size_t)p.hot_words[r] * rowbytes + (size_t)u * 16);
+          u < upr - 1 ? *reinterpret_cast<const D2 *>(phib + (size_t)p.hot_words[r] * rowbytes + (size_t)u * 16) : D2{0.0, 0.0};
     }
+    if (threadIdx.x < kHotTailBytes / 8) reinterpret_cast<double *>(smem + p.hot_off + p.num_hot * p.hot_pitch)[threadIdx.x] = 0.0;
   }
   __syncthreads();
   auto load_theta = [&](const int d0, const int d1, double (&tv)[kChunkDocs][NT]) {
@@ -416,11 +423,11 @@ __global__ __launch_bounds__(kSlicedWaves * 64) __attribute__((amdgpu_waves_per_
     for (int r = 0; r < kChunkDocs; ++r)
 #pragma unroll
       for (int t = 0; t < NT; ++t)
-        if (t * 64 + lane < KMAX) reinterpret_cast<double *>(thb + r * kThetaRow)[t * 64 + lane] = tv0[r][t];
+        if (t * 64 + lane < NS * kSliceTopics) reinterpret_cast<double *>(thb + r * kThetaRow)[t * 64 + lane] = tv0[r][t];
     const unsigned char *trow = thb + ((unsigned)w0 >> kSlotShift) * kThetaRow;
     const unsigned char *hrow = smem + p.hot_off + (w0 & ((1 << kSlotShift) - 1)) * p.hot_pitch;
     if (id0 >= 0) {
-      double sum = 0.0;
+      double sum = 0.0, ck[NS];
       static_for<0, NS>([&](auto sidx) {                           // GGS:96-101
         constexpr int s = decltype(sidx)::value;
         D2 ph[kSliceUnits], th[kSliceUnits];
@@ -436,42 +443,68 @@ __global__ __launch_bounds__(kSlicedWaves * 64) __attribute__((amdgpu_waves_per_
             sum += th[u].a * ph[u].a;
             sum += th[u].b * ph[u].b;
           }
-        asm volatile("" ::: "memory");                             // one slice's reads in flight at a time: the register budget is 128
+        asm volatile("" : "+v"(sum) : : "memory");                 // one slice's reads in flight at a time (the register budget is 128): the chain is pinned before the next slice's reads
+        ck[s] = sum;
       });
       const uint64_t gtok = (uint64_t)(p.tok_base + id0);
       const U4 o = philox4x32_10((uint32_t)gtok, (uint32_t)(gtok >> 32), (uint32_t)GGS_PURPOSE_Z << 24, p.iteration,
                                  (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
-      double t = 0.0 - u53(o.x, o.y) * sum;                        // the negated walk of z_sliced_kernel's finish()
-      int cnt = 0;
-      bool live = true;
-      static_for<0, NS>([&](auto sidx) {                           // GGS:108-113
-        constexpr int s = decltype(sidx)::value;
-        if (live) {                                                // wave-uniform
-          D2 ph[kSliceUnits], th[kSliceUnits];
+      const double t0 = u53(o.x, o.y) * sum;                       // GGS:107-108
+      const double delta = (sum * (double)K) * 0x1p-51 * p.margin_scale;
+      // the first slice whose closing checkpoint proves the walk has stopped (d = t0 - s is monotone)
+      int gsel = NS;
+      static_for<0, NS>([&](auto sidx) {
+        constexpr int s = NS - 1 - decltype(sidx)::value;
+        if (t0 - ck[s] < -delta) gsel = s;
+      });
+      bool undecided = gsel == NS;                                 // the walk would not end inside the row, NaN, or too close to call
+      if (undecided) gsel = 0;
+      double s = 0.0;                                              // the chain as it stood when pass 1 entered the slice
+      static_for<0, NS - 1>([&](auto sidx) {
+        constexpr int q = decltype(sidx)::value;
+        if (gsel == q + 1) s = ck[q];
+      });
+      undecided |= fabs(t0 - s) <= delta;                          // d_{r-1} > delta for r at the head of the slice (t_0 > delta for r = 0)
+      int ahead = 0;                                               // topics of the slice the walk is proved to pass
+      {
+        const unsigned char *hs = hrow + gsel * (kSliceTopics * 8), *ts = trow + gsel * (kSliceTopics * 8);
 #pragma unroll
-          for (int u = 0; u < kSliceUnits; ++u)
-            if (s * kSliceTopics + 2 * u + 1 < KMAX) {
-              ph[u] = lds_d2(hrow + s * (kSliceTopics * 8) + u * 16);
-              th[u] = lds_d2(trow + s * (kSliceTopics * 8) + u * 16);
-            }
-          uint32_t bits = 0;
+        for (int h = 0; h < 2; ++h) {                              // half a slice's reads in flight at a time
+          D2 ph[kSliceUnits / 2], th[kSliceUnits / 2];
 #pragma unroll
-          for (int u = 0; u < kSliceUnits; ++u)
-            if (s * kSliceTopics + 2 * u + 1 < KMAX) {
-              bits = __builtin_amdgcn_alignbit(bits, (uint32_t)hi32(t), 31);
-              t += th[u].a * ph[u].a;
-              bits = __builtin_amdgcn_alignbit(bits, (uint32_t)hi32(t), 31);
-              t += th[u].b * ph[u].b;
-            }
-          cnt += __popc(bits);
-          live = __any(hi32(t) < 0);
+          for (int u = 0; u < kSliceUnits / 2; ++u) {
+            ph[u] = lds_d2(hs + (h * (kSliceUnits / 2) + u) * 16);
+            th[u] = lds_d2(ts + (h * (kSliceUnits / 2) + u) * 16);
+          }
+#pragma unroll
+          for (int u = 0; u < kSliceUnits / 2; ++u) {
+            s += th[u].a * ph[u].a;
+            double d = t0 - s;
+            ahead += d >= -delta;
+            undecided |= fabs(d) <= delta;
+            s += th[u].b * ph[u].b;
+            d = t0 - s;
+            ahead += d >= -delta;
+            undecided |= fabs(d) <= delta;
+          }
           asm volatile("" ::: "memory");
         }
-      });
-      int new_topic = cnt - 1;
-      if (new_topic < 0 || hi32(t) < 0) {                          // GGS:116-118
-        atomicOr(p.status, ST_INVALID_TOPIC);
-        new_topic = new_topic < 0 ? 0 : K - 1;
+      }
+      int new_topic = gsel * kSliceTopics + ahead;
+      if (undecided || ahead >= kSliceTopics || new_topic >= K) {
+        // the exact replay: GGS:108-113 element by element from the table row (rare; see ggs_z_stream.hpp)
+        const double *prow = reinterpret_cast<const double *>(hrow), *trw = reinterpret_cast<const double *>(trow);
+        double sample = t0;
+        new_topic = -1;
+        while (sample > 0.0) {
+          ++new_topic;
+          if (new_topic >= K) break;
+          sample -= trw[new_topic] * prow[new_topic];
+        }
+        if (new_topic < 0 || new_topic >= K) {                     // GGS:116-118 (and the index past K Java would throw on)
+          atomicOr(p.status, ST_INVALID_TOPIC);
+          new_topic = new_topic < 0 ? 0 : K - 1;
+        }
       }
       p.z[id0] = new_topic;
       p.zw[ip0] = new_topic;

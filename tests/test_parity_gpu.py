@@ -162,7 +162,8 @@ def test_wide_topic_rows_use_the_streaming_kernel(native, oracle, K):
 
 
 @pytest.mark.parametrize("mode,K", [(2, 33), (2, 48), (2, 100), (2, 184), (1, 192), (1, 185), (3, 48), (3, 257), (3, 1024), ("margin9", 257), ("margin9", 1024), ("margin13", 64),
-                                    ("margin13", 300), ("ldsck", 300), ("ldsck", 1024), ("group2", 200), ("group4", 200), ("group4", 500), ("onerow", 200), ("onerow", 40), ("tworows", 1024), ("tworows", 600), (0, 5), (0, 100), (0, 257), ("fused", 20), ("fused", 100), ("chain", 9), ("nohot", 20), ("hot3", 100), ("queue0", 100), ("queue5", 24), ("queue5", 300)])
+                                    ("margin13", 300), ("ldsck", 300), ("ldsck", 1024), ("group2", 200), ("group4", 200), ("group4", 500), ("onerow", 200), ("onerow", 40), ("tworows", 1024), ("tworows", 600), (0, 5), (0, 100), (0, 257), ("fused", 20), ("fused", 100), ("chain", 9), ("nohot", 20), ("hot3", 100), ("queue0", 100), ("queue5", 24), ("queue5", 300),
+                                    ("split", 100), ("split", 8), ("split", 97), ("split", 184), ("hotmargin9", 100), ("hotmargin9", 184), ("hotmargin13", 20), ("hotmargin13", 104), ("hotmargin13", 113)])
 def test_alternate_z_kernels_agree(native, oracle, K, mode, monkeypatch):
     """The z kernels are interchangeable: GGS_DEBUG_ZKERNEL=2 forces the (one-pass) streaming kernel below 193 topics,
     =3 its two-pass form (every row streamed twice, the walk replayed in full: the cross-check of the one-pass kernel's
@@ -171,20 +172,26 @@ def test_alternate_z_kernels_agree(native, oracle, K, mode, monkeypatch):
     =0 the whole-row LDS tile kernel (first-generation, kept as a cross-check); GGS_DEBUG_SPLIT=0 ("fused")
     lets one sliced kernel take cold and hot chunks in turn instead of running z_hot_kernel beside it;
     GGS_DEBUG_CHAIN=1 ("chain") walks the Phi normalisers element by element instead of the exact parallel sums;
+    GGS_DEBUG_SPLIT=2 ("split", "hotmargin*") keeps z_hot_kernel beside the cold kernel whatever the first step's timing says -- its walk is decided by
+    the same margin argument, so GGS_DEBUG_MARGIN drives its tokens through its own exact replay;
     GGS_DEBUG_HOT caps the hot-word table (0: every chunk is a cold chunk; 3: three hot words);
     GGS_DEBUG_GAMMA_QUEUE caps the LDS queue of the gamma draws' leftovers (0 / 5 entries: the elements the straight-line
     first try does not settle are drawn by the general loops on the spot instead of gathered into full waves)."""
     env = {"fused": ("GGS_DEBUG_SPLIT", "0"), "chain": ("GGS_DEBUG_CHAIN", "1"), "nohot": ("GGS_DEBUG_HOT", "0"),
            "hot3": ("GGS_DEBUG_HOT", "3"), "margin9": ("GGS_DEBUG_MARGIN", "1e9"), "margin13": ("GGS_DEBUG_MARGIN", "1e13"), "ldsck": ("GGS_DEBUG_REGCK", "0"), "group2": ("GGS_DEBUG_GROUP", "2"), "group4": ("GGS_DEBUG_GROUP", "4"),
            "onerow": ("GGS_DEBUG_TWOROWS", "0"), "tworows": ("GGS_DEBUG_TWOROWS", "1"),
-           "queue0": ("GGS_DEBUG_GAMMA_QUEUE", "0"), "queue5": ("GGS_DEBUG_GAMMA_QUEUE", "5")}.get(mode, ("GGS_DEBUG_ZKERNEL", str(mode)))
+           "queue0": ("GGS_DEBUG_GAMMA_QUEUE", "0"), "queue5": ("GGS_DEBUG_GAMMA_QUEUE", "5"), "split": ("GGS_DEBUG_SPLIT", "2"),
+           "hotmargin9": ("GGS_DEBUG_MARGIN", "1e9"), "hotmargin13": ("GGS_DEBUG_MARGIN", "1e13")}.get(mode, ("GGS_DEBUG_ZKERNEL", str(mode)))
     monkeypatch.setenv(*env)
+    if str(mode).startswith("hotmargin"):
+        monkeypatch.setenv("GGS_DEBUG_SPLIT", "2")
     if str(mode).startswith("margin") or mode == "ldsck" or str(mode).startswith("group") or mode in ("onerow", "tworows"):
         monkeypatch.setenv("GGS_DEBUG_ZKERNEL", "2")
     c = random_corpus(150, 400, 140, seed=K + (mode if isinstance(mode, int) else 7), empty_every=11)
     g, o = make_pair(native, oracle, c, K, 0.1, 0.01, 70 + K, flags=native.FLAG_PARANOID, zseed=K)
     monkeypatch.delenv(env[0])
     monkeypatch.delenv("GGS_DEBUG_ZKERNEL", raising=False)
+    monkeypatch.delenv("GGS_DEBUG_SPLIT", raising=False)
     g.sweep(3)
     o.sweep(3)
     compare_state(g, o, "z kernel mode %s K=%d" % (mode, K))

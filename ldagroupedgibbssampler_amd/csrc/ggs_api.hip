@@ -61,6 +61,7 @@ struct ggs_handle {
 
   int64_t D = 0, N = 0, C = 0, S = 0, doc_base = 0, tok_base = 0, global_tokens = -1;
   bool have_corpus = false, have_phi = false, in_sweep = false;
+  int32_t theta_lds_main = 0;
   int32_t theta_docs_per_block = 0, theta_lds = 0, z_lds = 0, z_tile_tokens = 0, z_waves_per_cu = 0, num_cus = 0;
   bool z_sliced = false;   // scores-in-registers kernel (K <= kSlicedMaxTopics)
   bool z_stream = false;   // streaming kernel (K > kSlicedMaxTopics): rows once (z_stream1_kernel) ...
@@ -97,6 +98,12 @@ struct ggs_handle {
   hipStream_t side = nullptr;
   hipStream_t side_hot = nullptr;                      // z_hot_kernel runs here, beside z_sliced_kernel on the main stream
   hipEvent_t ev_hot_fork = nullptr, ev_hot_join = nullptr;
+  // Whole sweeps on one GPU (ggs_sweep, K <= 184): the next theta is the LONGER of the two legs behind the z step (0.61 ms
+  // against 0.50 for the counts and the Phi chain), and a dependency across streams takes 10-25 us to resolve -- so the
+  // long leg stays on the handle's stream, directly between two z steps, and the short one (count rebuild + Phi chain)
+  // goes to the high-priority stream the hot chunks used during the z step.  GGS_DEBUG_THETA_MAIN=0: the other way round.
+  bool theta_main = true, chain_on_side = false;
+  hipEvent_t ev_chain_done = nullptr;
   bool z_split = true;                                 // GGS_DEBUG_SPLIT=0: one kernel takes cold and hot chunks in turn
   bool z_split_allowed = true, z_split_forced = false, z_split_tried = false;  // the first z step of a corpus times both forms and keeps the faster
   int32_t hot_wave_lds = 0;
@@ -686,6 +693,14 @@ int settle_sweeps(ggs_handle *h) {
   return GGS_OK;
 }
 
+// the handle's launches go to another stream for a scope (the count rebuild and the Phi chain of a whole sweep)
+struct StreamSwap {
+  ggs_handle *h;
+  hipStream_t user;
+  StreamSwap(ggs_handle *h_, hipStream_t s) : h(h_), user(h_->stream) { h->stream = s; }
+  ~StreamSwap() { h->stream = user; }
+};
+
 int z_phase(ggs_handle *h) {
   int rc;
   if (h->ev_pending >= kEvRing - 2 && (rc = settle_sweeps(h))) return rc;   // keep this slot and the next one free
@@ -754,25 +769,42 @@ int z_phase(ggs_handle *h) {
   } else {
     if ((rc = launch_z(h))) return rc;
     HIP_TRY(h, hipEventRecord(E.e[2], h->stream));
+    h->chain_on_side = h->chain_on_side && ahead;
     if (ahead) {
       // theta of iteration t+1 from the z just drawn, concurrent with the counts and the Phi draw
       Events &N = h->evs[(h->ev_head + 1) % kEvRing];
-      HIP_TRY(h, hipStreamWaitEvent(h->side, E.e[2], 0));
-      HIP_TRY(h, hipEventRecord(N.th0, h->side));
-      if ((rc = launch_theta(h, h->side, h->d_theta_next, h->iteration + 1))) return rc;
-      HIP_TRY(h, hipEventRecord(N.th1, h->side));
+      hipStream_t ts = h->chain_on_side ? h->stream : h->side;
+      HIP_TRY(h, hipStreamWaitEvent(h->chain_on_side ? h->side_hot : h->side, E.e[2], 0));
+      HIP_TRY(h, hipEventRecord(N.th0, ts));
+      if ((rc = launch_theta(h, ts, h->d_theta_next, h->iteration + 1, 0, -1, h->chain_on_side ? h->theta_lds_main : 0))) return rc;
+      HIP_TRY(h, hipEventRecord(N.th1, ts));
       h->theta_ahead_iter = (int64_t)h->iteration + 1;
     }
   }
-  if ((rc = launch_count_rebuild(h))) return rc;   // this shard's counts; summed across shards by the caller
-  HIP_TRY(h, hipEventRecord(E.e[3], h->stream));
+  {
+    StreamSwap on_chain(h, h->chain_on_side ? h->side_hot : h->stream);
+    if ((rc = launch_count_rebuild(h))) return rc;   // this shard's counts; summed across shards by the caller
+    HIP_TRY(h, hipEventRecord(E.e[3], h->stream));
+  }
   return GGS_OK;
 }
 
 // `settle` = wait for the device, raise what the sweeps flagged and add their phase times to the timings.  A batch
 // (ggs_sweep with n_sweeps > 1) settles once, after its last sweep: the device flags are sticky, and the ~40 us host
 // round trip per sweep is 2 % of a 1.9 ms sweep.
+int finish_sweep_enqueue_on(ggs_handle *h, bool with_phi);
 int finish_sweep_enqueue(ggs_handle *h, bool with_phi) {
+  if (!h->chain_on_side) return finish_sweep_enqueue_on(h, with_phi);
+  int rc;
+  {
+    StreamSwap on_chain(h, h->side_hot);
+    if ((rc = finish_sweep_enqueue_on(h, with_phi))) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev_chain_done, h->stream));
+  }
+  HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_chain_done, 0));   // behind the theta draw: the next z step, a getter, a synchronise see both legs
+  return GGS_OK;
+}
+int finish_sweep_enqueue_on(ggs_handle *h, bool with_phi) {
   int rc;
   Events &E = h->evs[h->ev_head];
   HIP_TRY(h, hipEventRecord(E.e[4], h->stream));
@@ -1053,6 +1085,10 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     // 14.5 KiB per workgroup: with the CU's LDS handed out to theta workgroups to the last granule it waited for the
     // theta draw to END -- 5 ms at K = 1024).
     h->theta_docs_per_block = B; h->theta_lds = std::max(lds_of(B), (kMaxLdsBytes - 24 * 1024) / 4);
+    // ... unless the theta draw is the critical leg itself (theta_main, below): then it takes what fits -- five workgroups
+    // per CU at K = 100, the walk's 14.5 KiB still free (measured, ms per sweep: 4 per CU 1.60-1.61, 5 or 6 1.58, 3 1.61)
+    h->theta_lds_main = lds_of(B);
+    if (const char *e = debug_env("GGS_DEBUG_THETA_WGS")) h->theta_lds_main = std::max(lds_of(B), (kMaxLdsBytes - 24 * 1024) / std::max(1, std::atoi(e)));
     // K > 192 (one-pass streaming z kernel): theta workgroups small enough to sit BESIDE the z waves -- three of
     // them, on the LDS the z waves give up -- so that the next theta of a part of the documents is drawn while the
     // following parts are sampled (z_phase).  The padded request caps them at three per CU while z runs.
@@ -1160,6 +1196,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     if (hipEventCreate(&E.th0) != hipSuccess || hipEventCreate(&E.th1) != hipSuccess) return bail(GGS_ERR_HIP);
   }
   if (const char *e = debug_env("GGS_DEBUG_NO_OVERLAP")) h->overlap_theta = std::atoi(e) == 0;
+  if (const char *e = debug_env("GGS_DEBUG_THETA_MAIN")) h->theta_main = std::atoi(e) != 0;
   if (const char *e = debug_env("GGS_DEBUG_GAMMA_QUEUE")) h->gamma_queue_cap = std::max(0, std::atoi(e));
   {
     // lowest priority: the theta draw fills whatever the Phi phase (on the caller's stream) leaves idle
@@ -1169,7 +1206,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     // serialises with the legacy default stream, so the overlap is lost -- priority alone it is)
     if (hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, lo) != hipSuccess) return bail(GGS_ERR_HIP);
     if (hipStreamCreateWithPriority(&h->side_hot, hipStreamNonBlocking, hi) != hipSuccess || hipEventCreate(&h->ev_hot_fork) != hipSuccess ||
-        hipEventCreate(&h->ev_hot_join) != hipSuccess)
+        hipEventCreate(&h->ev_hot_join) != hipSuccess || hipEventCreateWithFlags(&h->ev_chain_done, hipEventDisableTiming) != hipSuccess)
       return bail(GGS_ERR_HIP);
   }
   if (hipDeviceSynchronize() != hipSuccess) return bail(GGS_ERR_HIP);   // the memsets above ran on the null stream
@@ -1207,6 +1244,7 @@ void ggs_destroy(ggs_handle *h) {
   if (h->side_hot) (void)hipStreamDestroy(h->side_hot);
   if (h->ev_hot_fork) (void)hipEventDestroy(h->ev_hot_fork);
   if (h->ev_hot_join) (void)hipEventDestroy(h->ev_hot_join);
+  if (h->ev_chain_done) (void)hipEventDestroy(h->ev_chain_done);
   delete h;
 }
 
@@ -1520,10 +1558,15 @@ int ggs_sweep_end_async(ggs_handle *h) {
 
 int ggs_sweep(ggs_handle *h, int32_t n_sweeps) {
   for (int32_t i = 0; i < n_sweeps; ++i) {
+    // see theta_main: only where the z step is one launch pair (no parts), theta is drawn at all, and no collective is in the chain
+    h->chain_on_side = h && h->theta_main && h->z_sliced && h->side_hot && h->ev_chain_done && !h->xg && !h->collapsed && !(h->flags & GGS_FLAG_PCGS);
     int rc = ggs_sweep_begin(h);
+    if (!rc) {
+      h->in_sweep = false;
+      rc = finish_sweep(h, true, i == n_sweeps - 1);
+    }
+    if (h) h->chain_on_side = false;
     if (rc) return rc;
-    h->in_sweep = false;
-    if ((rc = finish_sweep(h, true, i == n_sweeps - 1))) return rc;
   }
   return GGS_OK;
 }

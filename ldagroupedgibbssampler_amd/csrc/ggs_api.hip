@@ -61,7 +61,7 @@ struct ggs_handle {
 
   int64_t D = 0, N = 0, C = 0, S = 0, doc_base = 0, tok_base = 0, global_tokens = -1;
   bool have_corpus = false, have_phi = false, in_sweep = false;
-  int32_t theta_lds_main = 0;
+  int32_t theta_lds_main = 0, theta_b_main = 0;       // the theta draw as the critical leg (theta_main): workgroup size and LDS request
   int32_t theta_docs_per_block = 0, theta_lds = 0, z_lds = 0, z_tile_tokens = 0, z_waves_per_cu = 0, num_cus = 0;
   bool z_sliced = false;   // scores-in-registers kernel (K <= kSlicedMaxTopics)
   bool z_stream = false;   // streaming kernel (K > kSlicedMaxTopics): rows once (z_stream1_kernel) ...
@@ -466,14 +466,15 @@ int launch_phi(ggs_handle *h, bool initial, bool accumulate_mean, Events *E = nu
   return GGS_OK;
 }
 
-int launch_theta(ggs_handle *h, hipStream_t stream, double *dst, int32_t iteration, int64_t d0 = 0, int64_t d1 = -1, int32_t lds = 0) {
+int launch_theta(ggs_handle *h, hipStream_t stream, double *dst, int32_t iteration, int64_t d0 = 0, int64_t d1 = -1, int32_t lds = 0, int32_t docs_per_block = 0) {
   if (d1 < 0) d1 = h->D;
   if (d1 <= d0) return GGS_OK;
+  if (docs_per_block <= 0) docs_per_block = h->theta_docs_per_block;
   ThetaParams tp{};
   tp.doc_ptr = h->d_doc_ptr + d0; tp.z = h->d_z; tp.alpha = h->d_alpha; tp.theta = dst + (size_t)d0 * h->K; tp.status = h->d_status;
   tp.num_docs = d1 - d0; tp.doc_base = h->doc_base + d0; tp.seed = h->seed; tp.iteration = (uint32_t)iteration;
-  tp.K = h->K; tp.docs_per_block = h->theta_docs_per_block; tp.queue_cap = std::min(kGammaQueue, h->gamma_queue_cap);
-  const int64_t grid = (d1 - d0 + h->theta_docs_per_block - 1) / h->theta_docs_per_block;
+  tp.K = h->K; tp.docs_per_block = docs_per_block; tp.queue_cap = std::min(kGammaQueue, h->gamma_queue_cap);
+  const int64_t grid = (d1 - d0 + docs_per_block - 1) / docs_per_block;
   hipLaunchKernelGGL(theta_kernel<kThetaBlock>, dim3((unsigned)grid), dim3(kThetaBlock), lds ? lds : h->theta_lds, stream, tp);
   HIP_TRY(h, hipGetLastError());
   return GGS_OK;
@@ -776,7 +777,7 @@ int z_phase(ggs_handle *h) {
       hipStream_t ts = h->chain_on_side ? h->stream : h->side;
       HIP_TRY(h, hipStreamWaitEvent(h->chain_on_side ? h->side_hot : h->side, E.e[2], 0));
       HIP_TRY(h, hipEventRecord(N.th0, ts));
-      if ((rc = launch_theta(h, ts, h->d_theta_next, h->iteration + 1, 0, -1, h->chain_on_side ? h->theta_lds_main : 0))) return rc;
+      if ((rc = launch_theta(h, ts, h->d_theta_next, h->iteration + 1, 0, -1, h->chain_on_side ? h->theta_lds_main : 0, h->chain_on_side ? h->theta_b_main : 0))) return rc;
       HIP_TRY(h, hipEventRecord(N.th1, ts));
       h->theta_ahead_iter = (int64_t)h->iteration + 1;
     }
@@ -1085,10 +1086,13 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     // 14.5 KiB per workgroup: with the CU's LDS handed out to theta workgroups to the last granule it waited for the
     // theta draw to END -- 5 ms at K = 1024).
     h->theta_docs_per_block = B; h->theta_lds = std::max(lds_of(B), (kMaxLdsBytes - 24 * 1024) / 4);
-    // ... unless the theta draw is the critical leg itself (theta_main, below): then it takes what fits -- five workgroups
-    // per CU at K = 100, the walk's 14.5 KiB still free (measured, ms per sweep: 4 per CU 1.60-1.61, 5 or 6 1.58, 3 1.61)
-    h->theta_lds_main = lds_of(B);
-    if (const char *e = debug_env("GGS_DEBUG_THETA_WGS")) h->theta_lds_main = std::max(lds_of(B), (kMaxLdsBytes - 24 * 1024) / std::max(1, std::atoi(e)));
+    // ... unless the theta draw is the critical leg itself (theta_main, below): then five workgroups per CU, of 16 documents
+    // each.  Measured at K = 100 on one box, ms per sweep (documents per workgroup x workgroups per CU): 32x4 1.60-1.61,
+    // 32x5 1.598-1.62, 24x5 1.593, 16x4 1.614, 16x5 1.568-1.587, 16x6 1.58, 16x8 1.598, 12x5 1.609, 8x8 1.635 -- the smaller
+    // workgroups leave the Phi chain beside them its pace (0.39 ms against 0.44), so that it ends before the theta draw does.
+    h->theta_b_main = std::min(B, 16);
+    if (const char *e = debug_env("GGS_DEBUG_THETA_B")) h->theta_b_main = std::max(1, std::min(B, std::atoi(e)));
+    h->theta_lds_main = std::max(lds_of(h->theta_b_main), (kMaxLdsBytes - 24 * 1024) / (debug_env("GGS_DEBUG_THETA_WGS") ? std::max(1, std::atoi(debug_env("GGS_DEBUG_THETA_WGS"))) : 5));
     // K > 192 (one-pass streaming z kernel): theta workgroups small enough to sit BESIDE the z waves -- three of
     // them, on the LDS the z waves give up -- so that the next theta of a part of the documents is drawn while the
     // following parts are sampled (z_phase).  The padded request caps them at three per CU while z runs.

@@ -45,6 +45,8 @@ struct Events {
   hipEvent_t x[3] = {nullptr, nullptr, nullptr};   // with an exchange: after the count reduce-scatter, after the slice's Phi draw, after the last all-gather (both halves in)
   hipEvent_t th0 = nullptr, th1 = nullptr;   // side-stream theta draw consumed by this sweep
   bool used_ahead = false, exchanged = false;
+  bool e4_is_e3 = false;        // a whole sweep (ggs_sweep): nothing happens between the end of the count rebuild and the start of the Phi phase
+  bool theta_on_main = false;   // the theta this sweep consumes was drawn on the handle's own stream, right behind the previous z step: no th0 (= that sweep's e[2])
 };
 
 }  // namespace
@@ -103,6 +105,8 @@ struct ggs_handle {
   // long leg stays on the handle's stream, directly between two z steps, and the short one (count rebuild + Phi chain)
   // goes to the high-priority stream the hot chunks used during the z step.  GGS_DEBUG_THETA_MAIN=0: the other way round.
   bool theta_main = true, chain_on_side = false;
+  bool whole_sweep = false;                            // inside ggs_sweep: z phase and Phi phase are enqueued back to back
+  hipEvent_t hot_fork_from = nullptr;                  // an event already on the handle's stream that the hot kernel's stream may wait for instead of a fork event of its own
   hipEvent_t ev_chain_done = nullptr;
   bool z_split = true;                                 // GGS_DEBUG_SPLIT=0: one kernel takes cold and hot chunks in turn
   bool z_split_allowed = true, z_split_forced = false, z_split_tried = false;  // the first z step of a corpus times both forms and keeps the faster
@@ -601,8 +605,12 @@ int launch_z(ggs_handle *h, bool force_fused = false, int64_t c0 = 0, int64_t c1
       ZParams hp = zp;
       hp.wave_lds = h->hot_wave_lds; hp.hot_off = kSlicedWaves * h->hot_wave_lds;
       void *hargs[] = {&hp};
-      HIP_TRY(h, hipEventRecord(h->ev_hot_fork, h->stream));
-      HIP_TRY(h, hipStreamWaitEvent(h->side_hot, h->ev_hot_fork, 0));
+      if (h->hot_fork_from) {
+        HIP_TRY(h, hipStreamWaitEvent(h->side_hot, h->hot_fork_from, 0));
+      } else {
+        HIP_TRY(h, hipEventRecord(h->ev_hot_fork, h->stream));
+        HIP_TRY(h, hipStreamWaitEvent(h->side_hot, h->ev_hot_fork, 0));
+      }
       zp.num_chunks = h->Cc; zp.num_hot = 0;
       static const int only = debug_env("GGS_DEBUG_ONLY") ? std::atoi(debug_env("GGS_DEBUG_ONLY")) : 0;   // timing experiments: 1 cold only, 2 hot only
       if (only != 2) HIP_TRY(h, hipLaunchKernel(sliced_kernel_for(h->K), grid_of(h->Cc), sblock, args, (size_t)(kSlicedWaves * h->wave_lds), h->stream));
@@ -674,18 +682,21 @@ int settle_sweeps(ggs_handle *h) {
     float ms = 0;
     // a consumed ahead-draw: the stream waited on th1 before the z kernel, so both side-stream events are complete;
     // their span is the duration of a kernel that ran beside the previous sweep's Phi phase
-    if (E.used_ahead) { HIP_TRY(h, hipEventElapsedTime(&ms, E.th0, E.th1)); }
+    // (every event or barrier packet on the critical stream costs ~6 us of device time: a theta drawn on it starts at the
+    // previous sweep's e[2])
+    if (E.used_ahead && E.theta_on_main) { HIP_TRY(h, hipEventElapsedTime(&ms, h->evs[((h->ev_head - j - 1) % kEvRing + kEvRing) % kEvRing].e[2], E.th1)); }
+    else if (E.used_ahead) { HIP_TRY(h, hipEventElapsedTime(&ms, E.th0, E.th1)); }
     else { HIP_TRY(h, hipEventElapsedTime(&ms, E.e[0], E.e[1])); }
     h->tm.theta_ms += ms;
     HIP_TRY(h, hipEventElapsedTime(&ms, E.e[1], E.e[2])); h->tm.z_ms += ms;
     HIP_TRY(h, hipEventElapsedTime(&ms, E.e[2], E.e[3])); h->tm.merge_ms += ms;
     if (E.exchanged) {   // reduce-scatter | slice draw (the first half's all-gather beneath it) | what is left of the all-gathers | repack
-      HIP_TRY(h, hipEventElapsedTime(&ms, E.e[4], E.x[0])); h->tm.exchange_ms += ms; h->tm.exchange_rs_ms += ms;
+      HIP_TRY(h, hipEventElapsedTime(&ms, E.e[E.e4_is_e3 ? 3 : 4], E.x[0])); h->tm.exchange_ms += ms; h->tm.exchange_rs_ms += ms;
       HIP_TRY(h, hipEventElapsedTime(&ms, E.x[0], E.x[1])); h->tm.phi_ms += ms;
       HIP_TRY(h, hipEventElapsedTime(&ms, E.x[1], E.x[2])); h->tm.exchange_ms += ms; h->tm.exchange_ag_ms += ms;
       HIP_TRY(h, hipEventElapsedTime(&ms, E.x[2], E.e[5])); h->tm.phi_ms += ms;
     } else {
-      HIP_TRY(h, hipEventElapsedTime(&ms, E.e[4], E.e[5])); h->tm.phi_ms += ms;
+      HIP_TRY(h, hipEventElapsedTime(&ms, E.e[E.e4_is_e3 ? 3 : 4], E.e[5])); h->tm.phi_ms += ms;
     }
     h->tm.sweeps += 1;
     h->tm.tokens_sampled += h->N;
@@ -718,10 +729,13 @@ int z_phase(ggs_handle *h) {
     return GGS_OK;
   }
   E.used_ahead = h->theta_ahead_iter == (int64_t)h->iteration;
+  h->hot_fork_from = nullptr;
   if (E.used_ahead) {
-    HIP_TRY(h, hipStreamWaitEvent(h->stream, E.th1, 0));   // drawn during the previous iteration's Phi phase
+    if (E.theta_on_main) h->hot_fork_from = E.th1;          // drawn on this very stream: nothing to wait for, and the hot kernel's stream (which ran the Phi chain) forks from th1
+    else HIP_TRY(h, hipStreamWaitEvent(h->stream, E.th1, 0));   // drawn during the previous iteration's Phi phase
     std::swap(h->d_theta, h->d_theta_next);
   } else {
+    E.theta_on_main = false;
     if (h->side) HIP_TRY(h, hipStreamSynchronize(h->side));
     HIP_TRY(h, hipEventRecord(E.e[0], h->stream));
     if ((rc = launch_theta(h, h->stream, h->d_theta, h->iteration))) return rc;
@@ -759,7 +773,7 @@ int z_phase(ggs_handle *h) {
       if ((rc = launch_z(h, false, h->part_chunk[(size_t)p], h->part_chunk[(size_t)p + 1]))) return rc;
       HIP_TRY(h, hipEventRecord(h->ev_part[p], h->stream));
       HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_part[p], 0));
-      if (p == 0) HIP_TRY(h, hipEventRecord(N.th0, h->side));
+      if (p == 0) { N.theta_on_main = false; HIP_TRY(h, hipEventRecord(N.th0, h->side)); }
       if ((rc = launch_theta(h, h->side, h->d_theta_next, h->iteration + 1, h->part_doc[(size_t)p], h->part_doc[(size_t)p + 1],
                              p + 1 < P ? h->theta_lds_beside_z : 0)))
         return rc;
@@ -776,7 +790,8 @@ int z_phase(ggs_handle *h) {
       Events &N = h->evs[(h->ev_head + 1) % kEvRing];
       hipStream_t ts = h->chain_on_side ? h->stream : h->side;
       HIP_TRY(h, hipStreamWaitEvent(h->chain_on_side ? h->side_hot : h->side, E.e[2], 0));
-      HIP_TRY(h, hipEventRecord(N.th0, ts));
+      N.theta_on_main = h->chain_on_side;
+      if (!h->chain_on_side) HIP_TRY(h, hipEventRecord(N.th0, ts));
       if ((rc = launch_theta(h, ts, h->d_theta_next, h->iteration + 1, 0, -1, h->chain_on_side ? h->theta_lds_main : 0, h->chain_on_side ? h->theta_b_main : 0))) return rc;
       HIP_TRY(h, hipEventRecord(N.th1, ts));
       h->theta_ahead_iter = (int64_t)h->iteration + 1;
@@ -808,7 +823,8 @@ int finish_sweep_enqueue(ggs_handle *h, bool with_phi) {
 int finish_sweep_enqueue_on(ggs_handle *h, bool with_phi) {
   int rc;
   Events &E = h->evs[h->ev_head];
-  HIP_TRY(h, hipEventRecord(E.e[4], h->stream));
+  E.e4_is_e3 = h->whole_sweep;                         // one event packet less on the stream (~6 us each)
+  if (!E.e4_is_e3) HIP_TRY(h, hipEventRecord(E.e[4], h->stream));
   bool acc = false;
   E.exchanged = false;
   if (with_phi) {
@@ -1563,13 +1579,14 @@ int ggs_sweep_end_async(ggs_handle *h) {
 int ggs_sweep(ggs_handle *h, int32_t n_sweeps) {
   for (int32_t i = 0; i < n_sweeps; ++i) {
     // see theta_main: only where the z step is one launch pair (no parts), theta is drawn at all, and no collective is in the chain
+    if (h) h->whole_sweep = true;
     h->chain_on_side = h && h->theta_main && h->z_sliced && h->side_hot && h->ev_chain_done && !h->xg && !h->collapsed && !(h->flags & GGS_FLAG_PCGS);
     int rc = ggs_sweep_begin(h);
     if (!rc) {
       h->in_sweep = false;
       rc = finish_sweep(h, true, i == n_sweeps - 1);
     }
-    if (h) h->chain_on_side = false;
+    if (h) h->chain_on_side = h->whole_sweep = false;
     if (rc) return rc;
   }
   return GGS_OK;
@@ -1726,7 +1743,7 @@ int group_phi(ggs_handle **hs, int32_t n, bool initial, bool in_sweep) {
     if (in_sweep) {
       Events &E = h->evs[h->ev_head];
       if (hipEventRecord(E.e[4], h->stream) != hipSuccess) { rc = set_err(h, GGS_ERR_HIP, "hipEventRecord"); break; }
-      E.exchanged = true;
+      E.exchanged = true; E.e4_is_e3 = false;
       acc[(size_t)i] = (h->flags & GGS_FLAG_SAVE_PHI_MEAN) && sample_phi_this_iteration(h);
     }
   }
@@ -1859,7 +1876,7 @@ int ggs_group_sweep(ggs_handle **hs, int32_t n, int32_t n_sweeps) {
         ggs_handle *h = hs[i];
         if ((rc = bind_device(h))) return rc;
         Events &E = h->evs[h->ev_head];
-        E.exchanged = false;
+        E.exchanged = false; E.e4_is_e3 = false;
         HIP_TRY(h, hipEventRecord(E.e[4], h->stream));
         if ((rc = launch_magnitude(h))) return rc;
         HIP_TRY(h, hipEventRecord(E.e[5], h->stream));

@@ -116,6 +116,10 @@ struct ggs_handle {
   // (side stream) while the following parts are still being sampled: the streaming z kernel waits on memory, the theta
   // draw on the VALU.  The last part's theta runs beside the Phi phase as before.
   int32_t z_parts = 1, theta_lds_beside_z = 0;
+  // the two launch configurations of the K > 192 path, chosen per corpus (ggs_set_corpus): with the z step cut into parts
+  // (theta workgroups beside the z waves) or in one piece
+  struct ZCfg { int32_t parts = 1, z_waves_per_cu = 0, theta_docs_per_block = 0, theta_lds = 0, theta_lds_beside_z = 0; } cfg_plain, cfg_parts;
+  bool z_parts_forced = false;
   int32_t gamma_queue_cap = 1 << 20;   // GGS_DEBUG_GAMMA_QUEUE: a tiny queue sends the leftovers of the first try down the on-the-spot path
   std::vector<int64_t> part_doc, part_chunk;           // [z_parts + 1] boundaries
   hipEvent_t ev_part[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1112,7 +1116,8 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     // K > 192 (one-pass streaming z kernel): theta workgroups small enough to sit BESIDE the z waves -- three of
     // them, on the LDS the z waves give up -- so that the next theta of a part of the documents is drawn while the
     // following parts are sampled (z_phase).  The padded request caps them at three per CU while z runs.
-    if (const char *e = debug_env("GGS_DEBUG_ZPARTS")) h->z_parts = std::max(1, std::min(8, std::atoi(e)));
+    h->cfg_plain.parts = 1; h->cfg_plain.z_waves_per_cu = h->z_waves_per_cu; h->cfg_plain.theta_docs_per_block = h->theta_docs_per_block; h->cfg_plain.theta_lds = h->theta_lds;
+    if (const char *e = debug_env("GGS_DEBUG_ZPARTS")) { h->z_parts = std::max(1, std::min(8, std::atoi(e))); h->z_parts_forced = true; }
     else h->z_parts = (h->z_stream && !h->z_two_pass && !(h->flags & GGS_FLAG_PCGS)) ? 8 : 1;   // measured at K = 1024: 1 part 18.4 ms per sweep, 2: 18.1, 4: 16.5, 8: 15.9
     if (h->z_parts > 1 && h->z_stream && !h->z_two_pass) {
       constexpr int kGranule = 2048;
@@ -1130,6 +1135,8 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
         h->z_parts = 1;
       }
     }
+    h->cfg_parts.parts = h->z_parts; h->cfg_parts.z_waves_per_cu = h->z_waves_per_cu; h->cfg_parts.theta_docs_per_block = h->theta_docs_per_block;
+    h->cfg_parts.theta_lds = h->theta_lds; h->cfg_parts.theta_lds_beside_z = h->theta_lds_beside_z;
   }
   if (h->z_sliced && (hipFuncSetAttribute(sliced_kernel_for(h->K), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess ||
                       hipFuncSetAttribute(hot_kernel_for(h->K), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess))
@@ -1385,6 +1392,17 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
   h->D = D; h->N = N; h->C = (int64_t)cstart.size(); h->S = (int64_t)seg_word.size(); h->doc_base = doc_base; h->tok_base = tok_base;
   {
     // the parts of the z step (z_phase): consecutive documents with about equal token counts, and their chunk ranges
+    // Parts pay where the theta draw (D x K gammas) is longer than the Phi chain it otherwise hides beside (V x K gammas):
+    // the excess is what is drawn beside the z parts.  Measured: D = 100 000, V = 50 000, K = 1 024: 1 part 18.4 ms per
+    // sweep, 2: 18.1, 4: 16.5, 8: 15.9; D = 18 846, V = 60 000, K = 200: 8 parts 1.112, 4: 1.071, 2: 1.019, 1: 1.006 (every part
+    // costs an event packet, a launch and the drain of the persistent z waves).
+    {
+      int32_t want = h->cfg_parts.parts;
+      if (!h->z_parts_forced && want > 1) want = D <= (int64_t)h->V ? 1 : D < 2 * (int64_t)h->V ? std::min(want, 4) : want;
+      const ggs_handle::ZCfg &c = want > 1 ? h->cfg_parts : h->cfg_plain;
+      h->z_parts = want; h->z_waves_per_cu = c.z_waves_per_cu; h->theta_docs_per_block = c.theta_docs_per_block; h->theta_lds = c.theta_lds;
+      h->theta_lds_beside_z = c.theta_lds_beside_z;
+    }
     const int32_t P = (h->z_parts > 1 && D >= 64 * h->z_parts) ? h->z_parts : 1;
     h->part_doc.assign((size_t)P + 1, D); h->part_chunk.assign((size_t)P + 1, (int64_t)cstart.size());
     h->part_doc[0] = 0; h->part_chunk[0] = 0;
@@ -1580,7 +1598,8 @@ int ggs_sweep(ggs_handle *h, int32_t n_sweeps) {
   for (int32_t i = 0; i < n_sweeps; ++i) {
     // see theta_main: only where the z step is one launch pair (no parts), theta is drawn at all, and no collective is in the chain
     if (h) h->whole_sweep = true;
-    h->chain_on_side = h && h->theta_main && h->z_sliced && h->side_hot && h->ev_chain_done && !h->xg && !h->collapsed && !(h->flags & GGS_FLAG_PCGS);
+    h->chain_on_side = h && h->theta_main && h->z_sliced && h->side_hot && h->ev_chain_done && !h->xg && !h->collapsed && !(h->flags & GGS_FLAG_PCGS) &&
+                       h->D >= (int64_t)h->V;             // D x K gammas against V x K: otherwise the Phi chain is the longer leg and keeps the handle's stream
     int rc = ggs_sweep_begin(h);
     if (!rc) {
       h->in_sweep = false;

@@ -766,6 +766,7 @@ int z_phase(ggs_handle *h) {
     if (t_fused < t_split) h->z_split = false;
     HIP_TRY(h, hipEventRecord(E.e[1], h->stream));          // this sweep's z time: one launch of the form kept
   }
+  if (!h->hot_fork_from) h->hot_fork_from = E.e[1];        // the event just recorded serves as the hot chunks' fork: one packet less
   h->theta_ahead_iter = INT64_MIN;
   const bool ahead = h->overlap_theta && h->side && h->D > 0;
   const int32_t P = (int32_t)h->part_doc.size() - 1;   // 1 for a small corpus

@@ -806,7 +806,10 @@ int z_phase(ggs_handle *h) {
     StreamSwap on_chain(h, h->chain_on_side ? h->side_hot : h->stream);
     if ((rc = launch_count_rebuild(h))) return rc;   // this shard's counts; summed across shards by the caller
     HIP_TRY(h, hipEventRecord(E.e[3], h->stream));
+    if (h->chain_on_side && !h->whole_sweep) HIP_TRY(h, hipEventRecord(h->ev_chain_done, h->stream));
   }
+  // ggs_sweep_begin on its own: what the caller does on the handle's stream before ggs_sweep_end (a getter) sees the counts
+  if (h->chain_on_side && !h->whole_sweep) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_chain_done, 0));
   return GGS_OK;
 }
 
@@ -1569,12 +1572,19 @@ int ggs_init_phi(ggs_handle *h) {
 int ggs_set_iteration(ggs_handle *h, int32_t it) { if (!h) return GGS_ERR_BAD_ARG; h->iteration = it; return GGS_OK; }   // a theta drawn ahead for another iteration is simply not used
 int ggs_get_iteration(const ggs_handle *h, int32_t *it) { if (!h || !it) return GGS_ERR_BAD_ARG; *it = h->iteration; return GGS_OK; }
 
+// see theta_main: only where the z step is one launch pair (no parts), theta is drawn at all, no collective is in the chain, and
+// the theta draw (D x K gammas) is the longer leg (the Phi chain draws V x K)
+bool chain_on_side_ok(const ggs_handle *h) {
+  return h->theta_main && h->z_sliced && h->side_hot && h->ev_chain_done && !h->xg && !h->collapsed && !(h->flags & GGS_FLAG_PCGS) && h->D >= (int64_t)h->V;
+}
+
 int ggs_sweep_begin(ggs_handle *h) {
   int rc = require_ready(h, true);
   if (rc) return rc;
   if (h->in_sweep) return set_err(h, GGS_ERR_STATE, "ggs_sweep_begin called twice without ggs_sweep_end");
   h->iteration += 1;                                   // currentIteration = iteration, UPLDA:646
-  if ((rc = z_phase(h))) return rc;
+  h->chain_on_side = chain_on_side_ok(h);              // kept until the sweep's end
+  if ((rc = z_phase(h))) { h->chain_on_side = false; return rc; }
   h->in_sweep = true;
   return GGS_OK;
 }
@@ -1584,7 +1594,9 @@ int ggs_sweep_end(ggs_handle *h) {
   if (rc) return rc;
   if (!h->in_sweep) return set_err(h, GGS_ERR_STATE, "ggs_sweep_end without ggs_sweep_begin");
   h->in_sweep = false;
-  return finish_sweep(h, true);
+  rc = finish_sweep(h, true);
+  h->chain_on_side = false;
+  return rc;
 }
 
 int ggs_sweep_end_async(ggs_handle *h) {
@@ -1592,15 +1604,14 @@ int ggs_sweep_end_async(ggs_handle *h) {
   if (rc) return rc;
   if (!h->in_sweep) return set_err(h, GGS_ERR_STATE, "ggs_sweep_end_async without ggs_sweep_begin");
   h->in_sweep = false;
-  return finish_sweep(h, true, false);
+  rc = finish_sweep(h, true, false);
+  h->chain_on_side = false;
+  return rc;
 }
 
 int ggs_sweep(ggs_handle *h, int32_t n_sweeps) {
   for (int32_t i = 0; i < n_sweeps; ++i) {
-    // see theta_main: only where the z step is one launch pair (no parts), theta is drawn at all, and no collective is in the chain
     if (h) h->whole_sweep = true;
-    h->chain_on_side = h && h->theta_main && h->z_sliced && h->side_hot && h->ev_chain_done && !h->xg && !h->collapsed && !(h->flags & GGS_FLAG_PCGS) &&
-                       h->D >= (int64_t)h->V;             // D x K gammas against V x K: otherwise the Phi chain is the longer leg and keeps the handle's stream
     int rc = ggs_sweep_begin(h);
     if (!rc) {
       h->in_sweep = false;

@@ -197,6 +197,42 @@ def test_alternate_z_kernels_agree(native, oracle, K, mode, monkeypatch):
     compare_state(g, o, "z kernel mode %s K=%d" % (mode, K))
 
 
+@pytest.mark.parametrize("K,legs", [(20, "theta_main"), (100, "theta_main"), (100, "chain_main"), (150, "theta_main")])
+def test_more_documents_than_types_and_split_sweeps(native, oracle, monkeypatch, K, legs):
+    """With at least as many documents as word types (and K <= 184, no exchange) the theta draw is the longer leg behind the z step
+    and keeps the handle's stream, while the count rebuild and the Phi chain run on the side stream (GGS_DEBUG_THETA_MAIN=0: the
+    other way round) -- through ggs_sweep and through the split ggs_sweep_begin / ggs_sweep_end(_async) of the Java binding,
+    with getters between the two halves: after ggs_sweep_begin alone the counts of the z just drawn are there (UPLDA:1107-1221)."""
+    if legs == "chain_main":
+        monkeypatch.setenv("GGS_DEBUG_THETA_MAIN", "0")
+    c = random_corpus(500, 180, 120, seed=K + 5, empty_every=13)
+    assert c.num_docs >= c.num_types
+    g, o = make_pair(native, oracle, c, K, 0.1, 0.01, 31 + K, flags=native.FLAG_PARANOID, zseed=K + 1)
+    monkeypatch.delenv("GGS_DEBUG_THETA_MAIN", raising=False)
+    g.sweep(3)
+    o.sweep(3)
+    compare_state(g, o, "D >= V, K=%d %s: whole sweeps" % (K, legs))
+    for it in range(3):
+        g.sweep_begin()
+        o.set_iteration(o.iteration + 1)
+        o.z_step()
+        o.update_counts()
+        assert_bit_equal(g.get_z(), o.get_z(), "z between the halves")
+        assert_bit_equal(g.get_type_topic_counts(), o.get_type_topic_counts(), "n_wk between the halves")
+        assert_bit_equal(g.get_doc_topic_counts(), o.get_doc_topic_counts(), "n_dk between the halves")
+        if it == 1:
+            g.sweep_end_async()
+        else:
+            g.sweep_end()
+        o.sample_phi()
+        compare_state(g, o, "D >= V, K=%d %s: split sweep %d" % (K, legs, it + 1))
+    g.sweep(2)                                                      # and back: the theta drawn ahead by a split sweep is consumed by a whole one
+    o.sweep(2)
+    compare_state(g, o, "D >= V, K=%d %s: whole sweeps after split ones" % (K, legs))
+    t = g.get_timings()
+    assert t["sweeps"] == 8 and t["theta_ms"] > 0 and t["z_ms"] > 0 and t["merge_ms"] > 0 and t["phi_ms"] > 0
+
+
 def test_asymmetric_alpha_and_tiny_alpha(native, oracle):
     K = 5
     alphas = np.array([0.01, 5.0, 0.04, 0.1, 0.000001])    # ModifiedSimpleLDATest.java:12

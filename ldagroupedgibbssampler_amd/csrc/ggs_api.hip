@@ -104,7 +104,7 @@ struct ggs_handle {
   // against 0.50 for the counts and the Phi chain), and a dependency across streams takes 10-25 us to resolve -- so the
   // long leg stays on the handle's stream, directly between two z steps, and the short one (count rebuild + Phi chain)
   // goes to the high-priority stream the hot chunks used during the z step.  GGS_DEBUG_THETA_MAIN=0: the other way round.
-  bool theta_main = true, chain_on_side = false;
+  bool theta_main = true, chain_on_side = false, theta_main_always = false;   // GGS_DEBUG_THETA_MAIN=2: whatever D and V are (tests)
   bool whole_sweep = false;                            // inside ggs_sweep: z phase and Phi phase are enqueued back to back
   hipEvent_t hot_fork_from = nullptr;                  // an event already on the handle's stream that the hot kernel's stream may wait for instead of a fork event of its own
   hipEvent_t ev_chain_done = nullptr;
@@ -1227,7 +1227,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     if (hipEventCreate(&E.th0) != hipSuccess || hipEventCreate(&E.th1) != hipSuccess) return bail(GGS_ERR_HIP);
   }
   if (const char *e = debug_env("GGS_DEBUG_NO_OVERLAP")) h->overlap_theta = std::atoi(e) == 0;
-  if (const char *e = debug_env("GGS_DEBUG_THETA_MAIN")) h->theta_main = std::atoi(e) != 0;
+  if (const char *e = debug_env("GGS_DEBUG_THETA_MAIN")) { h->theta_main = std::atoi(e) != 0; h->theta_main_always = std::atoi(e) == 2; }
   if (const char *e = debug_env("GGS_DEBUG_GAMMA_QUEUE")) h->gamma_queue_cap = std::max(0, std::atoi(e));
   {
     // lowest priority: the theta draw fills whatever the Phi phase (on the caller's stream) leaves idle
@@ -1575,7 +1575,8 @@ int ggs_get_iteration(const ggs_handle *h, int32_t *it) { if (!h || !it) return 
 // see theta_main: only where the z step is one launch pair (no parts), theta is drawn at all, no collective is in the chain, and
 // the theta draw (D x K gammas) is the longer leg (the Phi chain draws V x K)
 bool chain_on_side_ok(const ggs_handle *h) {
-  return h->theta_main && h->z_sliced && h->side_hot && h->ev_chain_done && !h->xg && !h->collapsed && !(h->flags & GGS_FLAG_PCGS) && h->D >= (int64_t)h->V;
+  return h->theta_main && h->z_sliced && h->side_hot && h->ev_chain_done && !h->xg && !h->collapsed && !(h->flags & GGS_FLAG_PCGS) &&
+         (h->D >= (int64_t)h->V || h->theta_main_always);
 }
 
 int ggs_sweep_begin(ggs_handle *h) {

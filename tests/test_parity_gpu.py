@@ -197,7 +197,7 @@ def test_alternate_z_kernels_agree(native, oracle, K, mode, monkeypatch):
     compare_state(g, o, "z kernel mode %s K=%d" % (mode, K))
 
 
-@pytest.mark.parametrize("K,legs", [(20, "theta_main"), (100, "theta_main"), (100, "chain_main"), (150, "theta_main")])
+@pytest.mark.parametrize("K,legs", [(20, "theta_main"), (100, "theta_main"), (100, "chain_main"), (150, "theta_main"), (100, "forced"), (64, "forced")])
 def test_more_documents_than_types_and_split_sweeps(native, oracle, monkeypatch, K, legs):
     """With at least as many documents as word types (and K <= 184, no exchange) the theta draw is the longer leg behind the z step
     and keeps the handle's stream, while the count rebuild and the Phi chain run on the side stream (GGS_DEBUG_THETA_MAIN=0: the
@@ -205,8 +205,12 @@ def test_more_documents_than_types_and_split_sweeps(native, oracle, monkeypatch,
     with getters between the two halves: after ggs_sweep_begin alone the counts of the z just drawn are there (UPLDA:1107-1221)."""
     if legs == "chain_main":
         monkeypatch.setenv("GGS_DEBUG_THETA_MAIN", "0")
-    c = random_corpus(500, 180, 120, seed=K + 5, empty_every=13)
-    assert c.num_docs >= c.num_types
+    if legs == "forced":                                           # =2: the theta draw on the handle's stream whatever D and V are
+        monkeypatch.setenv("GGS_DEBUG_THETA_MAIN", "2")
+        c = random_corpus(140, 420, 150, seed=K + 5, empty_every=13)
+    else:
+        c = random_corpus(500, 180, 120, seed=K + 5, empty_every=13)
+        assert c.num_docs >= c.num_types
     g, o = make_pair(native, oracle, c, K, 0.1, 0.01, 31 + K, flags=native.FLAG_PARANOID, zseed=K + 1)
     monkeypatch.delenv("GGS_DEBUG_THETA_MAIN", raising=False)
     g.sweep(3)

@@ -89,6 +89,9 @@ def measured_traffic(kernel_prefixes, workload, sha):
     return None, "no profiles/r*pmc_counters.txt stamped with this workload and csrc hash"
 
 
+SLICED_MAX_K = 160      # ggs_api.hip: the score-register z kernels up to here, the one-pass streaming kernel above
+
+
 def z_kernels(K, scheme):
     kmax = 8 * ((K + 7) // 8)
     nb = 1
@@ -98,7 +101,7 @@ def z_kernels(K, scheme):
         return ["pcgs_sliced_kernel<%d, true>" % kmax] if K <= 192 else ["pcgs_wave_kernel<%d, true>" % nb]
     if scheme == "pcgs":
         return ["pcgs_sliced_kernel<%d>" % kmax] if K <= 192 else ["pcgs_wave_kernel<%d, false>" % nb]
-    return ["z_sliced_kernel<%d>" % kmax, "z_hot_kernel<%d>" % kmax] if K <= 184 else ["z_stream1_kernel"]
+    return ["z_sliced_kernel<%d>" % kmax, "z_hot_kernel<%d>" % kmax] if K <= SLICED_MAX_K else ["z_stream1_kernel"]
 
 
 def row_stats(corpus, K, num_hot):
@@ -113,7 +116,7 @@ def row_stats(corpus, K, num_hot):
     hot_tokens = int(np.sort(freq)[::-1][:num_hot].sum()) if num_hot > 0 else 0
     row = 8 * (K + (K & 1))
     ns = (K + 15) // 16
-    gathered = row + (0 if K <= 184 else 128 * (1 if ns <= 16 else 2 if ns <= 32 else 4))   # the one-pass kernel streams the row once plus one checkpoint group again
+    gathered = row + (0 if K <= SLICED_MAX_K else 128 * (1 if ns <= 16 else 2 if ns <= 32 else 4))   # the one-pass kernel streams the row once plus one checkpoint group again
     return {
         "compulsory_bytes": int(N * (3 * 4 + 4 + 2 * 4) + D * K * 8 + V * row),
         "cold_row_bytes": int((N - hot_tokens) * gathered),
@@ -148,10 +151,10 @@ def roofline_block(corpus, K, scheme, n_local, z_ms, workload, sha, num_hot, z_p
     hbm_bytes = traffic if traffic is not None else rs["compulsory_bytes"]
     alg = n_local * btok
     return {
-        # what the counters say bounds the kernel (profiles/): up to 184 topics one wave per SIMD issuing on half of its cycles
+        # what the counters say bounds the kernel (profiles/): up to 160 topics one wave per SIMD issuing on half of its cycles
         # on top of a row gather served by L2 / Infinity Cache; above, the latency of that gather.  `frac` is still
         # the memory-side traffic against the HBM peak -- the one roofline the byte counters can be read against.
-        "bound": "issue+cache-gather" if (K <= 184 and scheme == "ggs") else "cache-gather-latency",
+        "bound": "issue+cache-gather" if (K <= SLICED_MAX_K and scheme == "ggs") else "cache-gather-latency",
         "kernel": " + ".join(zk),
         "achieved": gbs(hbm_bytes),
         "peak": HBM_PEAK_GBS,
@@ -163,7 +166,7 @@ def roofline_block(corpus, K, scheme, n_local, z_ms, workload, sha, num_hot, z_p
         "traffic_source": src,
         "compulsory_bytes": rs["compulsory_bytes"],
         "limiter": ("instruction issue + L2/Infinity-Cache row gather (far from the HBM roofline: see row_gather and profiles/)"
-                    if K <= 184 else "L2/Infinity-Cache/HBM row gather latency (one pass over the rows; see row_gather and profiles/)"),
+                    if K <= SLICED_MAX_K else "L2/Infinity-Cache/HBM row gather latency (one pass over the rows; see row_gather and profiles/)"),
         "row_gather": {"row_bytes": rs["cold_row_bytes"], "GBps": gbs(rs["cold_row_bytes"]), "l2_ceiling_GBps": L2_GATHER_PEAK_GBS,
                        "infinity_cache_ceiling_GBps": MALL_GATHER_PEAK_GBS, "frac_of_l2_ceiling": round(gbs(rs["cold_row_bytes"]) / L2_GATHER_PEAK_GBS, 4),
                        "hot_token_frac_in_lds": rs["hot_token_frac"]},

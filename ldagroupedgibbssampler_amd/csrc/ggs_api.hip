@@ -100,7 +100,7 @@ struct ggs_handle {
   hipStream_t side = nullptr;
   hipStream_t side_hot = nullptr;                      // z_hot_kernel runs here, beside z_sliced_kernel on the main stream
   hipEvent_t ev_hot_fork = nullptr, ev_hot_join = nullptr;
-  // Whole sweeps on one GPU (ggs_sweep, K <= 184): the next theta is the LONGER of the two legs behind the z step (0.61 ms
+  // Whole sweeps on one GPU (ggs_sweep, K <= 160): the next theta is the LONGER of the two legs behind the z step (0.61 ms
   // against 0.50 for the counts and the Phi chain), and a dependency across streams takes 10-25 us to resolve -- so the
   // long leg stays on the handle's stream, directly between two z steps, and the short one (count rebuild + Phi chain)
   // goes to the high-priority stream the hot chunks used during the z step.  GGS_DEBUG_THETA_MAIN=0: the other way round.
@@ -1024,11 +1024,13 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     auto alloc_of = [&](int bytes) { return (bytes + kGranule - 1) / kGranule * kGranule; };
     const int pitch = h->pitch16 * 16, thbytes = ((h->Kp * 8 + 15) / 16) * 16;
     // the sliced kernel tags chunk tokens (word ids) in bit 30
-    // score-register kernels up to K = 184: measured on the benchmark corpus (sweep, ms) K=152: 2.64 sliced / 3.28 streaming,
-    // 168: 3.35 / 3.48, 184: 3.55 / 3.64, 192: 4.22 / 3.59 -- beyond that the one-pass streaming kernel with the next
-    // theta drawn beside it wins (the sliced kernels can take K up to kSlicedMaxTopics = 192: GGS_DEBUG_ZKERNEL=1)
+    // score-register kernels up to K = 160: measured on the benchmark corpus (sweep, ms; round 3) K=136: 2.13 sliced / 2.40
+    // streaming, 152: 2.33 / 2.56, 160: 2.40 / 2.50, 164: 3.06 / 2.83, 168: 3.06 / 2.75, 184: 3.24 / 2.94 (round 2: 184: 3.55 /
+    // 3.64, 192: 4.22 / 3.59) -- from KMAX = 168 on the cold kernel fills the whole register file (256 + 256) and the one-pass
+    // streaming kernel with the next theta drawn beside it wins (the sliced kernels can take K up to kSlicedMaxTopics = 192:
+    // GGS_DEBUG_ZKERNEL=1)
     const bool sliced_ok = h->K <= kSlicedMaxTopics && h->V < (1 << kSlotShift);
-    h->z_sliced = sliced_ok && h->K <= 184;
+    h->z_sliced = sliced_ok && h->K <= kSlicedDefaultTopics;
     h->z_stream = !h->z_sliced && h->K > 2 * kSliceTopics;
     if (const char *e = debug_env("GGS_DEBUG_ZKERNEL")) {          // 0: whole-row tile kernel, 1: sliced where possible, 2: streaming kernel where it applies, 3: its two-pass form
       const int mode = std::atoi(e);

@@ -63,6 +63,7 @@ constexpr int kSliceBytes = 64 * 128;     // 64 rows x 16 topics x 8 B
 #endif
 constexpr int kRingSlots = GGS_RING_SLOTS;
 constexpr int kSlicedMaxTopics = 192;     // 384 score registers (VGPR + AGPR) + working set < 512
+constexpr int kSlicedDefaultTopics = 160; // ... and the largest K the host gives to these kernels unasked (ggs_api.hip: measured break-even)
 constexpr int kPhiTailPadBytes = 1024;    // zeroed bytes after the last phiT row (see above; the pcgs kernel pads K to 48, the one-pass stream kernel to a multiple of 64)
 constexpr int kSlicedWaves = 4;           // waves per workgroup (one per SIMD), sharing the hot-word table
 constexpr int kChunkDocs = 2;             // documents a chunk may draw tokens from

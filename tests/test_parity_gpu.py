@@ -185,6 +185,8 @@ def test_alternate_z_kernels_agree(native, oracle, K, mode, monkeypatch):
     monkeypatch.setenv(*env)
     if str(mode).startswith("hotmargin"):
         monkeypatch.setenv("GGS_DEBUG_SPLIT", "2")
+    if str(mode).startswith("hotmargin") or mode in ("split", "fused", "nohot", "hot3"):
+        monkeypatch.setenv("GGS_DEBUG_ZKERNEL", "1")                # the score-register kernels also above their default range (K <= 160)
     if str(mode).startswith("margin") or mode == "ldsck" or str(mode).startswith("group") or mode in ("onerow", "tworows"):
         monkeypatch.setenv("GGS_DEBUG_ZKERNEL", "2")
     c = random_corpus(150, 400, 140, seed=K + (mode if isinstance(mode, int) else 7), empty_every=11)
@@ -199,7 +201,7 @@ def test_alternate_z_kernels_agree(native, oracle, K, mode, monkeypatch):
 
 @pytest.mark.parametrize("K,legs", [(20, "theta_main"), (100, "theta_main"), (100, "chain_main"), (150, "theta_main"), (100, "forced"), (64, "forced")])
 def test_more_documents_than_types_and_split_sweeps(native, oracle, monkeypatch, K, legs):
-    """With at least as many documents as word types (and K <= 184, no exchange) the theta draw is the longer leg behind the z step
+    """With at least as many documents as word types (and K <= 160, no exchange) the theta draw is the longer leg behind the z step
     and keeps the handle's stream, while the count rebuild and the Phi chain run on the side stream (GGS_DEBUG_THETA_MAIN=0: the
     other way round) -- through ggs_sweep and through the split ggs_sweep_begin / ggs_sweep_end(_async) of the Java binding,
     with getters between the two halves: after ggs_sweep_begin alone the counts of the z just drawn are there (UPLDA:1107-1221)."""

@@ -225,6 +225,29 @@ def cpu_baseline(corpus, K, alpha, beta, seed, z0, sample_docs):
     }
 
 
+_T0 = time.time()
+
+
+def stage(rank, msg):
+    """A timestamped line per rank on stderr: a stall of an N-rank run is then attributable to a stage."""
+    sys.stderr.write("[bench %s +%6.1fs rank %d] %s\n" % (time.strftime("%H:%M:%S"), time.time() - _T0, rank, msg))
+    sys.stderr.flush()
+
+
+def sha256_of(a):
+    import hashlib
+
+    import numpy as np
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def state_digests(h, z_local=None):
+    """sha256 of what a rank holds after its sweeps: its z shard, the (replicated) Phi, tokensPerTopic (a COLLECTIVE
+    getter with an exchange attached), its theta rows.  Bit patterns, not values."""
+    z = h.get_z() if z_local is None else z_local
+    return {"z": sha256_of(z), "phi": sha256_of(h.get_phi()), "n_k": sha256_of(h.get_topic_totals()), "theta": sha256_of(h.get_theta()), "tokens": int(z.size)}
+
+
 def make_handle(native, K, V, args, local_rank):
     return native.GGSHandle(K, V, args.alpha, args.beta, args.seed, device_id=local_rank,
                             flags={"ggs": 0, "pcgs": native.FLAG_PCGS, "collapsed": native.FLAG_COLLAPSED}[args.scheme])
@@ -316,6 +339,8 @@ def main():
                          "the native exchange then runs over its callback provider with host staging")
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (rehearsal only; the number is not a multi-GPU result)")
     ap.add_argument("--no-weak-leg", action="store_true", help="N>1: skip the second measurement (the other scaling regime)")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="N>1 / --force-sharded: skip the comparison of the N-rank end state with one handle over the whole corpus (parity_vs_one_gpu)")
     ap.add_argument("--force-sharded", action="store_true",
                     help="run the doc-sharded path (process group + RCCL exchange) even with one rank; for testing")
     ap.add_argument("--simulate-rank", type=int, default=0)
@@ -389,6 +414,7 @@ def main():
             raise
 
     def run_sharded_on(h, corpus, weak):
+        stage(rank, "%s leg: corpus built (D=%d, N=%d), attaching the exchange" % ("weak" if weak else "strong", corpus.num_docs, corpus.num_tokens))
         if weak:
             sizes = gather_shard_sizes(corpus, rank, world, device="cuda" if args.backend == "nccl" else None)
             total_docs, total_tokens = sum(d for d, _ in sizes), sum(t for _, t in sizes)
@@ -398,24 +424,83 @@ def main():
             total_docs, total_tokens = corpus.num_docs, corpus.num_tokens
             sh = ShardedGGS(h, exchange_factory(), corpus, rank, world)
             sh.set_z_global(java_lcg_initial_z(corpus.num_tokens, K, args.seed))
+        xinfo = h.exchange_info() if args.exchange == "native" else {"provider": "torch.distributed all-reduce", "comm_nranks": world, "comm_rank": rank, "nranks": world}
+        stage(rank, "exchange attached, shard uploaded (%d documents, %d tokens), initial z / counts / Phi in place; exchange: %s"
+              % (sh.local.num_docs, sh.local.num_tokens, json.dumps(xinfo)))
 
         def run(n):
             # the sweeps are enqueued back to back, exchange included; the host waits once per batch of 5
             for i in range(0, n, 5):
                 sh.sweep(min(5, n - i))
         run(args.warmup)
+        stage(rank, "warm-up done (%d sweeps)" % args.warmup)
         h.reset_timings()
         fence()
         t0 = time.perf_counter()
         run(args.steps)
         fence()
         dt = max_over_ranks(time.perf_counter() - t0)
+        stage(rank, "timed region done: %d sweeps in %.2f ms (max over ranks)" % (args.steps, dt * 1e3))
         tm = h.get_timings()
         h.check_invariants()            # with the native exchange: a collective call (gathers the corpus-wide counts)
         res = dict(dt=dt, phases=phases(tm), docs=total_docs, tokens=total_tokens, n_local=sh.local.num_tokens, V=corpus.num_types,
-                   info=h.launch_info(), local=sh.local)
+                   info=h.launch_info(), local=sh.local, exchange=xinfo)
+        if not weak and not args.no_verify:
+            # what this rank ends with, for the comparison with ONE handle over the whole corpus (verify_against_one_gpu)
+            res["digests"] = state_digests(h)
+            res["tok_range"] = (int(sh.tok_base), int(sh.tok_base + sh.local.num_tokens))
+            res["corpus"] = corpus
         h.close()                       # before a second leg builds its handle: hardware queues are few
         return res
+
+    def verify_against_one_gpu(r):
+        """The N-rank state against ONE handle over the whole corpus after the same number of sweeps from the same z0:
+        every rank's z shard, theta rows and Phi, and tokensPerTopic, as sha256 of the bit patterns.  Sharding is exact
+        (identical Philox element ids on every rank), so anything but equality is a bug in the exchange.
+        Rank 0 runs the one-GPU handle (the same --warmup + --steps sweeps; the others wait at the barrier)."""
+        mine = dict(r["digests"], tok_range=r["tok_range"], rank=rank, z_form=r["info"].get("z_form"), comm_nranks=r["exchange"].get("comm_nranks"))
+        every = [None] * world
+        if world > 1:
+            dist.all_gather_object(every, mine)
+        else:
+            every = [mine]
+        out = None
+        if rank == 0:
+            stage(rank, "verification: one handle over the whole corpus, %d sweeps" % (args.warmup + args.steps))
+            corpus = r["corpus"]
+            h1 = make_handle(native, K, corpus.num_types, args, local_rank)
+            try:
+                h1.set_corpus(corpus.doc_ptr, corpus.tokens)
+                h1.set_z(java_lcg_initial_z(corpus.num_tokens, K, args.seed), redraw_phi=True)
+                for n in (args.warmup, args.steps):             # the same batches; only the number of sweeps matters to the state
+                    for i in range(0, n, 5):
+                        h1.sweep(min(5, n - i))
+                z1, th1 = h1.get_z(), h1.get_theta()
+                one = state_digests(h1, z1)
+                bounds = even_split(corpus.num_docs, world)
+                bad = []
+                for e in every:
+                    a, b = e["tok_range"]
+                    d0, d1 = bounds[e["rank"]], bounds[e["rank"] + 1]
+                    if sha256_of(z1[a:b]) != e["z"]:
+                        bad.append("z of rank %d" % e["rank"])
+                    if sha256_of(th1[d0:d1]) != e["theta"]:
+                        bad.append("theta of rank %d" % e["rank"])
+                    if e["phi"] != one["phi"]:
+                        bad.append("phi on rank %d" % e["rank"])
+                    if e["n_k"] != one["n_k"]:
+                        bad.append("n_k on rank %d" % e["rank"])
+                out = {"parity_vs_one_gpu": not bad,
+                       "compared": "sha256 of the bit patterns of z and theta (per shard), phi and n_k (on every rank) after %d sweeps from the same z0, against ONE handle "
+                                   "over the whole corpus run by rank 0 after the timed region" % (args.warmup + args.steps),
+                       "mismatches": bad, "one_gpu_z_form": h1.launch_info().get("z_form"), "z_form_per_rank": [e["z_form"] for e in every],
+                       "comm_nranks_per_rank": [e["comm_nranks"] for e in every]}
+            finally:
+                h1.close()
+            stage(rank, "verification %s" % ("OK: bit-identical to the one-GPU run" if out["parity_vs_one_gpu"] else "FAILED: %s" % out["mismatches"]))
+        if world > 1:
+            dist.barrier()
+        return out
 
     fallback = []
 
@@ -435,7 +520,7 @@ def main():
             return res
         if args.exchange != "native":
             raise RuntimeError(err or "another rank failed")
-        sys.stderr.write("[bench rank %d] native exchange failed (%s); falling back to --exchange torch\n" % (rank, err or "on another rank"))
+        stage(rank, "native exchange failed (%s); falling back to --exchange torch" % (err or "on another rank"))
         fallback.append(err or "failed on another rank")
         args.exchange = "torch"
         return run_sharded(weak)
@@ -443,11 +528,17 @@ def main():
     sha = csrc_sha16()
     other = None
     corpus = z0 = None
+    verification = None
     if sharded:
         weak_first = args.scaling == "weak"
         r = run_sharded_or_fall_back(weak_first)
+        r2 = None
         if world > 1 and not args.no_weak_leg:
             r2 = run_sharded_or_fall_back(not weak_first)
+        strong_leg = r2 if weak_first else r
+        if strong_leg is not None and "digests" in strong_leg:
+            verification = verify_against_one_gpu(strong_leg)
+        if r2 is not None:
             other = {"value": round(r2["tokens"] * args.steps / r2["dt"] / 1e6, 3), "unit": "M tokens/s",
                      "ms_per_step": round(r2["dt"] / args.steps * 1e3, 4), "phase_ms_per_sweep": r2["phases"],
                      "workload": ("every rank brings D=%d documents: D=%d, N=%d tokens over %d ranks" % (args.docs, r2["docs"], r2["tokens"], world)) if not weak_first
@@ -493,8 +584,19 @@ def main():
             "config": {"workload": workload, "parallelism": par},
             "roofline": roofline_block(r["local"], K, args.scheme, r["n_local"], r["phases"]["z_ms"], workload, sha, r["info"].get("num_hot", 0), r["info"].get("z_parts", 1)),
             "phase_ms_per_sweep": r["phases"],
+            # which z kernel(s) ran, and which of the two forms of the K <= 160 step the first z step's timed comparison kept
+            "z_step": {k: r["info"].get(k) for k in ("z_kernel", "z_form", "z_form_calibrated", "z_parts", "num_hot")},
             "build": {"csrc_sha16": sha},
         }
+        if sharded:
+            # who carried the collectives, as the library reports it: for RCCL the rank count read back from the communicator
+            x = r.get("exchange", {})
+            line["exchange"] = {"provider": x.get("provider"), "rccl_nranks": x.get("comm_nranks") if x.get("provider") == "rccl" else None,
+                                "nranks": x.get("nranks"), "topic_slice_rank0": [x.get("k_begin"), x.get("k_end")]}
+            if verification is not None:
+                line.update({"parity_vs_one_gpu": verification["parity_vs_one_gpu"], "verification": verification})
+            else:
+                line["parity_vs_one_gpu"] = None
         if other is not None:
             line["weak_scaling" if args.scaling == "strong" else "strong_scaling"] = other
         if not sharded and args.simulate_world <= 1:
@@ -505,6 +607,8 @@ def main():
         print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0 and verification is not None and not verification["parity_vs_one_gpu"]:
+        sys.exit("bench.py: the %d-rank end state differs from the one-GPU run: %s" % (world, verification["mismatches"]))
 
 
 if __name__ == "__main__":

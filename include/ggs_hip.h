@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GGS_ABI_VERSION 3
+#define GGS_ABI_VERSION 4
 
 typedef struct ggs_handle ggs_handle;
 
@@ -261,6 +261,11 @@ int ggs_group_gather_counts(ggs_handle **handles, int32_t n);
 int ggs_attach_null_exchange(ggs_handle *h, int32_t rank, int32_t nranks);
 /* rank, nranks and the rank's topic slice [k_begin, k_end) (0, 1, 0, K without an exchange) */
 int ggs_get_exchange_info(const ggs_handle *h, int32_t *rank, int32_t *nranks, int32_t *k_begin, int32_t *k_end);
+/* Who carries the collectives: *provider = 0 none, 1 RCCL, 2 the caller's callbacks, 3 the null timing aid; for RCCL
+ * *comm_nranks / *comm_rank are read back from the communicator itself (ncclCommCount / ncclCommUserRank: what RCCL
+ * saw, not what the caller passed to the attach call; -1 if the query fails), otherwise the attach call's values.
+ * A benchmark line quotes these beside its number.  ABI version 4. */
+int ggs_get_exchange_provider(const ggs_handle *h, int32_t *provider, int32_t *comm_nranks, int32_t *comm_rank);
 
 /* ---- state copy-back (the Java getters) ------------------------------------ */
 int ggs_get_z(ggs_handle *h, int32_t *z /*N*/);                         /* getZIndicators, MSLDA:464-477 */
@@ -287,6 +292,13 @@ int ggs_get_num_hot_words(ggs_handle *h, int32_t *num_hot);
  * step is cut into (K > 192; the next theta of a part is drawn beside the following parts) -- bench.py scales the
  * per-launch PMC counters of a profile by it. */
 int ggs_get_z_parts(ggs_handle *h, int32_t *parts);
+/* Which z kernel(s) the sweeps of the current corpus run, so that a benchmark line can NAME what it timed instead of
+ * assuming it: *kernel = 0 whole-row tile kernel, 1 score-register kernels (K <= 160), 2 one-pass streaming kernel,
+ * 3 its two-pass cross-check, 4 pcgs lane-per-document, 5 pcgs wave-per-document; *form (kernel 1 only, else 0) =
+ * 1 split (cold chunks and hot chunks as two kernels side by side), 2 fused (one kernel takes both in turn);
+ * *calibrated = 1 once the first z step of the corpus has timed both forms and kept the faster (0 before that, and
+ * when a form is forced or there is nothing to split).  ABI version 4. */
+int ggs_get_z_form(ggs_handle *h, int32_t *kernel, int32_t *form, int32_t *calibrated);
 /* ---- primitives, exported so the parity tests can pin each layer ----------- */
 int ggs_debug_philox(int32_t device_id, int64_t n, const uint32_t *ctr /*n*4*/, const uint32_t *key /*n*2*/, uint32_t *out /*n*4*/);
 int ggs_debug_math(int32_t device_id, int32_t op /*0 log,1 pow,2 sqrt,3 div*/, int64_t n, const double *x, const double *y, double *out);

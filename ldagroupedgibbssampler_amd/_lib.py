@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GGS_HIP_LIB") or os.path.join(CSRC, "libggs_hip.so")   # override: kernel experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ggs_hip.h")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 class GGSConfig(C.Structure):
@@ -106,6 +106,7 @@ SIGNATURES = {
     "ggs_get_launch_info": (C.c_int, [_vp, _lp, _ip, _ip]),
     "ggs_get_num_hot_words": (C.c_int, [_vp, _ip]),
     "ggs_get_z_parts": (C.c_int, [_vp, _ip]),
+    "ggs_get_z_form": (C.c_int, [_vp, _ip, _ip, _ip]),
     "ggs_attach_exchange": (C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(GGSExchangeOps)]),
     "ggs_rccl_unique_id": (C.c_int, [_vp]),
     "ggs_attach_rccl": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),
@@ -118,6 +119,7 @@ SIGNATURES = {
     "ggs_group_gather_counts": (C.c_int, [C.POINTER(_vp), C.c_int32]),
     "ggs_attach_null_exchange": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "ggs_get_exchange_info": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
+    "ggs_get_exchange_provider": (C.c_int, [_vp, _ip, _ip, _ip]),
     "ggs_debug_philox": (C.c_int, [C.c_int32, C.c_int64, _up, _up, _up]),
     "ggs_debug_math": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _dp, _dp, _dp]),
     "ggs_debug_draw": (C.c_int, [C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int64,

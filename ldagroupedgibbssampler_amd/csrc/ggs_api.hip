@@ -1699,7 +1699,7 @@ int ggs_attach_null_exchange(ggs_handle *h, int32_t rank, int32_t nranks) {
   if (rc) return rc;
   auto *x = new (std::nothrow) Exchange();
   if (!x) return GGS_ERR_HIP;
-  x->rank = rank; x->nranks = nranks;
+  x->rank = rank; x->nranks = nranks; x->is_null = true;
   x->ops.struct_size = (int32_t)sizeof(ggs_exchange_ops); x->ops.ctx = x;
   x->ops.reduce_scatter_i32 = xops::null_reduce_scatter_i32;
   x->ops.all_gather_f64 = xops::null_all_gather<double>;
@@ -1755,6 +1755,20 @@ int ggs_get_exchange_info(const ggs_handle *h, int32_t *rank, int32_t *nranks, i
   if (nranks) *nranks = h->xg ? h->xg->nranks : 1;
   if (k_begin) *k_begin = h->k0;
   if (k_end) *k_end = h->k0 + h->Ks;
+  return GGS_OK;
+}
+
+int ggs_get_exchange_provider(const ggs_handle *h, int32_t *provider, int32_t *comm_nranks, int32_t *comm_rank) {
+  if (!h) return GGS_ERR_BAD_ARG;
+  const Exchange *x = h->xg;
+  if (provider) *provider = !x ? 0 : x->api ? 1 : x->is_null ? 3 : 2;
+  int n = x ? x->nranks : 1, r = x ? x->rank : 0;
+  if (x && x->api && x->comm) {                         // what the communicator itself reports, not what the caller passed in
+    if (x->api->CommCount && x->api->CommCount(x->comm, &n) != ncclSuccess) n = -1;
+    if (x->api->CommUserRank && x->api->CommUserRank(x->comm, &r) != ncclSuccess) r = -1;
+  }
+  if (comm_nranks) *comm_nranks = n;
+  if (comm_rank) *comm_rank = r;
   return GGS_OK;
 }
 
@@ -2288,6 +2302,16 @@ int ggs_get_z_parts(ggs_handle *h, int32_t *parts) {
   if (!h || !parts) return GGS_ERR_BAD_ARG;
   const int32_t P = (int32_t)h->part_doc.size() - 1;
   *parts = (h->z_stream && h->overlap_theta && P > 1 && !(h->flags & GGS_FLAG_PCGS)) ? P : 1;
+  return GGS_OK;
+}
+
+int ggs_get_z_form(ggs_handle *h, int32_t *kernel, int32_t *form, int32_t *calibrated) {
+  if (!h) return GGS_ERR_BAD_ARG;
+  const bool pcgs = (h->flags & GGS_FLAG_PCGS) != 0;
+  const bool splittable = !pcgs && h->z_sliced && h->Cs > h->Cc && h->Cc > 0;
+  if (kernel) *kernel = pcgs ? (h->pcgs_wave ? 5 : 4) : h->z_sliced ? 1 : h->z_stream ? (h->z_two_pass ? 3 : 2) : 0;
+  if (form) *form = (!pcgs && h->z_sliced) ? (splittable && h->z_split ? 1 : 2) : 0;
+  if (calibrated) *calibrated = (splittable && h->z_split_tried && !h->z_split_forced && h->z_split_allowed) ? 1 : 0;
   return GGS_OK;
 }
 

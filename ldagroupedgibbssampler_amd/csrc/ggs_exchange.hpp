@@ -32,6 +32,8 @@ struct RcclApi {
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclCommCount) CommCount = nullptr;           // optional: what the communicator itself says (ggs_get_exchange_provider)
+  decltype(&ncclCommUserRank) CommUserRank = nullptr;
 
   // nullptr + err when librccl cannot be loaded
   static RcclApi *get(std::string &err) {
@@ -57,6 +59,8 @@ struct RcclApi {
       api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
       api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
       api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+      api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.lib, "ncclCommCount"));
+      api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(dlsym(api.lib, "ncclCommUserRank"));
     });
     if (!load_err.empty()) { err = load_err; return nullptr; }
     return &api;
@@ -69,6 +73,7 @@ struct Exchange {
   ncclComm_t comm = nullptr;       // RCCL provider
   bool own_comm = false;
   RcclApi *api = nullptr;
+  bool is_null = false;            // the timing aid (ggs_attach_null_exchange)
   std::string err;                 // text of the last failed collective
 };
 

@@ -119,7 +119,11 @@ class GGSHandle:
     def exchange_info(self):
         r, n, a, b = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         self._chk(self._L.ggs_get_exchange_info(self._h, C.byref(r), C.byref(n), C.byref(a), C.byref(b)))
-        return {"rank": r.value, "nranks": n.value, "k_begin": a.value, "k_end": b.value}
+        p, cn, cr = C.c_int32(), C.c_int32(), C.c_int32()
+        self._chk(self._L.ggs_get_exchange_provider(self._h, C.byref(p), C.byref(cn), C.byref(cr)))
+        return {"rank": r.value, "nranks": n.value, "k_begin": a.value, "k_end": b.value,
+                "provider": {0: "none", 1: "rccl", 2: "callbacks", 3: "null (timing aid)"}.get(p.value, str(p.value)),
+                "comm_nranks": cn.value, "comm_rank": cr.value}
 
     def __del__(self):
         try:
@@ -282,7 +286,15 @@ class GGSHandle:
         self._chk(self._L.ggs_get_launch_info(self._h, C.byref(c), C.byref(l), C.byref(b)))
         self._chk(self._L.ggs_get_num_hot_words(self._h, C.byref(nh)))
         self._chk(self._L.ggs_get_z_parts(self._h, C.byref(zp)))
-        return {"num_chunks": c.value, "lds_bytes_z": l.value, "docs_per_block_theta": b.value, "num_hot": nh.value, "z_parts": zp.value}
+        zk, zf, zc = C.c_int32(), C.c_int32(), C.c_int32()
+        self._chk(self._L.ggs_get_z_form(self._h, C.byref(zk), C.byref(zf), C.byref(zc)))
+        return {"num_chunks": c.value, "lds_bytes_z": l.value, "docs_per_block_theta": b.value, "num_hot": nh.value, "z_parts": zp.value,
+                "z_kernel": Z_KERNEL_NAMES.get(zk.value, str(zk.value)), "z_form": {0: "n/a", 1: "split", 2: "fused"}.get(zf.value, str(zf.value)),
+                "z_form_calibrated": bool(zc.value)}
+
+
+Z_KERNEL_NAMES = {0: "z_kernel (whole-row tiles)", 1: "z_sliced_kernel + z_hot_kernel (score registers)", 2: "z_stream1_kernel (one pass)",
+                  3: "z_stream_kernel (two passes)", 4: "pcgs_sliced_kernel (lane per document)", 5: "pcgs_wave_kernel (wave per document)"}
 
 
 class GGSGroup:

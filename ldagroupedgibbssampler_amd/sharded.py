@@ -158,9 +158,24 @@ def rccl_exchange(rank, world_size, group=None):
     def factory(engine):
         import torch.distributed as dist
         from . import native
-        box = [native.rccl_unique_id() if rank == 0 else None]
+        # ncclCommInitRank is a blocking collective: a rank that cannot even load librccl must say so BEFORE the others
+        # enter it, or they wait for ever.  Every rank therefore makes the id call (rank 0's is the one used) and the
+        # ranks agree on the outcome first.
+        uid, err = None, None
+        try:
+            uid = native.rccl_unique_id()
+        except Exception as e:      # noqa: BLE001 -- reported to every rank below
+            err = "rank %d: %s: %s" % (rank, type(e).__name__, e)
+        box = [uid if rank == 0 else None]
         if world_size > 1:
+            errs = [None] * world_size
+            dist.all_gather_object(errs, err, group=group)
+            errs = [e for e in errs if e]
+            if errs:
+                raise RuntimeError("RCCL is not usable on every rank: " + "; ".join(errs))
             dist.broadcast_object_list(box, src=0, group=group)
+        elif err:
+            raise RuntimeError(err)
         engine.attach_rccl(rank, world_size, box[0])
         return NativeExchange()
     return factory

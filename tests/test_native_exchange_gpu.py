@@ -41,15 +41,20 @@ def reference_run(oracle, corpus, K, alpha, beta, seed, zseed, sweeps, scheme="g
     return o
 
 
-@pytest.mark.parametrize("scheme,K", [("ggs", 20), ("ggs", 100), ("ggs", 200), ("pcgs", 24)])
-def test_one_rank_through_rccl(native, oracle, scheme, K):
+@pytest.mark.parametrize("scheme,K,V", [("ggs", 20, 700), ("ggs", 100, 700), ("ggs", 200, 700), ("pcgs", 24, 700),
+                                        # V >= 1024 (16 segments of 64 rows): the vocabulary travels in TWO halves, the first on the
+                                        # communication stream under the draw of the second (this path had no parity test)
+                                        ("ggs", 20, 1300), ("ggs", 100, 2100), ("pcgs", 24, 1100), ("ggs", 200, 1029)])
+def test_one_rank_through_rccl(native, oracle, scheme, K, V):
     """ncclCommInitRank with one rank: the whole exchange path (own stream, slice-major send buffer, reduce-scatter,
-    slice draw, all-gather, repack, lazily gathered counts) must not change a bit."""
-    c = random_corpus(240, 700, 140, seed=11 + K, empty_every=8)
+    slice draw, all-gather in one piece or in two halves, repack, lazily gathered counts) must not change a bit."""
+    c = random_corpus(240, V, 140, seed=11 + K, empty_every=8)
     flags = (native.FLAG_PCGS if scheme == "pcgs" else 0) | native.FLAG_SAVE_PHI_MEAN | native.FLAG_PARANOID
     h = native.GGSHandle(K, c.num_types, 0.1, 0.01, 99, flags=flags, phi_burn_in=1, phi_mean_thin=1)
     h.attach_rccl(0, 1, native.rccl_unique_id())
-    assert h.exchange_info() == {"rank": 0, "nranks": 1, "k_begin": 0, "k_end": K}
+    info = h.exchange_info()
+    assert {k: info[k] for k in ("rank", "nranks", "k_begin", "k_end")} == {"rank": 0, "nranks": 1, "k_begin": 0, "k_end": K}
+    assert info["provider"] == "rccl" and info["comm_nranks"] == 1 and info["comm_rank"] == 0   # read back from the communicator
     h.set_corpus(c.doc_ptr, c.tokens)
     h.set_z(java_lcg_initial_z(c.num_tokens, K, 3), redraw_phi=True)
     h.sweep(2)
@@ -171,13 +176,16 @@ def _thread_rank(native, tr, rank, world, whole, K, scheme, zseed, sweeps, out, 
         tr.bar.abort()
 
 
-@pytest.mark.parametrize("scheme,K,world,docs", [("ggs", 100, 3, 310), ("ggs", 7, 4, 310), ("pcgs", 24, 2, 310), ("ggs", 200, 3, 310), ("ggs", 2, 3, 310),
-                                                 ("ggs", 5, 4, 3), ("pcgs", 5, 3, 2)])
-def test_topic_sliced_exchange_between_handles(native, oracle, scheme, K, world, docs):
+@pytest.mark.parametrize("scheme,K,world,docs,V", [("ggs", 100, 3, 310, 900), ("ggs", 7, 4, 310, 900), ("pcgs", 24, 2, 310, 900), ("ggs", 200, 3, 310, 900),
+                                                   ("ggs", 2, 3, 310, 900), ("ggs", 5, 4, 3, 40), ("pcgs", 5, 3, 2, 40),
+                                                   # the two-half all-gather (V >= 1024): unequal slices, a rank without a topic, pcgs, a ragged last segment
+                                                   ("ggs", 100, 3, 310, 2100), ("ggs", 2, 3, 200, 1100), ("pcgs", 24, 2, 310, 1500), ("ggs", 7, 4, 200, 1025)])
+def test_topic_sliced_exchange_between_handles(native, oracle, scheme, K, world, docs, V):
     """`world` doc shards, each a handle with the callback exchange: z, theta per shard and counts, Phi, phi mean on
     every rank equal the unsharded oracle.  K = 100 over 3 ranks has unequal slices (34, 33, 33); K = 2 over 3 leaves
-    rank 2 without a topic; 3 documents over 4 ranks (2 over 3) leave a rank without a document."""
-    whole = random_corpus(docs, 900 if docs > 10 else 40, 120 if docs > 10 else 25, seed=5 + K, empty_every=9 if docs > 10 else 0)
+    rank 2 without a topic; 3 documents over 4 ranks (2 over 3) leave a rank without a document; V >= 1024 sends the
+    gammas in two halves (the first on the communication stream under the draw of the second)."""
+    whole = random_corpus(docs, V, 120 if docs > 10 else 25, seed=5 + K, empty_every=9 if docs > 10 else 0)
     sweeps = 4
     tr, out, errs = ThreadTransport(world), [None] * world, []
     ts = [threading.Thread(target=_thread_rank, args=(native, tr, r, world, whole, K, scheme, 17, sweeps, out, errs)) for r in range(world)]
@@ -202,7 +210,8 @@ def test_topic_sliced_exchange_between_handles(native, oracle, scheme, K, world,
     ll_docs = 0.0
     for r, p in enumerate(out):
         a, b = lay.slice_of(r)
-        assert p["info"] == {"rank": r, "nranks": world, "k_begin": a, "k_end": b}
+        assert {k: p["info"][k] for k in ("rank", "nranks", "k_begin", "k_end")} == {"rank": r, "nranks": world, "k_begin": a, "k_end": b}
+        assert p["info"]["provider"] == "callbacks" and p["info"]["comm_nranks"] == world
         assert_bit_equal(p["nwk"], o.get_type_topic_counts(), "n_wk on rank %d" % r)
         assert_bit_equal(p["nk"], o.get_topic_totals(), "n_k on rank %d" % r)
         assert_bit_equal(p["phi"], o.get_phi(), "phi on rank %d" % r)
@@ -263,10 +272,11 @@ def test_two_processes_native_exchange_over_gloo(oracle, tmp_path, scheme):
         assert_bit_equal(p["ho_docs"], ho_docs, "held-out per document")
 
 
-def test_one_process_group_api(native, oracle):
+@pytest.mark.parametrize("V", [300, 1200])
+def test_one_process_group_api(native, oracle, V):
     """ggs_group_create / ggs_group_set_z / ggs_group_sweep with the one device there is (ncclCommInitAll, every
-    collective inside ncclGroupStart/End)."""
-    c = random_corpus(150, 300, 90, seed=3, empty_every=6)
+    collective inside ncclGroupStart/End); V = 1200: the all-gather in two halves, grouped step by step."""
+    c = random_corpus(150, V, 90, seed=3, empty_every=6)
     K = 40
     g = native.GGSGroup(K, c.num_types, 0.1, 0.01, 31337, device_ids=[0])
     h = g.handles[0]
@@ -341,13 +351,13 @@ class OneThreadTransport:
                 lambda s_, r_, c, st: self._arrive("ag32", rank, s_, r_, c))
 
 
-@pytest.mark.parametrize("scheme", ["ggs", "pcgs", "collapsed"])
-def test_group_entry_points_from_one_thread_over_a_deferred_transport(native, oracle, scheme):
+@pytest.mark.parametrize("scheme,V", [("ggs", 260), ("pcgs", 260), ("collapsed", 260), ("ggs", 1100), ("pcgs", 1290)])
+def test_group_entry_points_from_one_thread_over_a_deferred_transport(native, oracle, scheme, V):
     """ggs_group_adopt + ggs_group_set_z / ggs_group_sweep / ggs_group_gather_counts with TWO handles driven from one
     thread -- the call order a JVM would use -- over a transport that moves data only when both handles have made the
     call: every collective step is issued for all handles before any handle goes on, so nothing waits on a call that
     the same thread has yet to make.  Results: the one-handle run's, bit for bit."""
-    c = random_corpus(170, 260, 70, seed=12, empty_every=7)
+    c = random_corpus(170, V, 70, seed=12, empty_every=7)
     K, n = 13, 2
     flags = {"ggs": 0, "pcgs": native.FLAG_PCGS, "collapsed": native.FLAG_COLLAPSED}[scheme]
     tr = OneThreadTransport(n)
@@ -384,6 +394,28 @@ def test_group_entry_points_from_one_thread_over_a_deferred_transport(native, or
     g.close()
     for h in hs:
         h.close()
+
+
+@pytest.mark.parametrize("split", [1, 3, 6])
+def test_forced_split_point_of_the_all_gather(native, oracle, monkeypatch, split):
+    """GGS_DEBUG_AGSPLIT=k: the first k 64-row segments travel as the first half whatever V is -- the split point must
+    not matter (one segment, an uneven cut, all but one)."""
+    monkeypatch.setenv("GGS_DEBUG_AGSPLIT", str(split))
+    c = random_corpus(120, 440, 90, seed=31, empty_every=7)       # 7 segments, the last one ragged
+    K = 17
+    h = native.GGSHandle(K, c.num_types, 0.1, 0.01, 12, flags=native.FLAG_SAVE_PHI_MEAN, phi_burn_in=1, phi_mean_thin=1)
+    h.attach_rccl(0, 1, native.rccl_unique_id())
+    h.set_corpus(c.doc_ptr, c.tokens)
+    h.set_z(java_lcg_initial_z(c.num_tokens, K, 8), redraw_phi=True)
+    h.sweep(3)
+    o = reference_run(oracle, c, K, 0.1, 0.01, 12, 8, 3, save_mean=True)
+    assert_bit_equal(h.get_z(), o.get_z(), "z")
+    assert_bit_equal(h.get_phi(), o.get_phi(), "phi")
+    gm, gn = h.get_phi_mean()
+    om, on = o.get_phi_mean()
+    assert gn == on
+    assert_bit_equal(gm, om, "phi mean")
+    h.close()
 
 
 def test_attach_order_and_errors(native):

@@ -32,6 +32,7 @@ final class GGSDevice {
 	private int[] flatZ;                              // N, reused for every copy in either direction
 	private boolean javaStateStale = false;
 	private boolean testSetUploaded = false;
+	private boolean sweepsInFlight = false;           // a ggs_sweep_end_async whose errors have not been asked for yet
 
 	GGSDevice(UncollapsedParallelLDA model, int schemeFlags) {
 		this.model = model;
@@ -48,6 +49,10 @@ final class GGSDevice {
 		long[] docPtr = new long[D + 1];
 		for (int d = 0; d < D; d++)
 			docPtr[d + 1] = docPtr[d] + ((FeatureSequence) model.data.get(d).instance.getData()).getLength();
+		// one Java array holds the corpus (int indices), and one device at most 2^31 - 1 tokens (ggs_set_corpus)
+		if (docPtr[D] > Integer.MAX_VALUE)
+			throw new IllegalArgumentException("Corpus of " + docPtr[D] + " tokens: more than Integer.MAX_VALUE ("
+					+ Integer.MAX_VALUE + ") cannot be flattened into one int[]; split the corpus over several JVMs");
 		int N = (int) docPtr[D];
 		int[] tokens = new int[N];
 		flatZ = new int[N];
@@ -92,9 +97,22 @@ final class GGSDevice {
 		javaStateStale = true;
 	}
 
-	/** samplePhi (GGS:139-171). */
-	void phiStep() {
-		if (!multi()) GGSNative.nSweepEnd(handles[0]);
+	/** samplePhi (GGS:139-171).  readBack = a diagnostic or getter of this iteration will look at the result: wait for the
+	 *  device and raise what the sweep flagged (ggs_sweep_end).  Otherwise the Phi draw is only enqueued
+	 *  (ggs_sweep_end_async): the device's error flags are sticky and surface at the next waiting call -- the next
+	 *  readBack iteration, syncToJava(), a diagnostic -- and the host round trip per iteration is saved
+	 *  (the loop it serves: UPLDA:645-930). */
+	void phiStep(boolean readBack) {
+		if (multi()) return;                          // ggs_group_sweep did the whole iteration and waited
+		if (readBack) { GGSNative.nSweepEnd(handles[0]); sweepsInFlight = false; }
+		else { GGSNative.nSweepEndAsync(handles[0]); sweepsInFlight = true; }
+	}
+
+	/** Waits for enqueued sweeps and throws what they flagged (the IllegalStateException of GGS:84-85,116-118). */
+	private void settle() {
+		if (!sweepsInFlight) return;
+		GGSNative.nSynchronize(handles[0]);
+		sweepsInFlight = false;
 	}
 
 	/** setZIndicators (UPLDA:1797-1843) */
@@ -141,16 +159,24 @@ final class GGSDevice {
 	/** modelLogLikelihood (UPLDA:1644-1758) on the device-resident state: the documents' side summed over the shards
 	 *  plus one topic side. */
 	double modelLogLikelihood() {
+		settle();
 		if (multi()) GGSNative.nGroupGatherCounts(handles);   // the per-handle call would start a collective one thread cannot complete
-		double ll = GGSNative.nModelLogLikelihoodTopicSide(handles[0]);
-		for (long h : handles) ll += GGSNative.nModelLogLikelihoodDocSide(h);
+		double ll = 0;
+		for (int r = 0; r < handles.length; r++) {            // ONE evaluation per handle: {its documents' side, the replicated topic side}
+			double[] sides = GGSNative.nModelLogLikelihood(handles[r]);
+			ll += sides[0] + (r == 0 ? sides[1] : 0.0);
+		}
 		return ll;
 	}
 
 	/** The body of the private computeLogPosterior (UPLDA:1573-1634), for its call site UPLDA:820-821. */
 	double logPosterior() {
-		double lp = GGSNative.nLogPosteriorTopicSide(handles[0]);
-		for (long h : handles) lp += GGSNative.nLogPosteriorDocSide(h);
+		settle();
+		double lp = 0;
+		for (int r = 0; r < handles.length; r++) {            // one pass over each shard (under pcgs it also redraws the shard's theta)
+			double[] sides = GGSNative.nLogPosterior(handles[r]);
+			lp += sides[0] + (r == 0 ? sides[1] : 0.0);
+		}
 		return lp;
 	}
 
@@ -170,6 +196,7 @@ final class GGSDevice {
 	/** evaluator.evaluateLeftToRight(testSet, numParticles, null) (UPLDA:622,841) on the device-resident counts. */
 	double heldOutLogLikelihood(int numParticles) {
 		if (!testSetUploaded) throw new IllegalStateException("no test set: addTestInstances first");
+		settle();
 		if (multi()) GGSNative.nGroupGatherCounts(handles);
 		return GGSNative.nHeldOutLogLikelihood(handles[0], numParticles);
 	}
@@ -177,6 +204,7 @@ final class GGSDevice {
 	/** Copies the device state into the Java fields the diagnostics and getters read. */
 	void syncToJava() {
 		if (!javaStateStale) return;
+		settle();
 		if (multi()) GGSNative.nGroupGatherCounts(handles);   // the counts live as topic slices on the GPUs
 		int D = model.data.size(), K = model.numTopics, V = model.numTypes;
 		for (int r = 0; r < handles.length; r++) {

@@ -26,6 +26,8 @@ final class GGSNative {
 	static native void nSetIteration(long h, int iteration);                              // ggs_set_iteration
 	static native void nSweepBegin(long h);                                               // ggs_sweep_begin
 	static native void nSweepEnd(long h);                                                 // ggs_sweep_end
+	static native void nSweepEndAsync(long h);                                            // ggs_sweep_end_async: enqueued, not waited for
+	static native void nSynchronize(long h);                                              // ggs_synchronize: waits, raises what the async sweeps flagged
 	static native void nSampleZGivenPhi(long h, int sweeps);                              // ggs_sample_z_given_phi
 	static native void nGetZ(long h, int[] z);                                            // ggs_get_z
 	static native void nGetTypeTopicCounts(long h, int[] nwk);                            // ggs_get_type_topic_counts, [V][K]
@@ -35,10 +37,8 @@ final class GGSNative {
 	static native int nGetPhiMean(long h, double[] phiMean);                              // ggs_get_phi_mean; returns noSampledPhi
 	static native void nGetTheta(long h, long docBegin, long docEnd, double[] theta);     // ggs_get_theta
 	static native double[] nGetTimings(long h);                                           // ggs_get_timings: theta, z, merge, phi, exchange (ms, cumulative)
-	static native double nModelLogLikelihoodDocSide(long h);                              // ggs_model_log_likelihood, first output
-	static native double nModelLogLikelihoodTopicSide(long h);                            // ggs_model_log_likelihood, second output
-	static native double nLogPosteriorDocSide(long h);                                    // ggs_log_posterior, first output
-	static native double nLogPosteriorTopicSide(long h);                                  // ggs_log_posterior, second output
+	static native double[] nModelLogLikelihood(long h);                                   // ggs_model_log_likelihood: {doc side, topic side} of ONE evaluation
+	static native double[] nLogPosterior(long h);                                         // ggs_log_posterior: {doc side, topic side} of ONE evaluation
 	static native void nSetTestCorpus(long h, long[] docPtr, int[] tokens);               // ggs_set_test_corpus
 	static native double nHeldOutLogLikelihood(long h, int numParticles);                 // ggs_heldout_log_likelihood
 	static native void nSetGlobalTokenCount(long h, long n);                              // ggs_set_global_token_count

@@ -51,16 +51,21 @@ public class LDAPartiallyCollapsedGibbsSamplerHIP extends LDAPartiallyCollapsedG
 
 	@Override
 	protected void samplePhi() {                        // LDAPartiallyCollapsedGibbsSampler.java:48-83
-		device.phiStep();
+		device.phiStep(readsBackThisIteration());     // no diagnostic due: ggs_sweep_end_async, the host does not wait (UPLDA:645-930)
 		if (savePhiMeans() && samplePhiThisIteration()) noSampledPhi++;
+	}
+
+	/** Does anything of this iteration read the sampler's state on the host?  The diagnostics of UPLDA:829-905 do when
+	 *  compute_likelihood is set, a test set is attached or the iteration has reached start_diagnostic. */
+	private boolean readsBackThisIteration() {
+		int startDiagnostic = config.getStartDiagnostic(LDAConfiguration.START_DIAG_DEFAULT);
+		return config.computeLikelihood() || testSet != null || (startDiagnostic > 0 && currentIteration >= startDiagnostic);
 	}
 
 	@Override
 	public void postPhi() {                             // refresh Java fields only if this iteration reads them
 		super.postPhi();
-		int startDiagnostic = config.getStartDiagnostic(LDAConfiguration.START_DIAG_DEFAULT);
-		if (config.computeLikelihood() || testSet != null || (startDiagnostic > 0 && currentIteration >= startDiagnostic))
-			device.syncToJava();
+		if (readsBackThisIteration()) device.syncToJava();
 	}
 
 	@Override

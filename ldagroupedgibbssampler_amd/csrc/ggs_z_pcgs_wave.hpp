@@ -27,16 +27,47 @@
 //
 // Layout: a lane owns the 16-byte units u = lane + 64 j (topics 2u, 2u + 1) of a row, j < NB: every load instruction of
 // the wave reads 1 KiB of consecutive bytes of the row, and block j (topics 128 j .. 128 j + 127) is in lane order.
-// The next token's row is loaded into a second register set while the current token is computed.
+// The rows of the next one or two tokens are loaded into further register sets while the current token is computed
+// (two ahead up to K = 1024: round 4; the wave then waits for a row only when the memory system is more than two
+// tokens' arithmetic behind).
 // LDS per wave: counts int32 [128 NB] and alpha fp64 [128 NB]: 12 KiB at K = 1024.
 #pragma once
 #include "ggs_z_pcgs.hpp"
 
 namespace ggs {
 
+// How far ahead of the token being sampled its phiT row is requested: as many tokens as register sets of K/64 doubles
+// fit beside the working set WITH the resident waves kept (what the z step lives on): two up to K = 512, one at K = 1024
+// (three waves per SIMD; measured 15.0 ms against 16.9 with two sets ahead and two waves).  The sets rotate
+// by position in a loop unrolled kDepth + 1 times, so no row is ever copied.  Depth 0 (K > 2048: a row is 128 registers
+// per lane, two of them plus the working set spilled 450 bytes per lane to scratch and the collapsed z step took 637 ms
+// instead of 116; K = 2048 by measurement: pcgs 41.0 ms with depth 0 and six waves per CU against 48.8 with depth 1 and
+// four, collapsed 47.9 against 42.5) keeps ONE set: the token's row is
+// dead once the block the draw falls into has been picked out of it, and the next token's row is requested into the same
+// registers right there, under the rest of the step (the scan of the deciding block, the stores, the next token's start).
+#ifndef GGS_PCGS_WAVE_GROUPS
+#define GGS_PCGS_WAVE_GROUPS 8
+#endif
+#ifndef GGS_PCGS_WAVE_DEPTH_AT_16
+#define GGS_PCGS_WAVE_DEPTH_AT_16 0
+#endif
+#ifndef GGS_PCGS_WAVE_DEPTH_AT_8
+#define GGS_PCGS_WAVE_DEPTH_AT_8 1
+#endif
 template <int NB, bool COLLAPSED>
-__global__ __launch_bounds__(64) void pcgs_wave_kernel(PcgsParams p, double margin_scale) {
+constexpr int pcgs_wave_depth() { return NB < 8 ? 2 : NB == 8 ? GGS_PCGS_WAVE_DEPTH_AT_8 : NB == 16 ? (COLLAPSED ? 1 : GGS_PCGS_WAVE_DEPTH_AT_16) : 0; }
+
+// waves per SIMD the register allocation aims for: three at K = 1024 (12 waves of 12 KiB LDS per CU), where resident waves
+// decide the speed (measured, z step at K = 1024: 15.0 ms with 3 waves per SIMD and rows one token ahead, 16.9 with 2 waves
+// and rows two tokens ahead)
+template <int NB>
+constexpr int pcgs_wave_min_waves() { return NB == 8 ? 3 : 1; }
+
+template <int NB, bool COLLAPSED>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(pcgs_wave_min_waves<NB>()))) void pcgs_wave_kernel(PcgsParams p, double margin_scale) {
   constexpr int KT = NB * 128;
+  constexpr int kDepth = pcgs_wave_depth<NB, COLLAPSED>(), kSets = kDepth + 1;
+  constexpr int kNG = NB < GGS_PCGS_WAVE_GROUPS ? NB : GGS_PCGS_WAVE_GROUPS, kG = NB / kNG;   // groups of the block search, blocks per group
   extern __shared__ __align__(16) unsigned char smem[];
   int32_t *cnt = reinterpret_cast<int32_t *>(smem);                        // [KT]
   double *alb = reinterpret_cast<double *>(smem + (size_t)KT * 4);         // [KT] alpha, zero padded
@@ -46,15 +77,18 @@ __global__ __launch_bounds__(64) void pcgs_wave_kernel(PcgsParams p, double marg
   for (int k = lane; k < KT; k += 64) alb[k] = k < K ? p.alpha[k] : 0.0;
 
   struct Row { double a[NB], b[NB]; };
-  auto load_row = [&](int w, Row &r) {
+  auto load_row = [&](int w, Row &r) __attribute__((always_inline)) {
+    // UNCONDITIONAL loads (a lane past the row's last unit reads that unit again: its topics are >= K and score 0 by the
+    // guards of `scores`): a load under a lane mask or a branch makes the compiler's s_waitcnt accounting fall back to
+    // vmcnt(0) at the next use of ANY row -- which waited for the rows requested ahead as well and undid the prefetch
     const double2 *row = reinterpret_cast<const double2 *>(p.phiT + (size_t)w * p.Kp);
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-      const int u = lane + 64 * j;
-      const double2 v = u < units ? row[u] : double2{0.0, 0.0};
+      const double2 v = row[min(lane + 64 * j, units - 1)];
       r.a[j] = v.x; r.b[j] = v.y;
     }
   };
+  auto wave_sum = [&](double x) { return read_lane(wave_inclusive_scan(x), 63); };   // any association: a proposal only
 
   for (int64_t di = blockIdx.x; di < p.num_docs; di += gridDim.x) {
     const int d = p.order[di];
@@ -71,7 +105,7 @@ __global__ __launch_bounds__(64) void pcgs_wave_kernel(PcgsParams p, double marg
     // Per 64 tokens, lane-parallel and one chunk ahead of the sequential loop: the word, the old topic, the position in the
     // word-sorted order, the token's uniform (Philox) and, COLLAPSED, the own-topic psi -- none of them depends on what the
     // loop does to earlier tokens (z[beg + t] is only written at step t; the psi's counts are the sweep-start ones), so
-    // the loop itself waits for no memory but the phiT rows, and those are a token ahead.
+    // the loop itself waits for no memory but the phiT rows, and those are kDepth tokens ahead.
     struct Chunk { int w, zold, ip; double U, own; };
     auto load_chunk = [&](int t0) {
       Chunk c{0, 0, 0, 0.0, 0.0};
@@ -87,24 +121,35 @@ __global__ __launch_bounds__(64) void pcgs_wave_kernel(PcgsParams p, double marg
       }
       return c;
     };
-    Chunk ch = load_chunk(0), chn = ch;
-    Row cur, nxt;
-    load_row(__builtin_amdgcn_readlane(ch.w, 0), cur);
-    for (int t = 0; t < len; ++t) {
+    Chunk ch = load_chunk(0), chn = len > 64 ? load_chunk(64) : ch;
+    // word of token t (wave-uniform), t within the current chunk or the next one
+    auto word_of = [&](int t_in_chunk) {
+      return t_in_chunk < 64 ? __builtin_amdgcn_readlane(ch.w, t_in_chunk) : __builtin_amdgcn_readlane(chn.w, t_in_chunk - 64);
+    };
+    Row rows[kSets];
+    static_for<0, (kDepth > 0 ? kDepth : 1)>([&](auto i) {
+      constexpr int u = decltype(i)::value;
+      load_row(word_of(u), rows[u]);                                       // u >= len: lane u of the chunk holds word 0
+    });
+
+    // one token: `cur` holds its row, the row of token t + kDepth goes into `tgt` (the set the previous token has just left)
+    auto step = [&](const int t, const Row &cur, Row &tgt) __attribute__((always_inline)) {
       const int tl = t & 63;
-      if (tl == 0 && t + 64 < len) chn = load_chunk(t + 64);               // the chunk after this one: in flight for 64 tokens
-      const int w = __builtin_amdgcn_readlane(ch.w, tl), zold = __builtin_amdgcn_readlane(ch.zold, tl), ip = __builtin_amdgcn_readlane(ch.ip, tl);
+      const int zold = __builtin_amdgcn_readlane(ch.zold, tl), ip = __builtin_amdgcn_readlane(ch.ip, tl);
       const double U = read_lane(ch.U, tl), own = COLLAPSED ? read_lane(ch.own, tl) : 0.0;
-      (void)w;
-      if (t + 1 < len) load_row(tl == 63 ? __builtin_amdgcn_readlane(chn.w, 0) : __builtin_amdgcn_readlane(ch.w, tl + 1), nxt);   // in flight while this token is computed
+      if constexpr (kDepth > 0) load_row(word_of(tl + kDepth), tgt);       // in flight while this token and the next are computed; past the document's end: some valid row, never used
+      bool refilled = false;                                               // kDepth == 0: `tgt` IS `cur`, refilled in mid-step (below)
       if (lane == 0) cnt[zold] -= 1;                                       // UPLDA:1494
-      __syncthreads();
+      // One wave per workgroup: its LDS operations execute in program order, so all that is needed between lane 0's update
+      // and the other lanes' reads is that the COMPILER keeps that order.  (__syncthreads() here also meant
+      // s_waitcnt vmcnt(0): every token waited for the rows requested ahead.)
+      __builtin_amdgcn_wave_barrier();
 
       // scores of this lane's two topics of block j (UPLDA:1509-1513 / MSLDA:196-203): the same two roundings as in Java.
       // They are recomputed where they are needed again (the deciding block; the replay): keeping K doubles per wave in
       // LDS for that cost half of the resident waves, and waves in flight are what this kernel's row traffic lives on
       // (K = 1024: 27.0 ms per z step with 7 waves per CU, 20.2 with 12).
-      auto scores = [&](int j, double pa, double pb, double &qa, double &qb) {
+      auto scores = [&](int j, double pa, double pb, double &qa, double &qb) __attribute__((always_inline)) {
         const int k = 2 * (lane + 64 * j);
         const int2 n = *reinterpret_cast<const int2 *>(&cnt[k]);
         const double2 al = *reinterpret_cast<const double2 *>(&alb[k]);
@@ -112,36 +157,87 @@ __global__ __launch_bounds__(64) void pcgs_wave_kernel(PcgsParams p, double marg
         qa = k < K ? ((double)n.x + al.x) * pa : 0.0;
         qb = k + 1 < K ? ((double)n.y + al.y) * pb : 0.0;
       };
-      // block sums in any order: a proposal only
-      double tot[NB];                                                      // wave-uniform (scalar registers)
+      // The lane's share of every GROUP of kG adjacent blocks (at most 8 groups) and of every aligned range of groups (a
+      // binary tree, lane-local adds only); wave reductions then run ONLY along the path of the block search: 1 (the total)
+      // + log2(groups) (the descent) + at most kG - 1 (inside the group, its blocks' scores recomputed) instead of one per
+      // block -- sums in any association, which is all a proposal needs (header).
+      double gv[kNG];                                                      // the lane's share of group g; ranges of groups are added up where the search asks for them
 #pragma unroll
-      for (int j = 0; j < NB; ++j) {
-        double qa, qb;
-        scores(j, cur.a[j], cur.b[j], qa, qb);
-        tot[j] = read_lane(wave_inclusive_scan(qa + qb), 63);
+      for (int g = 0; g < kNG; ++g) {
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < kG; ++i) {
+          double qa, qb;
+          scores(g * kG + i, cur.a[g * kG + i], cur.b[g * kG + i], qa, qb);
+          acc = i == 0 ? qa + qb : acc + (qa + qb);
+        }
+        gv[g] = acc;
+        // wide rows: one group's LDS reads (counts, alpha) in flight at a time -- hoisted all at once they cost more
+        // registers than two rows of K/64 doubles leave (NB = 32: 147 dwords per lane spilled to scratch, the z step 3x slower)
+        if constexpr (NB >= 16) asm volatile("" ::: "memory");
       }
-      double s_hat = 0.0;
+      auto range_sum = [&](auto lo_c, auto width_c) __attribute__((always_inline)) {   // lane-local, pairwise
+        constexpr int lo = decltype(lo_c)::value, width = decltype(width_c)::value;
+        double x[width];
 #pragma unroll
-      for (int j = 0; j < NB; ++j) s_hat += tot[j];
+        for (int i = 0; i < width; ++i) x[i] = gv[lo + i];
+#pragma unroll
+        for (int w = width; w > 1; w /= 2)
+#pragma unroll
+          for (int i = 0; i < w / 2; ++i) x[i] = x[2 * i] + x[2 * i + 1];
+        return x[0];
+      };
+      // the total as left half + right half: the first level of the descent then has its `left` already
+      double root_left = 0.0, s_hat;
+      if constexpr (kNG > 1) {
+        root_left = wave_sum(range_sum(std::integral_constant<int, 0>{}, std::integral_constant<int, kNG / 2>{}));
+        s_hat = root_left + wave_sum(range_sum(std::integral_constant<int, kNG / 2>{}, std::integral_constant<int, kNG / 2>{}));
+      } else {
+        s_hat = wave_sum(gv[0]);
+      }
 
       const double T = U * s_hat;
       const double delta = ((double)(K + 16) * s_hat) * 0x1p-51 * margin_scale;
 
       int new_topic = -1;
       if (T > delta && s_hat < __builtin_huge_val()) {
-        double before = 0.0;                                               // C' at the start of the block
-        int js = -1;
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-          if (js < 0) {
-            if (T - (before + tot[j]) <= delta) js = j;                    // the crossing is in this block, or too close to its end to call
-            else before += tot[j];
+        // descend: at a node covering groups [lo, lo + width) with C' = `before` at its start, the crossing is in the left
+        // half iff the prefix at the left half's end is past T or too close to call; inside the group, block by block
+        double before = 0.0;
+        int js = 0;
+        auto descend = [&](auto self, auto lo_c, auto width_c) __attribute__((always_inline)) -> void {
+          constexpr int lo = decltype(lo_c)::value, width = decltype(width_c)::value;
+          if constexpr (width == 1) {
+            js = lo * kG + kG - 1;                                         // the group's last block unless an earlier one takes it
+            bool found = false;
+            static_for<0, kG - 1>([&](auto ic) {
+              constexpr int j = lo * kG + decltype(ic)::value;
+              if (!found) {                                                // wave-uniform
+                double qa, qb;
+                scores(j, cur.a[j], cur.b[j], qa, qb);
+                const double blk = wave_sum(qa + qb);
+                if (T - (before + blk) <= delta) { js = j; found = true; }
+                else before += blk;
+              }
+            });
+          } else {
+            const double left = (lo == 0 && width == kNG) ? root_left
+                                                          : wave_sum(range_sum(std::integral_constant<int, lo>{}, std::integral_constant<int, width / 2>{}));
+            if (T - (before + left) <= delta) {
+              self(self, std::integral_constant<int, lo>{}, std::integral_constant<int, width / 2>{});
+            } else {
+              before += left;
+              self(self, std::integral_constant<int, lo + width / 2>{}, std::integral_constant<int, width / 2>{});
+            }
           }
-        if (js >= 0) {
+        };
+        descend(descend, std::integral_constant<int, 0>{}, std::integral_constant<int, kNG>{});
+        {
           double pa = 0.0, pb = 0.0;                                       // this lane's row entries of block js (a static select: registers are not indexable)
 #pragma unroll
           for (int j = 0; j < NB; ++j)
             if (j == js) { pa = cur.a[j]; pb = cur.b[j]; }
+          if constexpr (kDepth == 0) { load_row(word_of(tl + 1), tgt); refilled = true; }   // the row is dead: the next token's takes its registers
           double a, b;
           scores(js, pa, pb, a, b);
           const double c_ab = before + wave_inclusive_scan(a + b), c_a = c_ab - b;   // prefixes after this lane's first / second topic
@@ -158,12 +254,16 @@ __global__ __launch_bounds__(64) void pcgs_wave_kernel(PcgsParams p, double marg
           }
         }
       }
-      if (new_topic < 0) {
+      if (__builtin_expect(new_topic < 0, 0)) {
         // undecided (or Java would throw): replay the token as Java runs it, UPLDA:1509-1531 (negated walk in counting form,
         // see ggs_z_sliced.hpp): the scores in k order -- block by block, lane by lane, first then second topic -- read
         // out of the lanes that hold them; every lane runs the same two chains.  (As a function of its own, reading the
         // row from memory again so that the main path need not keep it for this: measured slower, 32.7 ms against 20.2
         // at K = 1024 -- the compiler then holds the kernel at 128 registers and spills scalars in the token loop.)
+        if constexpr (kDepth == 0) {
+          if (refilled) load_row(word_of(tl), tgt);                        // the token's own row once more (this path is taken by one token in 10^9)
+          refilled = false;
+        }
         double sum = 0.0;
 #pragma unroll
         for (int j = 0; j < NB; ++j) {
@@ -193,15 +293,23 @@ __global__ __launch_bounds__(64) void pcgs_wave_kernel(PcgsParams p, double marg
           new_topic = new_topic < 0 ? 0 : K - 1;
         }
       }
-      __syncthreads();                                                     // every lane has read the counts
+      if constexpr (kDepth == 0) { if (!refilled) load_row(word_of(tl + 1), tgt); }
+      __builtin_amdgcn_wave_barrier();                                     // every lane's reads of the counts are issued before the update
       if (lane == 0) {
         cnt[new_topic] += 1;                                               // UPLDA:1535
         p.z[beg + t] = new_topic;
         p.zw[ip] = new_topic;
       }
-      cur = nxt;
-      if (tl == 63) ch = chn;
-    }
+      if (tl == 63) {                                                      // the next chunk becomes the current one, the one after it is requested
+        ch = chn;
+        if (t + 1 + 64 < len) chn = load_chunk(t + 1 + 64);
+      }
+    };
+    for (int t0 = 0; t0 < len; t0 += kSets)
+      static_for<0, kSets>([&](auto i) {
+        constexpr int u = decltype(i)::value;
+        if (t0 + u < len) step(t0 + u, rows[u], rows[(u + kDepth) % kSets]);
+      });
   }
 }
 

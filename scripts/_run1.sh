@@ -1,6 +1,8 @@
 cd $GRAFT_REPO_ROOT
-export GGS_DEBUG=1
-GGS_DEBUG_NO_OVERLAP=1 bash scripts/trace_sweep.sh sim8_noov --simulate-world 8 > gpurun_out/timeline_sim8_noov.txt 2>&1; tail -32 gpurun_out/timeline_sim8_noov.txt
-for pc in 1 3 6; do GGS_DEBUG_PHICOLS=$pc python3 bench.py --simulate-world 8 --no-cpu-baseline --no-extra-configs --steps 20 --warmup 3 2>/dev/null | python3 -c "
+timeout -k 10 900 python -m pytest tests/test_parity_gpu.py tests/test_collapsed_gpu.py -x -q -k "pcgs or parallel_schedule or wave" 2>&1 | tail -6 > gpurun_out/t_pcgs.log; cat gpurun_out/t_pcgs.log
+for lib in "" "$GRAFT_REPO_ROOT/scripts/bin/libggs_d16_0.so"; do
+for args in "--scheme pcgs --topics 2048 --steps 3 --warmup 1" "--scheme collapsed --topics 2048 --steps 3 --warmup 1" "--scheme pcgs --topics 4096 --steps 2 --warmup 1" "--scheme collapsed --topics 4096 --steps 2 --warmup 1"; do
+GGS_HIP_LIB=$lib python3 bench.py --no-cpu-baseline --no-extra-configs $args 2>/dev/null | python3 -c "
 import json,sys
-l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('phicols $pc', l['ms_per_step'], l['phase_ms_per_sweep'])"; done
+l=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('lib=$lib $args', l['ms_per_step'], l['phase_ms_per_sweep']['z_ms'])"
+done; done

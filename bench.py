@@ -183,7 +183,8 @@ def cpu_baseline(corpus, K, alpha, beta, seed, z0, sample_docs):
       cpu_ref_mt    the oracle: C restatement of the Java GGS sweep with the Java layouts kept (phi[K][V] column gather,
                     atomic [K][V] deltas, dynamic chunks of 100 documents, the Phi draw one topic per thread as GGS:139-171
                     hands it out) -- the headline `value`
-      cpu_ref_1t    the same on one thread, on a fiftieth of the sample
+      cpu_ref_1t    the same on one thread, on a fiftieth of the sample, the z step (what scales with the tokens) and the Phi
+                    draw (K*V gammas whatever the sample) timed apart; its `value` is the z-step rate
       cpu_tuned_mt  what a good CPU implementation does with the same arithmetic: transposed phiT rows, no per-document
                     allocation, no atomics (counts rebuilt per word), the Phi draw spread over (topic, 1024-type tile)
                     units so that every thread has work at K = 100
@@ -214,7 +215,28 @@ def cpu_baseline(corpus, K, alpha, beta, seed, z0, sample_docs):
         sweep = [run(sample_docs, t, tuned, n_sw) for t in counts]
         best = max(sweep, key=lambda r: r["value"])
         out[tag] = dict(best, thread_sweep={str(r["threads"]): r["value"] for r in sweep})
-    out["cpu_ref_1t"] = run(max(sample_docs // 50, 200), 1, False, 1)
+
+    def run_1t(docs):
+        """One thread, the phases timed apart: the z step scales with the tokens of the sample, the Phi draw (K*V gammas) does
+        not -- a single tokens/s figure over both would say more about the sample size than about the sampler."""
+        sub, _, _ = corpus.shard(0, min(docs, corpus.num_docs))
+        o = O.OracleSampler(K, corpus.num_types, alpha, beta, seed, threads=1)
+        o.set_corpus(sub.doc_ptr, sub.tokens)
+        o.set_z(z0[:sub.num_tokens], redraw_phi=True)
+        o.set_iteration(1)
+        t0 = time.perf_counter()
+        o.z_step()                     # GGS:47-132 for every document of the sample: theta draw + token loop
+        t1 = time.perf_counter()
+        o.update_counts()              # UPLDA:1107-1221
+        t2 = time.perf_counter()
+        o.sample_phi()                 # GGS:139-198: K*V gammas whatever the sample
+        t3 = time.perf_counter()
+        o.close()
+        return {"value": round(sub.num_tokens / (t1 - t0) / 1e6, 3), "unit": "M tokens/s (z step only: theta draw + token loop)", "threads": 1,
+                "z_step_s": round(t1 - t0, 3), "update_counts_s": round(t2 - t1, 3), "phi_draw_s": round(t3 - t2, 3),
+                "phi_draw_gammas_per_s": round(K * corpus.num_types / max(t3 - t2, 1e-9)),
+                "sample": "first %d docs (%d tokens), full V=%d, K=%d, one sweep with its three phases timed apart" % (sub.num_docs, sub.num_tokens, corpus.num_types, K)}
+    out["cpu_ref_1t"] = run_1t(max(sample_docs // 50, 200))
     return {
         "value": out["cpu_ref_mt"]["value"],
         "unit": "M tokens/s",

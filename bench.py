@@ -97,10 +97,10 @@ def z_kernels(K, scheme):
     nb = 1
     while nb * 128 < K + (K & 1):
         nb *= 2
-    if scheme == "collapsed":
-        return ["pcgs_sliced_kernel<%d, true>" % kmax] if K <= 192 else ["pcgs_wave_kernel<%d, true>" % nb]
+    if scheme == "collapsed":                            # ggs_api.hip: kCollapsedWaveFromTopics / kPcgsWaveFromTopics, the measured switch points
+        return ["pcgs_sliced_kernel<%d, true>" % kmax] if K <= 96 else ["pcgs_wave_kernel<%d, true>" % nb]
     if scheme == "pcgs":
-        return ["pcgs_sliced_kernel<%d>" % kmax] if K <= 192 else ["pcgs_wave_kernel<%d, false>" % nb]
+        return ["pcgs_sliced_kernel<%d>" % kmax] if K <= 176 else ["pcgs_wave_kernel<%d, false>" % nb]
     return ["z_sliced_kernel<%d>" % kmax, "z_hot_kernel<%d>" % kmax] if K <= SLICED_MAX_K else ["z_stream1_kernel"]
 
 

@@ -72,9 +72,10 @@ enum {
   GGS_FLAG_PCGS = 1 << 2          /* scheme=pcgs (LDAPartiallyCollapsedGibbsSampler): the z step is UPLDA:1466-1544,
                                      score = (n_dk + alpha_k)*phi[k][w], sequential inside a document; no theta draw;
                                      counts, Phi draw and exchange exactly as for ggs.  Any K up to 4096 and any
-                                     document length: up to 192 topics one LANE owns a document (64 documents per
-                                     wave, int16 counts in LDS); above that, or when a document has 32768 tokens or
-                                     more, one WAVE owns a document (int32 counts, the topics spread over the lanes). */
+                                     document length: up to 176 topics (scheme collapsed: 96 -- the measured break-even
+                                     points) one LANE owns a document (64 documents per wave, int16 counts in LDS); above
+                                     that, or when a document has 32768 tokens or more, one WAVE owns a document (int32
+                                     counts, the topics spread over the lanes). */
 };
 
 /* RNG stream addressing.  The reference draws from ThreadLocalRandom and a

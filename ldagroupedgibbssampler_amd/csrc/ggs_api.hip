@@ -525,9 +525,13 @@ const void *pcgs_wave_kernel_for(int nb, bool collapsed) {
   return collapsed ? reinterpret_cast<const void *>(pcgs_wave_kernel<32, true>) : reinterpret_cast<const void *>(pcgs_wave_kernel<32, false>);
 }
 constexpr int kPcgsWaveMaxTopics = 32 * 128;          // 4096: two rows of K/64 doubles per lane in registers
-// Above the score-register kernels' 192 topics the wave-per-document kernel takes over.  Measured on the benchmark corpus
-// (z step, ms): K = 160: 4.2 lane-per-document / 6.9 wave-per-document, 192: 6.0 / 7.0, 256: 16.5 (two-pass) / 7.3, 320: 20.1 / 10.5.
-constexpr int kPcgsWaveFromTopics = kSlicedMaxTopics;
+// Where the wave-per-document kernel takes over from the lane-per-document score-register kernels (which exist up to 192
+// topics; their 176..192 variants spill 12-164 bytes per lane to scratch).  Measured on the benchmark corpus, z step in ms,
+// lane-per-document / wave-per-document (round 4, after the wave kernel's rework; the wave kernel's time steps with the
+// number of 128-topic blocks: flat up to 128 topics, flat from 129 to 256):
+//   pcgs       K = 100: 2.51 / 3.33, 128: 3.69 / 3.3, 144: 4.02 / 4.9, 160: 4.28 / 4.9, 176: 4.69 / 4.9, 192: 6.04 / 5.0
+//   collapsed  K = 100: 3.60 / 3.74, 128: 6.31 / 3.71, 144: 6.96 / 5.6, 160: 7.63 / 5.6, 176: 8.62 / 5.6, 192: 11.4 / 5.6
+constexpr int kPcgsWaveFromTopics = 176, kCollapsedWaveFromTopics = 96;
 
 int launch_pcgs_z(ggs_handle *h) {
   if (h->N == 0) return GGS_OK;
@@ -1193,7 +1197,7 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&by_regs, pcgs_wave_kernel_for(nb, h->collapsed), 64, (size_t)h->pcgs_wave_lds) != hipSuccess || by_regs < 1) by_regs = 1;
       h->pcgs_wave_waves_per_cu = std::max(1, std::min(std::min(by_regs, 32), (kMaxLdsBytes - 2048) / ((h->pcgs_wave_lds + 2047) / 2048 * 2048)));
     }
-    h->pcgs_wave_forced = h->K > kPcgsWaveFromTopics;
+    h->pcgs_wave_forced = h->K > (h->collapsed ? kCollapsedWaveFromTopics : kPcgsWaveFromTopics);
     if (const char *e = debug_env("GGS_DEBUG_PCGS_WAVE")) h->pcgs_wave_forced = std::atoi(e) != 0;
     if (h->pcgs_wave_forced && !h->pcgs_wave_nb) return bail(GGS_ERR_UNSUPPORTED);   // more than 4096 topics
     if (h->pcgs_wave_nb && hipFuncSetAttribute(pcgs_wave_kernel_for(h->pcgs_wave_nb, h->collapsed), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess)

@@ -157,10 +157,47 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(pcgs_wave_mi
         qa = k < K ? ((double)n.x + al.x) * pa : 0.0;
         qb = k + 1 < K ? ((double)n.y + al.y) * pb : 0.0;
       };
+      int new_topic = -1;
+      // Given the block the draw falls into (js), the prefix before it and the inclusive scan of the block's lane sums:
+      // the proposal and its proof (header).  a, b = this lane's two scores of that block.
+      auto decide = [&](const int js, const double before, const double a, const double b, const double scan_ab, const double T,
+                        const double delta) __attribute__((always_inline)) {
+        (void)a;
+        const double c_ab = before + scan_ab, c_a = c_ab - b;              // prefixes after this lane's first / second topic
+        const double d_a = T - c_a, d_ab = T - c_ab;
+        const unsigned long long m_a = __ballot(d_a < -delta), m_ab = __ballot(d_ab < -delta);
+        if (m_a | m_ab) {
+          const int l = __ffsll((long long)(m_a | m_ab)) - 1;
+          const bool at_a = (m_a >> l) & 1ull;
+          // the topic before the proposed one must be surely NOT yet past the sample
+          const double d_prev = at_a ? (l == 0 ? T - before : read_lane(d_ab, max(l - 1, 0))) : read_lane(d_a, l);
+          const int k = 128 * js + 2 * l + (at_a ? 0 : 1);
+          const bool first = js == 0 && l == 0 && at_a;                    // topic 0: nothing before it (T > delta holds)
+          if ((first || d_prev > delta) && k < K) new_topic = k;
+        }
+      };
+      if constexpr (NB <= 2) {
+        // One or two blocks: the inclusive scan of each block gives its prefixes AND (lane 63) its total -- NB wave scans do
+        // the whole token where total + descent + deciding scan would take NB + 1 or NB + 2.
+        double qa[NB], qb[NB], sc[NB], tot[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+          scores(j, cur.a[j], cur.b[j], qa[j], qb[j]);
+          sc[j] = wave_inclusive_scan(qa[j] + qb[j]);
+          tot[j] = read_lane(sc[j], 63);
+        }
+        const double s_hat = NB == 2 ? tot[0] + tot[NB - 1] : tot[0];
+        const double T = U * s_hat;
+        const double delta = ((double)(K + 16) * s_hat) * 0x1p-51 * margin_scale;
+        if (T > delta && s_hat < __builtin_huge_val()) {
+          const bool second = NB == 2 && !(T - tot[0] <= delta);           // wave-uniform
+          decide(second ? 1 : 0, second ? tot[0] : 0.0, second ? qa[NB - 1] : qa[0], second ? qb[NB - 1] : qb[0], second ? sc[NB - 1] : sc[0], T, delta);
+        }
+      } else {
       // The lane's share of every GROUP of kG adjacent blocks (at most 8 groups) and of every aligned range of groups (a
-      // binary tree, lane-local adds only); wave reductions then run ONLY along the path of the block search: 1 (the total)
-      // + log2(groups) (the descent) + at most kG - 1 (inside the group, its blocks' scores recomputed) instead of one per
-      // block -- sums in any association, which is all a proposal needs (header).
+      // binary tree, lane-local adds only); wave reductions then run ONLY along the path of the block search: 2 (the total,
+      // as left half + right half) + log2(groups) - 1 (the rest of the descent) + at most kG - 1 (inside the group, its
+      // blocks' scores recomputed) instead of one per block -- sums in any association, which is all a proposal needs (header).
       double gv[kNG];                                                      // the lane's share of group g; ranges of groups are added up where the search asks for them
 #pragma unroll
       for (int g = 0; g < kNG; ++g) {
@@ -188,18 +225,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(pcgs_wave_mi
         return x[0];
       };
       // the total as left half + right half: the first level of the descent then has its `left` already
-      double root_left = 0.0, s_hat;
-      if constexpr (kNG > 1) {
-        root_left = wave_sum(range_sum(std::integral_constant<int, 0>{}, std::integral_constant<int, kNG / 2>{}));
-        s_hat = root_left + wave_sum(range_sum(std::integral_constant<int, kNG / 2>{}, std::integral_constant<int, kNG / 2>{}));
-      } else {
-        s_hat = wave_sum(gv[0]);
-      }
+      const double root_left = wave_sum(range_sum(std::integral_constant<int, 0>{}, std::integral_constant<int, kNG / 2>{}));
+      const double s_hat = root_left + wave_sum(range_sum(std::integral_constant<int, kNG / 2>{}, std::integral_constant<int, kNG / 2>{}));
 
       const double T = U * s_hat;
       const double delta = ((double)(K + 16) * s_hat) * 0x1p-51 * margin_scale;
 
-      int new_topic = -1;
       if (T > delta && s_hat < __builtin_huge_val()) {
         // descend: at a node covering groups [lo, lo + width) with C' = `before` at its start, the crossing is in the left
         // half iff the prefix at the left half's end is past T or too close to call; inside the group, block by block
@@ -232,27 +263,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(pcgs_wave_mi
           }
         };
         descend(descend, std::integral_constant<int, 0>{}, std::integral_constant<int, kNG>{});
-        {
-          double pa = 0.0, pb = 0.0;                                       // this lane's row entries of block js (a static select: registers are not indexable)
+        double pa = 0.0, pb = 0.0;                                         // this lane's row entries of block js (a static select: registers are not indexable)
 #pragma unroll
-          for (int j = 0; j < NB; ++j)
-            if (j == js) { pa = cur.a[j]; pb = cur.b[j]; }
-          if constexpr (kDepth == 0) { load_row(word_of(tl + 1), tgt); refilled = true; }   // the row is dead: the next token's takes its registers
-          double a, b;
-          scores(js, pa, pb, a, b);
-          const double c_ab = before + wave_inclusive_scan(a + b), c_a = c_ab - b;   // prefixes after this lane's first / second topic
-          const double d_a = T - c_a, d_ab = T - c_ab;
-          const unsigned long long m_a = __ballot(d_a < -delta), m_ab = __ballot(d_ab < -delta);
-          if (m_a | m_ab) {
-            const int l = __ffsll((long long)(m_a | m_ab)) - 1;
-            const bool at_a = (m_a >> l) & 1ull;
-            // the topic before the proposed one must be surely NOT yet past the sample
-            const double d_prev = at_a ? (l == 0 ? T - before : read_lane(d_ab, max(l - 1, 0))) : read_lane(d_a, l);
-            const int k = 128 * js + 2 * l + (at_a ? 0 : 1);
-            const bool first = js == 0 && l == 0 && at_a;                  // topic 0: nothing before it (T > delta holds)
-            if ((first || d_prev > delta) && k < K) new_topic = k;
-          }
-        }
+        for (int j = 0; j < NB; ++j)
+          if (j == js) { pa = cur.a[j]; pb = cur.b[j]; }
+        if constexpr (kDepth == 0) { load_row(word_of(tl + 1), tgt); refilled = true; }   // the row is dead: the next token's takes its registers
+        double a, b;
+        scores(js, pa, pb, a, b);
+        decide(js, before, a, b, wave_inclusive_scan(a + b), T, delta);
+      }
       }
       if (__builtin_expect(new_topic < 0, 0)) {
         // undecided (or Java would throw): replay the token as Java runs it, UPLDA:1509-1531 (negated walk in counting form,

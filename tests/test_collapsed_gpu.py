@@ -108,6 +108,23 @@ def test_parallel_schedule_matches_its_restatement(native, oracle, cats, K, alph
     assert e.value.code == native.ERR_UNSUPPORTED
 
 
+@pytest.mark.parametrize("K,wave", [(96, None), (97, None), (130, "0"), (192, "0")])
+def test_parallel_schedule_either_kernel_around_the_switch_point(native, oracle, monkeypatch, K, wave):
+    """scheme=collapsed takes the wave-per-document kernel from 97 topics on (ggs_api.hip: the measured break-even); the
+    lane-per-document variants above stay reachable (GGS_DEBUG_PCGS_WAVE=0) and give the same counts."""
+    if wave is not None:
+        monkeypatch.setenv("GGS_DEBUG_PCGS_WAVE", wave)
+    c = random_corpus(130, 300, 90, seed=K + 1, empty_every=7)
+    g, o = pair(native, oracle, c, K, 0.1, 0.01, 6 + K, K)
+    monkeypatch.delenv("GGS_DEBUG_PCGS_WAVE", raising=False)
+    want = "wave" if (wave is None and K > 96) else "lane"
+    assert want in g.launch_info()["z_kernel"]
+    for it in range(2):
+        g.sweep(1)
+        o.collapsed_parallel_sweep(1)
+        same_counts(g, o, "parallel K=%d (%s per document) sweep %d" % (K, want, it + 1))
+
+
 @pytest.mark.parametrize("K,force", [(500, False), (1024, False), (2049, False), (20, True), (130, True)])
 def test_parallel_schedule_wide_topic_rows(native, oracle, monkeypatch, K, force):
     """The count-form conditional (MSLDA:158-226) in the parallel schedule above 320 topics, and with a document of more

@@ -694,6 +694,23 @@ def test_pcgs_wave_kernel_forced_and_its_exact_replay(native, oracle, monkeypatc
     compare_state(g, o, "pcgs wave kernel K=%d margin x%s" % (K, margin), theta=False)
 
 
+@pytest.mark.parametrize("K,wave", [(176, None), (177, None), (192, "0"), (184, "0"), (150, "1")])
+def test_pcgs_either_kernel_around_the_switch_point(native, oracle, monkeypatch, K, wave):
+    """The lane-per-document score-register kernels serve up to 176 topics by default and the wave-per-document kernel
+    from 177 (ggs_api.hip: the measured break-even); both stay reachable on either side (GGS_DEBUG_PCGS_WAVE) and give the
+    oracle's bits -- including the 176..192 lane variants that spill."""
+    if wave is not None:
+        monkeypatch.setenv("GGS_DEBUG_PCGS_WAVE", wave)
+    c = random_corpus(150, 350, 110, seed=K + 3, empty_every=8)
+    g, o = _pcgs_pair(native, oracle, c, K, 0.1, 0.01, 21, K)
+    monkeypatch.delenv("GGS_DEBUG_PCGS_WAVE", raising=False)
+    want = "wave" if (wave == "1" or (wave is None and K > 176)) else "lane"
+    assert want in g.launch_info()["z_kernel"]
+    g.sweep(2)
+    o.sweep(2)
+    compare_state(g, o, "pcgs K=%d (%s per document)" % (K, want), theta=False)
+
+
 def test_pcgs_document_of_forty_thousand_tokens(native, oracle):
     """The lane-per-document kernels count a document's topics in int16: a document of 32 768 tokens or more used to be
     refused.  Such a corpus now goes to the wave-per-document kernel (int32 counts), whatever K."""

@@ -47,6 +47,7 @@ struct Events {
   bool used_ahead = false, exchanged = false;
   bool e4_is_e3 = false;        // a whole sweep (ggs_sweep): nothing happens between the end of the count rebuild and the start of the Phi phase
   bool theta_on_main = false;   // the theta this sweep consumes was drawn on the handle's own stream, right behind the previous z step: no th0 (= that sweep's e[2])
+  bool light = false;           // with an exchange: only e[1], e[2], e[5] were recorded; the span e[2]..e[5] is split as the last fully timed sweep's was
 };
 
 }  // namespace
@@ -159,6 +160,23 @@ struct ggs_handle {
   int32_t seg_split = 0, v_split = 0;                  // first segment / row of the second half (0: one all-gather)
   hipStream_t comm_stream = nullptr;
   hipEvent_t ev_half_drawn = nullptr, ev_half_gathered = nullptr;
+  int32_t *d_hseg_word = nullptr, *d_hseg_begin = nullptr, *d_hseg_end = nullptr;   // the hot words' count segments (the z kernels count the cold tokens themselves)
+  int64_t HS = 0;
+  // With an exchange every event packet on the handle's stream sits on the sweep's critical path (2.8 us each, 7.5 for two
+  // back to back: scripts/probes/event_cost_probe.hip), and a fully timed sweep records five that only the phase split
+  // needs (e[3], e[4], x[0..2]).  One sweep in kDetailEvery records them all; the others record the ends of the z step and
+  // of the sweep and split the rest in the proportions of the last fully timed sweep (GGS_DEBUG_TIMING_EVERY=1: all).
+  int32_t detail_every = 4;
+  bool force_detail = false;                           // a z step that no Phi phase follows (ggs_sample_z_given_phi) is timed in full
+  int64_t sweeps_enqueued = 0;
+  bool have_frac = false;
+  double frac[5] = {0, 0, 0, 0, 0};                    // of e[2]..e[5]: merge | reduce-scatter | slice draw | all-gather wait | repack
+  bool hot_join_pending = false, hot_counted = false;   // launch_z(defer_join): the handle's stream has not yet waited for the hot chunks' stream; the hot words' count ran there
+  bool z_counted = false;                              // this sweep's z step has already added its cells into d_cnt_send
+  bool cnt_send_zeroed = false;                        // d_cnt_send is all zero (cleared behind the last reduce-scatter): what the z kernels' own count updates start from
+  bool z_counts_forced = false;
+  bool z_counts = true;                                // GGS_DEBUG_ZCOUNTS=0: the count kernel also with an exchange (the cross-check)
+  SliceMap smap{};                                     // topic -> cell of the slice-major send buffer
   bool counts_global = true;                           // d_n_wk holds the corpus-wide counts
   bool cnt_own_valid = false;                          // d_cnt_own = reduce-scatter of the current d_cnt_send
   bool n_k_valid = false;                              // d_n_k follows d_n_wk
@@ -237,17 +255,31 @@ int launch_permute_z(ggs_handle *h) {
 int launch_count_rebuild(ggs_handle *h) {
   const size_t cells = h->xg ? (size_t)h->xg->nranks * h->V * h->Ksm : (size_t)h->K * h->V;
   int32_t *dst = h->xg ? h->d_cnt_send : h->d_n_wk;
-  HIP_TRY(h, hipMemsetAsync(dst, 0, cells * sizeof(int32_t), h->stream));
+  if (!(h->xg && h->cnt_send_zeroed)) HIP_TRY(h, hipMemsetAsync(dst, 0, cells * sizeof(int32_t), h->stream));
+  h->cnt_send_zeroed = false;
   if (h->S > 0) {
     CountParams cp{};
     cp.zw = h->d_zw; cp.seg_word = h->d_seg_word; cp.seg_begin = h->d_seg_begin; cp.n_wk = dst; cp.K = h->K; cp.num_segs = (int32_t)h->S;
     cp.koff = h->xg ? h->d_koff : nullptr; cp.row_stride = h->xg ? h->Ksm : h->K;
+    cp.seg_end = nullptr; cp.segs_per_block = kCountSegsPerBlock;
     hipLaunchKernelGGL(count_sorted_kernel, dim3((unsigned)((h->S + kCountSegsPerBlock - 1) / kCountSegsPerBlock)), dim3(256), (size_t)h->K * sizeof(int32_t),
                        h->stream, cp);
   }
   HIP_TRY(h, hipGetLastError());
   h->n_k_valid = false;
   if (h->xg) { h->counts_global = false; h->cnt_own_valid = false; }
+  return GGS_OK;
+}
+// The hot words' share of the send buffer, behind a z step whose kernels counted the cold tokens themselves.
+int launch_count_hot(ggs_handle *h) {
+  if (h->HS > 0) {
+    CountParams cp{};
+    cp.zw = h->d_zw; cp.seg_word = h->d_hseg_word; cp.seg_begin = h->d_hseg_begin; cp.seg_end = h->d_hseg_end; cp.n_wk = h->d_cnt_send; cp.K = h->K;
+    cp.num_segs = (int32_t)h->HS; cp.koff = h->d_koff; cp.row_stride = h->Ksm; cp.segs_per_block = 1;
+    hipLaunchKernelGGL(count_sorted_kernel, dim3((unsigned)h->HS), dim3(256), (size_t)h->K * sizeof(int32_t), h->stream, cp);
+    HIP_TRY(h, hipGetLastError());
+  }
+  h->n_k_valid = false; h->counts_global = false; h->cnt_own_valid = false;
   return GGS_OK;
 }
 
@@ -298,11 +330,30 @@ int xcall(ggs_handle *h, int rc, const char *what) {
   if (!rc) return GGS_OK;
   return set_err(h, GGS_ERR_HIP, std::string("exchange ") + what + " failed" + (h->xg->err.empty() ? "" : ": " + h->xg->err));
 }
+// Behind the reduce-scatter the send buffer is dead until the next z step fills it again (the z kernels add their cells
+// into it, or count_sorted_kernel does): it is cleared right here, off the z step's critical path -- on the communication
+// stream when the Phi phase is about to use it anyway (`defer_clear`: phi_step_b2 enqueues the fill behind the first
+// all-gather, and the event the main stream waits for before the second one covers it), otherwise on the handle's stream.
+int clear_send_buffer(ggs_handle *h, hipStream_t on) {
+  HIP_TRY(h, hipMemsetAsync(h->d_cnt_send, 0, (size_t)h->xg->nranks * h->V * h->Ksm * sizeof(int32_t), on));
+  h->cnt_send_zeroed = true;
+  return GGS_OK;
+}
+// NOT cleared in here: inside ncclGroupStart/End a collective is only collected, and a fill enqueued beside it would land
+// on the stream BEFORE it.  The callers clear once the collective is really enqueued (clear_send_buffer_if_dead); a
+// buffer nobody cleared is cleared by the next z step itself.
 int exchange_reduce_scatter(ggs_handle *h) {
   if (h->cnt_own_valid) return GGS_OK;
   int rc = xcall(h, h->xg->ops.reduce_scatter_i32(h->xg->ops.ctx, h->d_cnt_send, h->d_cnt_own, (int64_t)h->V * h->Ksm, h->stream), "reduce_scatter_i32");
-  if (!rc) h->cnt_own_valid = true;
-  return rc;
+  if (rc) return rc;
+  h->cnt_own_valid = true;
+  h->cnt_send_zeroed = false;
+  return GGS_OK;
+}
+// the send buffer's contents have been through the reduce-scatter (cnt_own is their sum): dead, clear them on `on`
+int clear_send_buffer_if_dead(ggs_handle *h, hipStream_t on) {
+  if (!h->xg || h->cnt_send_zeroed || !h->cnt_own_valid) return GGS_OK;
+  return clear_send_buffer(h, on);
 }
 
 // Corpus-wide counts in d_n_wk: with an exchange, gathered from the ranks' slices on demand (a COLLECTIVE call).  In
@@ -323,7 +374,7 @@ int gather_counts_step_unslice(ggs_handle *h) {
 int ensure_global_counts(ggs_handle *h) {
   if (!h->xg || h->counts_global) return GGS_OK;
   int rc;
-  if ((rc = exchange_reduce_scatter(h)) || (rc = gather_counts_step_gather(h))) return rc;
+  if ((rc = exchange_reduce_scatter(h)) || (rc = clear_send_buffer_if_dead(h, h->stream)) || (rc = gather_counts_step_gather(h))) return rc;
   return gather_counts_step_unslice(h);
 }
 
@@ -414,6 +465,8 @@ int launch_phi_slice(ggs_handle *h, bool initial, const int32_t *cnt, int32_t cn
 size_t half0_elems(const ggs_handle *h) { return (size_t)h->v_split * h->Ksm; }
 size_t half1_elems(const ggs_handle *h) { return (size_t)(h->V - h->v_split) * h->Ksm + (size_t)h->Ksm; }
 int phi_step_a(ggs_handle *h) { return exchange_reduce_scatter(h); }
+// behind step A, outside any ncclGroupStart/End: a short vocabulary has no communication-stream step to hide the fill under
+int phi_step_a_clear(ggs_handle *h) { return h->seg_split > 0 ? GGS_OK : clear_send_buffer_if_dead(h, h->stream); }
 int phi_step_b1(ggs_handle *h, bool initial) {
   int rc;
   if ((rc = launch_magnitude_on(h, h->d_cnt_own, h->Ksm, h->Ks, h->d_mag_own, h->d_n_k_own))) return rc;
@@ -430,7 +483,12 @@ int phi_step_g0(ggs_handle *h) {
 }
 int phi_step_b2(ggs_handle *h, bool initial) {
   int rc;
-  if (h->seg_split > 0) HIP_TRY(h, hipEventRecord(h->ev_half_gathered, h->comm_stream));
+  if (h->seg_split > 0) {
+    // behind the first all-gather on the communication stream (which waited for the slice's first half, hence for the
+    // reduce-scatter before it): the send buffer's zero fill, deferred by phi_step_a
+    if ((rc = clear_send_buffer_if_dead(h, h->comm_stream))) return rc;
+    HIP_TRY(h, hipEventRecord(h->ev_half_gathered, h->comm_stream));
+  }
   if ((rc = phi_slice_gamma(h, initial, h->d_cnt_own, h->Ksm, h->Ks, h->k0, h->d_phi_own, h->Ksm, h->d_mag_own, h->seg_split, h->sum_nseg))) return rc;
   return phi_slice_total(h, h->d_phi_own, h->Ksm, h->Ks, h->d_phi_own + (size_t)h->V * h->Ksm);
 }
@@ -457,7 +515,7 @@ int phi_step_c(ggs_handle *h, bool accumulate_mean) {
 int launch_phi(ggs_handle *h, bool initial, bool accumulate_mean, Events *E = nullptr) {
   int rc;
   if (h->xg) {
-    if ((rc = phi_step_a(h))) return rc;
+    if ((rc = phi_step_a(h)) || (rc = phi_step_a_clear(h))) return rc;
     if (E) HIP_TRY(h, hipEventRecord(E->x[0], h->stream));
     if ((rc = phi_step_b1(h, initial)) || (rc = phi_step_g0(h)) || (rc = phi_step_b2(h, initial))) return rc;
     if (E) HIP_TRY(h, hipEventRecord(E->x[1], h->stream));
@@ -579,7 +637,21 @@ int launch_pcgs_z(ggs_handle *h) {
   return GGS_OK;
 }
 
-int launch_z(ggs_handle *h, bool force_fused = false, int64_t c0 = 0, int64_t c1 = -1) {
+// `count`: with an exchange the sliced kernels add every token's new (word, topic) cell into the (zeroed) send buffer of the
+// count reduce-scatter themselves; the timed comparison of the two z forms launches without it
+// ... where few tokens share a cell: the atomics of different XCDs on one line serialise at the memory side.  Measured on the
+// benchmark corpus split N ways (z step with / without them, and the count kernel they replace): N = 8 (50 tokens per word
+// on the rank) 0.139 / 0.132 ms against 0.040 of count kernel; N = 4 (100) 0.290 / 0.26 against 0.05; N = 2 (200) 0.627 / 0.52
+// against 0.07 -- they pay up to about 64 tokens per word (GGS_DEBUG_ZCOUNTS=2 forces them).
+bool z_counts_itself(const ggs_handle *h) {
+  return h->xg && h->z_counts && h->z_sliced && !(h->flags & GGS_FLAG_PCGS) && (h->z_counts_forced || h->N <= (int64_t)64 * h->V);
+}
+// `defer_join` (with `count`, split form): the hot words' count launch follows the hot kernel on ITS stream and the
+// handle's stream is not made to wait for that stream here -- the caller does (join_hot_stream), behind the z step's end
+// event, so that the hot chunks' count sits beside the tail of the cold kernel instead of behind it.
+int launch_count_hot(ggs_handle *h);
+int launch_z(ggs_handle *h, bool force_fused = false, int64_t c0 = 0, int64_t c1 = -1, bool count = false, bool defer_join = false) {
+  h->hot_join_pending = false;
   if (h->C == 0) return GGS_OK;
   if (c1 < 0) c1 = h->C;
   if (c1 <= c0) return GGS_OK;
@@ -595,6 +667,8 @@ int launch_z(ggs_handle *h, bool force_fused = false, int64_t c0 = 0, int64_t c1
   zp.ct_tok = h->d_ct_tok; zp.ct_idx = h->d_ct_idx; zp.ct_ip = h->d_ct_ip; zp.c_docs = h->d_c_docs; zp.num_cold = h->Cc;
   zp.hot_words = h->d_hot_words; zp.num_hot = h->num_hot; zp.hot_pitch = h->hot_pitch;
   zp.wave_lds = h->wave_lds; zp.hot_off = kSlicedWaves * h->wave_lds; zp.ring_base = h->ring_base;
+  zp.cnt_send = (count && z_counts_itself(h)) ? h->d_cnt_send : nullptr;
+  zp.smap = h->smap;
   if (!h->z_sliced) {                                  // a range of the chunk table (the one-document chunks are in document order)
     zp.chunk_start += c0; zp.chunk_doc += c0; zp.chunk_len += c0; zp.num_chunks = c1 - c0;
     if (zp.chunk_doc1) zp.chunk_doc1 += c0;
@@ -623,8 +697,17 @@ int launch_z(ggs_handle *h, bool force_fused = false, int64_t c0 = 0, int64_t c1
       static const int only = debug_env("GGS_DEBUG_ONLY") ? std::atoi(debug_env("GGS_DEBUG_ONLY")) : 0;   // timing experiments: 1 cold only, 2 hot only
       if (only != 2) HIP_TRY(h, hipLaunchKernel(sliced_kernel_for(h->K), grid_of(h->Cc), sblock, args, (size_t)(kSlicedWaves * h->wave_lds), h->stream));
       if (only != 1) HIP_TRY(h, hipLaunchKernel(hot_kernel_for(h->K), grid_of(h->Cs - h->Cc), sblock, hargs, (size_t)(hp.hot_off + h->num_hot * h->hot_pitch + kHotTailBytes), h->side_hot));
+      if (defer_join && zp.cnt_send && only == 0) {
+        hipStream_t main_stream = h->stream;
+        h->stream = h->side_hot;
+        const int rc = launch_count_hot(h);
+        h->stream = main_stream;
+        if (rc) return rc;
+        h->hot_counted = true;
+      }
       HIP_TRY(h, hipEventRecord(h->ev_hot_join, h->side_hot));
-      HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_hot_join, 0));
+      if (defer_join) h->hot_join_pending = true;
+      else HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_hot_join, 0));
     } else {
       HIP_TRY(h, hipLaunchKernel(sliced_kernel_for(h->K), grid_of(std::max(h->Cc, h->Cs - h->Cc)), sblock, args,
                                  (size_t)(kSlicedWaves * h->wave_lds + h->num_hot * h->hot_pitch), h->stream));
@@ -697,8 +780,27 @@ int settle_sweeps(ggs_handle *h) {
     else { HIP_TRY(h, hipEventElapsedTime(&ms, E.e[0], E.e[1])); }
     h->tm.theta_ms += ms;
     HIP_TRY(h, hipEventElapsedTime(&ms, E.e[1], E.e[2])); h->tm.z_ms += ms;
+    if (E.light) {                                       // the ends only: the phases in the last fully timed sweep's proportions
+      HIP_TRY(h, hipEventElapsedTime(&ms, E.e[2], E.e[5]));
+      h->tm.merge_ms += ms * h->frac[0];
+      h->tm.exchange_rs_ms += ms * h->frac[1]; h->tm.exchange_ag_ms += ms * h->frac[3]; h->tm.exchange_ms += ms * (h->frac[1] + h->frac[3]);
+      h->tm.phi_ms += ms * (h->frac[2] + h->frac[4]);
+      h->tm.sweeps += 1;
+      h->tm.tokens_sampled += h->N;
+      continue;
+    }
     HIP_TRY(h, hipEventElapsedTime(&ms, E.e[2], E.e[3])); h->tm.merge_ms += ms;
-    if (E.exchanged) {   // reduce-scatter | slice draw (the first half's all-gather beneath it) | what is left of the all-gathers | repack
+    if (E.exchanged) {
+      float span = 0, part[5] = {ms, 0, 0, 0, 0};
+      (void)hipEventElapsedTime(&span, E.e[2], E.e[5]);
+      (void)hipEventElapsedTime(&part[1], E.e[E.e4_is_e3 ? 3 : 4], E.x[0]); (void)hipEventElapsedTime(&part[2], E.x[0], E.x[1]);
+      (void)hipEventElapsedTime(&part[3], E.x[1], E.x[2]); (void)hipEventElapsedTime(&part[4], E.x[2], E.e[5]);
+      if (span > 0) {
+        // what lies between e[3] and e[4] in a split sweep (the caller's own work) is nobody's phase: renormalise
+        const float sum = part[0] + part[1] + part[2] + part[3] + part[4];
+        for (int q = 0; q < 5; ++q) h->frac[q] = sum > 0 ? part[q] / sum : 0.0;
+        h->have_frac = true;
+      }   // reduce-scatter | slice draw (the first half's all-gather beneath it) | what is left of the all-gathers | repack
       HIP_TRY(h, hipEventElapsedTime(&ms, E.e[E.e4_is_e3 ? 3 : 4], E.x[0])); h->tm.exchange_ms += ms; h->tm.exchange_rs_ms += ms;
       HIP_TRY(h, hipEventElapsedTime(&ms, E.x[0], E.x[1])); h->tm.phi_ms += ms;
       HIP_TRY(h, hipEventElapsedTime(&ms, E.x[1], E.x[2])); h->tm.exchange_ms += ms; h->tm.exchange_ag_ms += ms;
@@ -726,6 +828,8 @@ int z_phase(ggs_handle *h) {
   if (h->ev_pending >= kEvRing - 2 && (rc = settle_sweeps(h))) return rc;   // keep this slot and the next one free
   h->ev_head = (h->ev_head + 1) % kEvRing;
   Events &E = h->evs[h->ev_head];
+  E.light = h->xg && h->have_frac && h->detail_every > 1 && !h->force_detail && (h->sweeps_enqueued % h->detail_every) != 0 && !h->collapsed;
+  h->sweeps_enqueued += 1;
   if (h->flags & GGS_FLAG_PCGS) {                       // no theta: it is integrated out (UPLDA:1509-1513)
     E.used_ahead = false;
     HIP_TRY(h, hipEventRecord(E.e[0], h->stream));
@@ -733,7 +837,7 @@ int z_phase(ggs_handle *h) {
     if ((rc = launch_pcgs_z(h))) return rc;
     HIP_TRY(h, hipEventRecord(E.e[2], h->stream));
     if ((rc = launch_count_rebuild(h))) return rc;
-    HIP_TRY(h, hipEventRecord(E.e[3], h->stream));
+    if (!E.light) HIP_TRY(h, hipEventRecord(E.e[3], h->stream));
     return GGS_OK;
   }
   E.used_ahead = h->theta_ahead_iter == (int64_t)h->iteration;
@@ -791,14 +895,19 @@ int z_phase(ggs_handle *h) {
     HIP_TRY(h, hipEventRecord(E.e[2], h->stream));
     h->theta_ahead_iter = (int64_t)h->iteration + 1;
   } else {
-    if ((rc = launch_z(h))) return rc;
-    HIP_TRY(h, hipEventRecord(E.e[2], h->stream));
+    const bool counting = z_counts_itself(h) && h->C > 0;
+    if (counting && !h->cnt_send_zeroed && (rc = clear_send_buffer(h, h->stream))) return rc;   // nobody cleared it behind the last reduce-scatter (or none came): counts no z step asked for are overwritten, as a count rebuild overwrites them
+    h->hot_counted = false;
+    if ((rc = launch_z(h, false, 0, -1, counting, /*defer_join=*/counting))) return rc;
+    if (counting) { h->z_counted = true; h->cnt_send_zeroed = false; }
+    HIP_TRY(h, hipEventRecord(E.e[2], h->stream));      // the cold kernel's end; the hot chunks' stream is joined below, and by the theta draw's stream
     h->chain_on_side = h->chain_on_side && ahead;
     if (ahead) {
       // theta of iteration t+1 from the z just drawn, concurrent with the counts and the Phi draw
       Events &N = h->evs[(h->ev_head + 1) % kEvRing];
       hipStream_t ts = h->chain_on_side ? h->stream : h->side;
       HIP_TRY(h, hipStreamWaitEvent(h->chain_on_side ? h->side_hot : h->side, E.e[2], 0));
+      if (h->hot_join_pending) HIP_TRY(h, hipStreamWaitEvent(ts, h->ev_hot_join, 0));   // the theta draw reads the hot chunks' z as well
       N.theta_on_main = h->chain_on_side;
       if (!h->chain_on_side) HIP_TRY(h, hipEventRecord(N.th0, ts));
       if ((rc = launch_theta(h, ts, h->d_theta_next, h->iteration + 1, 0, -1, h->chain_on_side ? h->theta_lds_main : 0, h->chain_on_side ? h->theta_b_main : 0))) return rc;
@@ -808,8 +917,13 @@ int z_phase(ggs_handle *h) {
   }
   {
     StreamSwap on_chain(h, h->chain_on_side ? h->side_hot : h->stream);
-    if ((rc = launch_count_rebuild(h))) return rc;   // this shard's counts; summed across shards by the caller
-    HIP_TRY(h, hipEventRecord(E.e[3], h->stream));
+    if (h->hot_join_pending) { HIP_TRY(h, hipStreamWaitEvent(h->stream, h->ev_hot_join, 0)); h->hot_join_pending = false; }
+    if (h->z_counted) {                              // the z kernels added the cold tokens' cells: the hot words' segments are left
+      h->z_counted = false;
+      if (h->hot_counted) { h->n_k_valid = false; h->counts_global = false; h->cnt_own_valid = false; }   // ... and were counted on the hot chunks' stream
+      else if ((rc = launch_count_hot(h))) return rc;
+    } else if ((rc = launch_count_rebuild(h))) return rc;   // this shard's counts; summed across shards by the caller
+    if (!E.light) HIP_TRY(h, hipEventRecord(E.e[3], h->stream));
     if (h->chain_on_side && !h->whole_sweep) HIP_TRY(h, hipEventRecord(h->ev_chain_done, h->stream));
   }
   // ggs_sweep_begin on its own: what the caller does on the handle's stream before ggs_sweep_end (a getter) sees the counts
@@ -836,7 +950,7 @@ int finish_sweep_enqueue_on(ggs_handle *h, bool with_phi) {
   int rc;
   Events &E = h->evs[h->ev_head];
   E.e4_is_e3 = h->whole_sweep;                         // one event packet less on the stream (~6 us each)
-  if (!E.e4_is_e3) HIP_TRY(h, hipEventRecord(E.e[4], h->stream));
+  if (!E.e4_is_e3 && !E.light) HIP_TRY(h, hipEventRecord(E.e[4], h->stream));
   bool acc = false;
   E.exchanged = false;
   if (with_phi) {
@@ -846,7 +960,7 @@ int finish_sweep_enqueue_on(ggs_handle *h, bool with_phi) {
       if ((rc = launch_magnitude(h))) return rc;
     } else {
       E.exchanged = h->xg != nullptr;
-      if ((rc = launch_phi(h, false, acc, &E))) return rc;
+      if ((rc = launch_phi(h, false, acc, E.light ? nullptr : &E))) return rc;
     }
   }
   HIP_TRY(h, hipEventRecord(E.e[5], h->stream));
@@ -890,6 +1004,14 @@ int setup_exchange(ggs_handle *h, Exchange *x) {
   const std::vector<int32_t> sl = topic_slices(h->K, x->nranks);
   h->xg = x;
   h->k0 = sl[(size_t)x->rank]; h->Ks = sl[(size_t)x->rank + 1] - h->k0; h->Ksm = (h->K + x->nranks - 1) / x->nranks;
+  {
+    auto magic = [](uint32_t d) { return d > 1 ? (uint32_t)((0x100000000ull + d - 1) / d) : 0u; };   // udiv_magic (ggs_kernels.hpp)
+    h->smap.size = h->K / x->nranks; h->smap.rem = h->K % x->nranks; h->smap.ksm = h->Ksm;
+    h->smap.m_size = magic((uint32_t)std::max(h->smap.size, 1)); h->smap.m_size1 = magic((uint32_t)h->smap.size + 1);
+    h->smap.rank_stride = (int64_t)h->V * h->Ksm;
+    if (const char *e = debug_env("GGS_DEBUG_ZCOUNTS")) { h->z_counts = std::atoi(e) != 0; h->z_counts_forced = std::atoi(e) == 2; }
+    if (const char *e = debug_env("GGS_DEBUG_TIMING_EVERY")) h->detail_every = std::max(1, std::atoi(e));
+  }
   std::vector<int64_t> koff((size_t)h->K);
   for (int32_t r = 0; r < x->nranks; ++r)
     for (int32_t k = sl[(size_t)r]; k < sl[(size_t)r + 1]; ++k) koff[(size_t)k] = (int64_t)r * h->V * h->Ksm + (k - sl[(size_t)r]);
@@ -947,6 +1069,7 @@ int setup_exchange(ggs_handle *h, Exchange *x) {
   }
   HIP_TRY(h, hipDeviceSynchronize());
   h->counts_global = false; h->cnt_own_valid = false; h->n_k_valid = false;
+  h->cnt_send_zeroed = true;                           // the memset above
   return GGS_OK;
 }
 
@@ -1259,7 +1382,8 @@ void ggs_destroy(ggs_handle *h) {
                   h->d_phiT, h->d_mag, h->d_tot, h->d_phi_mean, h->d_n_wk, h->d_n_k, h->d_perm, h->d_inv_perm, h->d_zw, h->d_seg_word, h->d_seg_begin,
                   h->d_status, h->d_scratch, h->d_sum_pref, h->d_sum_fn, h->d_ct_tok, h->d_ct_idx, h->d_ct_ip, h->d_c_docs, h->d_hot_words, h->d_order,
                   h->d_test_ptr, h->d_test_tok, h->d_test_ll, h->d_test_docs, h->d_koff, h->d_cnt_send, h->d_cnt_own, h->d_cnt_all, h->d_n_k_own,
-                  h->d_heldout_spill, h->d_phi_own, h->d_phi_all0, h->d_phi_all1, h->d_mag_own, h->d_krank, h->d_kcol, h->d_lcg, h->d_chunk_doc1};
+                  h->d_heldout_spill, h->d_phi_own, h->d_phi_all0, h->d_phi_all1, h->d_mag_own, h->d_krank, h->d_kcol, h->d_lcg, h->d_chunk_doc1,
+                  h->d_hseg_word, h->d_hseg_begin, h->d_hseg_end};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   exchange_free(h->xg);
@@ -1348,7 +1472,7 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
   // count-kernel work items: tokens sorted by word (counting sort, stable), each word's run
   // cut into segments of at most kSegTokens entries.
   constexpr int64_t kSegTokens = 4096;
-  std::vector<int32_t> perm((size_t)N), seg_word, seg_begin, hot_words;
+  std::vector<int32_t> perm((size_t)N), seg_word, seg_begin, hot_words, hseg_word, hseg_begin, hseg_end;
   {
     std::vector<int64_t> wptr((size_t)h->V + 1, 0);
     for (int64_t i = 0; i < N; ++i) wptr[(size_t)tokens[i] + 1]++;
@@ -1366,6 +1490,10 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
       auto freq = [&](int32_t w) { return wptr[(size_t)w + 1] - wptr[(size_t)w]; };
       std::partial_sort(order.begin(), order.begin() + nh, order.end(), [&](int32_t a, int32_t b) { return freq(a) != freq(b) ? freq(a) > freq(b) : a < b; });
       for (size_t r = 0; r < nh && freq(order[r]) > 0; ++r) hot_words.push_back(order[r]);
+      for (int32_t w : hot_words)
+        for (int64_t b = wptr[(size_t)w]; b < wptr[(size_t)w + 1]; b += kSegTokens) {
+          hseg_word.push_back(w); hseg_begin.push_back((int32_t)b); hseg_end.push_back((int32_t)std::min(b + kSegTokens, wptr[(size_t)w + 1]));
+        }
     }
     // a segment ends where the next begins, or at the end of its word's run
     // (seg_begin[s+1] is the next segment's start, which is exactly that)
@@ -1444,6 +1572,13 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
   HIP_TRY(h, hipMemcpy(h->d_doc_ptr, doc_ptr, sizeof(int64_t) * ((size_t)D + 1), hipMemcpyHostToDevice));
   if (N) HIP_TRY(h, hipMemcpy(h->d_tok, tokens, sizeof(int32_t) * (size_t)N, hipMemcpyHostToDevice));
   h->num_hot = (int32_t)hot_words.size();
+  h->HS = (int64_t)hseg_word.size();
+  if ((rc = dev_alloc(h, &h->d_hseg_word, hseg_word.size())) || (rc = dev_alloc(h, &h->d_hseg_begin, hseg_begin.size())) || (rc = dev_alloc(h, &h->d_hseg_end, hseg_end.size()))) return rc;
+  if (h->HS) {
+    HIP_TRY(h, hipMemcpy(h->d_hseg_word, hseg_word.data(), sizeof(int32_t) * hseg_word.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_hseg_begin, hseg_begin.data(), sizeof(int32_t) * hseg_begin.size(), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->d_hseg_end, hseg_end.data(), sizeof(int32_t) * hseg_end.size(), hipMemcpyHostToDevice));
+  }
   h->Cs = h->Cc = 0;
   if (h->z_sliced) {
     // Chunk lists of the sliced kernel: walk the documents in order and deal every token to the open
@@ -1663,7 +1798,10 @@ int ggs_sample_z_given_phi(ggs_handle *h, int32_t n_sweeps) {
   if (h->collapsed) return set_err(h, GGS_ERR_UNSUPPORTED, "scheme=collapsed has no Phi to condition on");
   for (int32_t i = 0; i < n_sweeps; ++i) {
     h->iteration += 1;                                 // UPLDA:980
-    if ((rc = z_phase(h))) return rc;
+    h->force_detail = true;
+    rc = z_phase(h);
+    h->force_detail = false;
+    if (rc) return rc;
     if ((rc = finish_sweep(h, false))) return rc;
   }
   // tokensPerTopic follows the rebuilt counts (with an exchange: the counts are merged here, UPLDA:993)
@@ -1794,24 +1932,25 @@ int group_phi(ggs_handle **hs, int32_t n, bool initial, bool in_sweep) {
     if ((rc = bind_device(h))) break;
     if (in_sweep) {
       Events &E = h->evs[h->ev_head];
-      if (hipEventRecord(E.e[4], h->stream) != hipSuccess) { rc = set_err(h, GGS_ERR_HIP, "hipEventRecord"); break; }
+      if (!E.light && hipEventRecord(E.e[4], h->stream) != hipSuccess) { rc = set_err(h, GGS_ERR_HIP, "hipEventRecord"); break; }
       E.exchanged = true; E.e4_is_e3 = false;
       acc[(size_t)i] = (h->flags & GGS_FLAG_SAVE_PHI_MEAN) && sample_phi_this_iteration(h);
     }
   }
   if (rc) return rc;
-  auto grouped = [&](auto step) { return group_collective(hs, n, [&](ggs_handle *h) { return step(h, in_sweep ? &h->evs[h->ev_head] : nullptr); }); };
+  auto timed = [&](ggs_handle *h) -> Events * { return (in_sweep && !h->evs[h->ev_head].light) ? &h->evs[h->ev_head] : nullptr; };   // a light sweep records no phase events
+  auto grouped = [&](auto step) { return group_collective(hs, n, [&](ggs_handle *h) { return step(h, timed(h)); }); };
   // a step for every handle; events are recorded AFTER a grouped step: inside ncclGroupStart/End the collectives are
   // only collected, and an event recorded there would land on the stream before them
   auto each = [&](auto step) {
     int r = GGS_OK;
     for (int32_t i = 0; i < n && !r; ++i)
-      if (!(r = bind_device(hs[i]))) r = step(hs[i], in_sweep ? &hs[i]->evs[hs[i]->ev_head] : nullptr);
+      if (!(r = bind_device(hs[i]))) r = step(hs[i], timed(hs[i]));
     return r;
   };
   auto record = [](ggs_handle *h, hipEvent_t ev) { return hipEventRecord(ev, h->stream) == hipSuccess ? GGS_OK : set_err(h, GGS_ERR_HIP, "hipEventRecord"); };
   if ((rc = grouped([](ggs_handle *h, Events *) { return phi_step_a(h); })) ||
-      (rc = each([&](ggs_handle *h, Events *E) { int r = E ? record(h, E->x[0]) : GGS_OK; return r ? r : phi_step_b1(h, initial); })) ||
+      (rc = each([&](ggs_handle *h, Events *E) { int r = phi_step_a_clear(h); if (!r && E) r = record(h, E->x[0]); return r ? r : phi_step_b1(h, initial); })) ||
       (rc = grouped([](ggs_handle *h, Events *) { return phi_step_g0(h); })) ||
       (rc = each([&](ggs_handle *h, Events *E) { int r = phi_step_b2(h, initial); if (!r && E) r = record(h, E->x[1]); return r ? r : phi_join_halves(h); })) ||
       (rc = grouped([](ggs_handle *h, Events *) { return phi_step_g1(h); })) ||
@@ -1835,6 +1974,8 @@ namespace {
 int group_gather_counts(ggs_handle **hs, int32_t n) {
   int rc;
   if ((rc = group_collective(hs, n, [](ggs_handle *h) { return h->counts_global ? GGS_OK : exchange_reduce_scatter(h); }))) return rc;
+  for (int32_t i = 0; i < n; ++i)
+    if ((rc = bind_device(hs[i])) || (rc = clear_send_buffer_if_dead(hs[i], hs[i]->stream))) return rc;
   if ((rc = group_collective(hs, n, [](ggs_handle *h) { return h->counts_global ? GGS_OK : gather_counts_step_gather(h); }))) return rc;
   for (int32_t i = 0; i < n; ++i)
     if (!hs[i]->counts_global && ((rc = bind_device(hs[i])) || (rc = gather_counts_step_unslice(hs[i])))) return rc;

@@ -188,6 +188,9 @@ struct CountParams {
   const int64_t *koff;       // null: the plain [V][K] layout.  With an exchange attached: the slice-major
                              // [nranks][V][Ksm] send buffer of the count reduce-scatter, koff[k] = slice(k)*V*Ksm + (k - k0(slice))
   int32_t K, num_segs, row_stride;
+  const int32_t *seg_end;    // null: segment s ends where s + 1 begins.  Given: a list of segments that are not adjacent
+                             // (the hot words' segments, counted on their own when the z kernels count the rest)
+  int32_t segs_per_block;    // kCountSegsPerBlock for the whole corpus (most segments are tiny), 1 for a list of full ones
 };
 
 constexpr int kCountSegsPerBlock = 8;   // most words are rare: a workgroup per <= 256-token segment would be mostly dispatch overhead
@@ -197,9 +200,9 @@ __global__ __launch_bounds__(256) void count_sorted_kernel(CountParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   int32_t *hist = reinterpret_cast<int32_t *>(smem);
   const int tid = threadIdx.x, K = p.K;
-  const int seg0 = blockIdx.x * kCountSegsPerBlock, seg1 = min(seg0 + kCountSegsPerBlock, p.num_segs);
+  const int seg0 = blockIdx.x * p.segs_per_block, seg1 = min(seg0 + p.segs_per_block, p.num_segs);
   for (int seg = seg0; seg < seg1; ++seg) {
-    const int beg = p.seg_begin[seg], end = p.seg_begin[seg + 1];
+    const int beg = p.seg_begin[seg], end = p.seg_end ? p.seg_end[seg] : p.seg_begin[seg + 1];
     int32_t *row = p.n_wk + (size_t)p.seg_word[seg] * p.row_stride;
     if (end - beg <= 256) {                    // uniform per block
       if (beg + tid < end) {

@@ -22,6 +22,23 @@
 
 namespace ggs {
 
+// Topic k of word w -> its cell in the slice-major send buffer of the count reduce-scatter, [nranks][V][Ksm] (rank r owns
+// the topics of slice r: sizes size + 1 for the first `rem` ranks, size for the rest -- EvenSplitTopicBatchBuilder.java:28-39).
+// Arithmetic only (two multiplies by a reciprocal): the z kernels call it once per token, and a table lookup there would be
+// a dependent load in front of the atomic.
+struct SliceMap {
+  int32_t rem, size, ksm;      // ksm = the widest slice = the row pitch of a rank's part
+  uint32_t m_size, m_size1;    // udiv_magic(size), udiv_magic(size + 1)
+  int64_t rank_stride;         // V * ksm
+};
+__device__ __forceinline__ int64_t slice_cell(const SliceMap &m, int k, int w) {
+  const int cut = m.rem * (m.size + 1);
+  int r, c;
+  if (k < cut) { r = udiv_small(k, m.m_size1); c = k - r * (m.size + 1); }
+  else { const int q = udiv_small(k - cut, m.m_size); r = m.rem + q; c = k - cut - q * m.size; }
+  return (int64_t)r * m.rank_stride + (int64_t)w * m.ksm + c;
+}
+
 struct ZParams {
   const int32_t *tok;
   const int32_t *inv_perm;     // position of token i in the word-sorted order
@@ -55,6 +72,13 @@ struct ZParams {
   // chunk_len then carries len | split << 8 (split = tokens of the first document) and chunk_doc1 the second document
   const int32_t *chunk_doc1;
   int32_t two_rows;
+  // With an exchange attached (z_sliced_kernel's cold chunks): the kernel adds every COLD token's new (word, topic) cell into
+  // the zeroed send buffer of the count reduce-scatter itself -- one fire-and-forget atomic per token beside its two z
+  // stores (UPLDA:1547-1557 did the same with AtomicIntegers; integer sums are order-free) -- and only the few hot words'
+  // segments are left to count_sorted_kernel between the z step and the collective (a rank in eight: 35 us -> a few).
+  // Null: the counts are rebuilt by count_sorted_kernel alone.
+  int32_t *cnt_send;
+  SliceMap smap;
 };
 
 struct alignas(16) D2 { double a, b; };

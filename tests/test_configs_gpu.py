@@ -142,6 +142,32 @@ def test_config5_one_shard(native, oracle):
     key = c.tokens.astype(np.int64) * K + z2
     assert np.array_equal(np.bincount(key, minlength=V * K).astype(np.int32).reshape(V, K), nwk), "n_wk is not the (word, z) histogram"
     del key
+    # how dense is what a rank of config 5 sends into the count reduce-scatter?  The send buffer is the
+    # shard's (word, topic) histogram, V*K cells; a sparse exchange would ship the non-zero cells (or, incrementally, the
+    # cells a sweep changed).  Reported, not asserted (DESIGN.md section 6 quotes it); written where gpurun collects files.
+    key1 = c.tokens.astype(np.int64) * K + z1
+    nwk1 = np.bincount(key1, minlength=V * K).astype(np.int32).reshape(V, K)
+    del key1
+    freq = np.bincount(c.tokens, minlength=V)
+    head = np.argsort(-freq, kind="stable")[:V // 100]               # the 1 % most frequent words
+    density = {
+        "workload": "one of the eight shards of BASELINE config 5: D=%d V=%d K=%d N=%d, Zipf(1.07) unigram words, z after 2 sweeps from a uniform z0" % (D, V, K, N),
+        "cells": int(V) * K,
+        "nnz_counts": int(np.count_nonzero(nwk)), "density_counts": float(np.count_nonzero(nwk)) / (V * K),
+        "nnz_delta_of_one_sweep": int(np.count_nonzero(nwk != nwk1)), "density_delta": float(np.count_nonzero(nwk != nwk1)) / (V * K),
+        "tokens_that_changed_topic": int(np.count_nonzero(z1 != z2)),
+        "words_with_tokens": int(np.count_nonzero(freq)), "rows_all_zero": int(V - np.count_nonzero(freq)),
+        "density_counts_in_the_1pct_most_frequent_words": float(np.count_nonzero(nwk[head])) / (head.size * K),
+        "tokens_in_the_1pct_most_frequent_words": float(freq[head].sum()) / N,
+        "bytes_dense_int32": int(V) * K * 4, "bytes_as_index_count_pairs": int(np.count_nonzero(nwk)) * 8,
+    }
+    del nwk1
+    print("config 5 shard, count-exchange cell density:", density)
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    if os.path.isdir(out_dir):
+        import json
+        with open(os.path.join(out_dir, "config5_cell_density.json"), "w") as f:
+            json.dump(density, f, indent=1)
     for a, b in ((0, 3), (D - 3, D)):                                # first and last documents: theta rows sum to one
         th = g.get_theta(a, b)
         assert np.allclose(th.sum(1), 1.0, atol=1e-12) and (th > 0).all()

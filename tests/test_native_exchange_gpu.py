@@ -418,6 +418,35 @@ def test_forced_split_point_of_the_all_gather(native, oracle, monkeypatch, split
     h.close()
 
 
+@pytest.mark.parametrize("zcounts,every", [("0", "1"), ("2", "1"), ("2", "3"), ("0", "4")])
+def test_who_counts_and_how_often_the_phases_are_timed(native, oracle, monkeypatch, zcounts, every):
+    """With an exchange the score-register z kernels add the cold tokens' (word, topic) cells into the send buffer themselves
+    and only the hot words' segments go through count_sorted_kernel (GGS_DEBUG_ZCOUNTS=2: whatever the corpus; =0: the count
+    kernel alone, the cross-check); and only one sweep in GGS_DEBUG_TIMING_EVERY records every phase event.  Same bits, and
+    the timers still add up."""
+    monkeypatch.setenv("GGS_DEBUG_ZCOUNTS", zcounts)
+    monkeypatch.setenv("GGS_DEBUG_TIMING_EVERY", every)
+    c = random_corpus(260, 1300, 150, seed=41, empty_every=8)
+    K = 37
+    h = native.GGSHandle(K, c.num_types, 0.1, 0.01, 77, flags=native.FLAG_PARANOID)
+    h.attach_rccl(0, 1, native.rccl_unique_id())
+    h.set_corpus(c.doc_ptr, c.tokens)
+    h.set_z(java_lcg_initial_z(c.num_tokens, K, 6), redraw_phi=True)
+    h.sweep(5)
+    h.sweep_begin()
+    h.sweep_end()
+    h.sweep(3)
+    o = reference_run(oracle, c, K, 0.1, 0.01, 77, 6, 9)
+    assert_bit_equal(h.get_z(), o.get_z(), "z")
+    assert_bit_equal(h.get_type_topic_counts(), o.get_type_topic_counts(), "n_wk")
+    assert_bit_equal(h.get_phi(), o.get_phi(), "phi")
+    assert_bit_equal(h.get_theta(), o.get_theta(), "theta")
+    t = h.get_timings()
+    assert t["sweeps"] == 9 and t["z_ms"] > 0 and t["phi_ms"] > 0 and t["exchange_ms"] > 0
+    assert abs(t["exchange_ms"] - (t["exchange_rs_ms"] + t["exchange_ag_ms"])) <= 1e-6 * max(t["exchange_ms"], 1.0)
+    h.close()
+
+
 def test_attach_order_and_errors(native):
     c = random_corpus(20, 50, 30, seed=1)
     h = native.GGSHandle(5, c.num_types, 0.1, 0.01, 1)

@@ -895,6 +895,27 @@ int z_phase(ggs_handle *h) {
     HIP_TRY(h, hipEventRecord(E.e[2], h->stream));
     h->theta_ahead_iter = (int64_t)h->iteration + 1;
   } else {
+    // TIMING EXPERIMENT (GGS_DEBUG_THETA_EARLY=1; results are WRONG on purpose): the next theta is launched BESIDE the z
+    // step instead of behind it -- drawn from the z the step is still writing.  What it measures is the best case of
+    // "theta_{t+1} of document part p beside the z step of part p + 1"  without the parts' own costs
+    // (an event packet, a launch and the drain of the persistent z waves each): the z step with a theta workgroup as the
+    // SIMDs' guest, and the counts + Phi chain alone behind it.  Needs LDS beside the z kernels: GGS_DEBUG_HOT shrinks
+    // the hot-word table.  DESIGN.md section 5 has the numbers.
+    static const int theta_early = debug_env("GGS_DEBUG_THETA_EARLY") ? std::atoi(debug_env("GGS_DEBUG_THETA_EARLY")) : 0;
+    bool early = false;
+    if (theta_early && ahead && !h->xg && h->z_sliced) {
+      Events &N = h->evs[(h->ev_head + 1) % kEvRing];
+      h->chain_on_side = false;
+      N.theta_on_main = false;
+      HIP_TRY(h, hipStreamWaitEvent(h->side, E.e[1], 0));
+      HIP_TRY(h, hipEventRecord(N.th0, h->side));
+      const int b = std::max(1, std::min(h->theta_docs_per_block, theta_early > 1 ? theta_early : 16));
+      const int bp = b | 1;
+      if ((rc = launch_theta(h, h->side, h->d_theta_next, h->iteration + 1, 0, -1, (int32_t)((size_t)h->K * bp * 8 + (size_t)b * 20 + kThetaQueueBytes), b))) return rc;
+      HIP_TRY(h, hipEventRecord(N.th1, h->side));
+      h->theta_ahead_iter = (int64_t)h->iteration + 1;
+      early = true;
+    }
     const bool counting = z_counts_itself(h) && h->C > 0;
     if (counting && !h->cnt_send_zeroed && (rc = clear_send_buffer(h, h->stream))) return rc;   // nobody cleared it behind the last reduce-scatter (or none came): counts no z step asked for are overwritten, as a count rebuild overwrites them
     h->hot_counted = false;
@@ -902,7 +923,7 @@ int z_phase(ggs_handle *h) {
     if (counting) { h->z_counted = true; h->cnt_send_zeroed = false; }
     HIP_TRY(h, hipEventRecord(E.e[2], h->stream));      // the cold kernel's end; the hot chunks' stream is joined below, and by the theta draw's stream
     h->chain_on_side = h->chain_on_side && ahead;
-    if (ahead) {
+    if (ahead && !early) {
       // theta of iteration t+1 from the z just drawn, concurrent with the counts and the Phi draw
       Events &N = h->evs[(h->ev_head + 1) % kEvRing];
       hipStream_t ts = h->chain_on_side ? h->stream : h->side;

@@ -204,9 +204,20 @@ int ggs_synchronize(ggs_handle *h);
  * collectives over `nranks` handles, rank r owning the documents of shard r and the TOPICS of slice r
  * (sizes K/nranks + (K % nranks > r), EvenSplitTopicBatchBuilder.java:28-39; Ksm = the largest slice):
  *   reduce_scatter_i32  send int32 [nranks][V][Ksm] (this shard's (word, topic) histogram, slice-major, zero padded)
- *                       -> recv int32 [V][Ksm] = the corpus-wide counts of the rank's own topics
- *   all_gather_f64      send fp64 [V][Ksm] (the rank's normalised Phi slice) -> recv fp64 [nranks][V][Ksm]
- *   all_gather_i32      the same for the count slices; only when a getter / diagnostic needs corpus-wide counts
+ *                       -> recv int32 [V][Ksm] = the corpus-wide counts of the rank's own topics.  Once per sweep, on the
+ *                       handle's stream.  (Or the sparse form in its place: all_gather_i32 of nranks pair counts, then
+ *                       all_to_all_v_i32 of (cell, count) pairs -- ggs_set_count_exchange.)
+ *   all_gather_f64      TWICE per Phi phase when the vocabulary has 16 or more 64-row segments (V >= 961), with DIFFERENT
+ *                       counts and on DIFFERENT streams of the one handle, never concurrently: what travels is the rank's
+ *                       UNNORMALISED gamma draws [V][Ksm] in two halves of the vocabulary -- first the rows below v_split
+ *                       (send_count = v_split * Ksm) on the handle's high-priority COMMUNICATION stream, under the draw of
+ *                       the second half; then, behind it on the handle's own stream, the rows from v_split on followed by
+ *                       the slice's Ksm column sums (send_count = (V - v_split) * Ksm + Ksm).  The receiver divides by the
+ *                       owner's sum while repacking (the division of ParallelDirichlet.java:60-66 on the same operands).
+ *                       A short vocabulary goes in one call of (V * Ksm + Ksm) elements.  A transport must therefore take
+ *                       count and stream from each call (no cached stream, no staging sized for one fixed count).
+ *   all_gather_i32      the same for the count slices ([V][Ksm] per rank) -- only when a getter / diagnostic needs corpus-wide
+ *                       counts -- and, with the sparse count exchange, for the nranks pair counts of every sweep
  * Attach after ggs_create and before ggs_set_corpus.  From then on ggs_sweep / ggs_sweep_end / ggs_init_phi /
  * ggs_set_z(redraw) / ggs_sample_z_given_phi contain the collectives, and every call that reads corpus-wide counts
  * (ggs_get_type_topic_counts, ggs_get_topic_totals, ggs_check_invariants, ggs_model_log_likelihood,
@@ -222,7 +233,17 @@ typedef struct ggs_exchange_ops {
   int (*reduce_scatter_i32)(void *ctx, const void *send, void *recv, int64_t recv_count, void *hip_stream);
   int (*all_gather_f64)(void *ctx, const void *send, void *recv, int64_t send_count, void *hip_stream);
   int (*all_gather_i32)(void *ctx, const void *send, void *recv, int64_t send_count, void *hip_stream);
+  /* Optional (ABI version 4; may be NULL, and a table of the version-3 size -- without this member -- is accepted): the
+   * SPARSE count exchange.  Rank r receives the recv_counts[s] int32 elements rank s addressed to it, at recv + recv_offsets[s];
+   * it sends send_counts[d] elements from send + send_offsets[d] to every rank d (its own block included: a local copy).
+   * The four arrays have nranks entries, live in HOST memory and are only read during the call; the counts agree pairwise
+   * (the library exchanges them beforehand with all_gather_i32).  Used when a rank's (word, topic) histogram is sparse --
+   * BASELINE config 5: 3 % of the cells of a shard are non-zero -- instead of reduce_scatter_i32 over the dense
+   * [nranks][V][Ksm] buffer: what travels are (cell, count) pairs of the non-zero cells.  See ggs_set_count_exchange. */
+  int (*all_to_all_v_i32)(void *ctx, const void *send, const int64_t *send_offsets, const int64_t *send_counts, void *recv,
+                          const int64_t *recv_offsets, const int64_t *recv_counts, void *hip_stream);
 } ggs_exchange_ops;
+#define GGS_EXCHANGE_OPS_V3_SIZE ((int32_t)(sizeof(ggs_exchange_ops) - sizeof(void *)))
 /* Caller-supplied transport (tests: gloo through host staging; a JVM with its own collectives). */
 int ggs_attach_exchange(ggs_handle *h, int32_t rank, int32_t nranks, const ggs_exchange_ops *ops);
 /* RCCL, one process per GPU: rank 0 calls ggs_rccl_unique_id and hands the 128 bytes to every rank (any channel);
@@ -260,6 +281,17 @@ int ggs_group_gather_counts(ggs_handle **handles, int32_t n);
  * become local copies), so that one GPU can time the per-rank compute phases of an N-GPU split.  Counts and Phi are
  * then wrong by construction (ggs_check_invariants fails). */
 int ggs_attach_null_exchange(ggs_handle *h, int32_t rank, int32_t nranks);
+/* How the counts travel (typeTopicCounts of the reference; BASELINE config 5 names its rows sparse; the reference itself
+ * tracks the touched cells per topic, UPLDA:1166-1176): mode 0 = by rule (sparse where the dense buffer is large and mostly
+ * zero: V*K >= 2^26 cells and fewer tokens per rank than half of them -- both known alike on every rank, so all ranks
+ * agree), 1 = always the dense reduce-scatter, 2 = always the (cell, count) pairs.  Every rank must make the same call
+ * (before the first sweep).  Sparse needs all_to_all_v_i32 and a handle of its own process or thread (not the one-process
+ * group entry points, whose collectives are collected step by step): otherwise the dense form runs.  Results are the
+ * same integers either way. */
+int ggs_set_count_exchange(ggs_handle *h, int32_t mode);
+/* *sparse = 1 if the next count exchange of this handle ships (cell, count) pairs; *pairs_last (or NULL) = pairs this rank
+ * sent in the last one, *cells (or NULL) = V * Ksm * nranks, the dense buffer's cells. */
+int ggs_get_count_exchange(const ggs_handle *h, int32_t *sparse, int64_t *pairs_last, int64_t *cells);
 /* rank, nranks and the rank's topic slice [k_begin, k_end) (0, 1, 0, K without an exchange) */
 int ggs_get_exchange_info(const ggs_handle *h, int32_t *rank, int32_t *nranks, int32_t *k_begin, int32_t *k_end);
 /* Who carries the collectives: *provider = 0 none, 1 RCCL, 2 the caller's callbacks, 3 the null timing aid; for RCCL

@@ -51,6 +51,12 @@ class GGSTimings(C.Structure):
 EXCHANGE_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 
+# int cb(void *ctx, const void *send, const int64_t *send_offsets, const int64_t *send_counts, void *recv, const int64_t *recv_offsets,
+#        const int64_t *recv_counts, void *hip_stream)
+A2AV_CB = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64),
+                      C.c_void_p)
+
+
 class GGSExchangeOps(C.Structure):
     _fields_ = [
         ("struct_size", C.c_int32),
@@ -59,6 +65,7 @@ class GGSExchangeOps(C.Structure):
         ("reduce_scatter_i32", EXCHANGE_CB),
         ("all_gather_f64", EXCHANGE_CB),
         ("all_gather_i32", EXCHANGE_CB),
+        ("all_to_all_v_i32", A2AV_CB),
     ]
 
 
@@ -120,6 +127,8 @@ SIGNATURES = {
     "ggs_attach_null_exchange": (C.c_int, [_vp, C.c_int32, C.c_int32]),
     "ggs_get_exchange_info": (C.c_int, [_vp, _ip, _ip, _ip, _ip]),
     "ggs_get_exchange_provider": (C.c_int, [_vp, _ip, _ip, _ip]),
+    "ggs_set_count_exchange": (C.c_int, [_vp, C.c_int32]),
+    "ggs_get_count_exchange": (C.c_int, [_vp, _ip, _lp, _lp]),
     "ggs_debug_philox": (C.c_int, [C.c_int32, C.c_int64, _up, _up, _up]),
     "ggs_debug_math": (C.c_int, [C.c_int32, C.c_int32, C.c_int64, _dp, _dp, _dp]),
     "ggs_debug_draw": (C.c_int, [C.c_int32, C.c_int32, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint64, C.c_int64,

@@ -171,6 +171,18 @@ struct ggs_handle {
   int64_t sweeps_enqueued = 0;
   bool have_frac = false;
   double frac[5] = {0, 0, 0, 0, 0};                    // of e[2]..e[5]: merge | reduce-scatter | slice draw | all-gather wait | repack
+  // the SPARSE count exchange (ggs_set_count_exchange): (cell, count) pairs of the non-zero cells instead of the dense buffer
+  int32_t count_mode = 0;                              // 0 by rule, 1 dense, 2 sparse
+  bool counted_sparse = false;                         // the last count of this shard was pass A of the sparse form (the dense send buffer does not hold it)
+  bool in_group = false;                               // a handle of ggs_group_create / ggs_group_adopt: its collectives are collected step by step, no host round trip inside
+  int64_t *d_sp_count = nullptr;                       // [nranks] pairs per destination (pass A), then the write cursors of pass B
+  int32_t *d_sp_cnt32 = nullptr, *d_sp_all = nullptr;  // [nranks] the same as int32 for the all-gather; [nranks][nranks] everybody's
+  int32_t *d_sp_wg_count = nullptr;                    // [workgroups][nranks] pairs per workgroup and destination
+  int64_t *d_sp_wg_off = nullptr;                      // ... and their exclusive prefix over the workgroups
+  int64_t sp_wgs = 0;
+  int32_t *d_sp_send = nullptr, *d_sp_recv = nullptr;
+  size_t sp_send_cap = 0, sp_recv_cap = 0;             // elements
+  int64_t sp_pairs_last = 0;
   bool hot_join_pending = false, hot_counted = false;   // launch_z(defer_join): the handle's stream has not yet waited for the hot chunks' stream; the hot words' count ran there
   bool z_counted = false;                              // this sweep's z step has already added its cells into d_cnt_send
   bool cnt_send_zeroed = false;                        // d_cnt_send is all zero (cleared behind the last reduce-scatter): what the z kernels' own count updates start from
@@ -250,9 +262,52 @@ int launch_permute_z(ggs_handle *h) {
   return GGS_OK;
 }
 
+// Does the next count exchange of this handle ship (cell, count) pairs?  Every input of the rule is the same on every rank.
+bool use_sparse(const ggs_handle *h) {
+  if (!h->xg || h->in_group || !h->xg->ops.all_to_all_v_i32 || h->xg->nranks > kSparseMaxRanks) return false;
+  if ((int64_t)h->V * h->Ksm >= ((int64_t)1 << 31)) return false;       // a cell index is an int32
+  if (h->count_mode == 1) return false;
+  if (h->count_mode == 2) return true;
+  if (h->global_tokens < 0) return false;              // the rule needs a figure all ranks share
+  const int64_t cells = (int64_t)h->V * h->K;
+  return cells >= ((int64_t)1 << 26) && h->global_tokens / h->xg->nranks < cells / 2;
+}
+SparseCountParams sparse_params(const ggs_handle *h) {
+  SparseCountParams sp{};
+  sp.zw = h->d_zw; sp.seg_word = h->d_seg_word; sp.seg_begin = h->d_seg_begin; sp.K = h->K; sp.num_segs = (int32_t)h->S; sp.nranks = h->xg->nranks;
+  sp.ksm = h->Ksm; sp.rem = h->smap.rem; sp.size = h->smap.size; sp.m_size = h->smap.m_size; sp.m_size1 = h->smap.m_size1;
+  return sp;
+}
+// pass A of the sparse form: how many pairs this rank has for every destination
+int launch_sparse_count(ggs_handle *h) {
+  const int n = h->xg->nranks;
+  int rc;
+  if (!h->d_sp_count && ((rc = dev_alloc(h, &h->d_sp_count, (size_t)n)) || (rc = dev_alloc(h, &h->d_sp_cnt32, (size_t)n)) || (rc = dev_alloc(h, &h->d_sp_all, (size_t)n * n)))) return rc;
+  const int64_t wgs = (h->S + kSparseSegsPerBlock - 1) / kSparseSegsPerBlock;
+  if (wgs != h->sp_wgs || !h->d_sp_wg_count) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if ((rc = dev_alloc(h, &h->d_sp_wg_count, (size_t)wgs * n)) || (rc = dev_alloc(h, &h->d_sp_wg_off, (size_t)wgs * n))) return rc;
+    h->sp_wgs = wgs;
+  }
+  if (wgs > 0) {
+    SparseCountParams sp = sparse_params(h);
+    sp.wg_count = h->d_sp_wg_count;
+    hipLaunchKernelGGL(sparse_count_kernel<false>, dim3((unsigned)wgs), dim3(256), (size_t)h->K * sizeof(int32_t), h->stream, sp);
+    hipLaunchKernelGGL(sparse_scan_kernel, dim3((unsigned)n), dim3(256), 0, h->stream, h->d_sp_wg_count, (int32_t)wgs, n, h->d_sp_wg_off, h->d_sp_count);
+    HIP_TRY(h, hipGetLastError());
+  } else {
+    HIP_TRY(h, hipMemsetAsync(h->d_sp_count, 0, sizeof(int64_t) * (size_t)n, h->stream));
+  }
+  h->n_k_valid = false; h->counts_global = false; h->cnt_own_valid = false;
+  h->counted_sparse = true;
+  return GGS_OK;
+}
+
 // n_wk = histogram of (word, z) over this handle's tokens (UPLDA:471-474 summed over the corpus).  With an exchange the
 // histogram goes straight into the slice-major send buffer of the count reduce-scatter.
 int launch_count_rebuild(ggs_handle *h) {
+  if (use_sparse(h)) return launch_sparse_count(h);     // no dense buffer: the pairs are emitted inside the exchange step, once their number is known
+  h->counted_sparse = false;
   const size_t cells = h->xg ? (size_t)h->xg->nranks * h->V * h->Ksm : (size_t)h->K * h->V;
   int32_t *dst = h->xg ? h->d_cnt_send : h->d_n_wk;
   if (!(h->xg && h->cnt_send_zeroed)) HIP_TRY(h, hipMemsetAsync(dst, 0, cells * sizeof(int32_t), h->stream));
@@ -342,8 +397,70 @@ int clear_send_buffer(ggs_handle *h, hipStream_t on) {
 // NOT cleared in here: inside ncclGroupStart/End a collective is only collected, and a fill enqueued beside it would land
 // on the stream BEFORE it.  The callers clear once the collective is really enqueued (clear_send_buffer_if_dead); a
 // buffer nobody cleared is cleared by the next z step itself.
+// The sparse form of the count exchange: pair counts to the host, all-gathered; the pairs emitted at their offsets;
+// all-to-all of the variable blocks; scatter-add into the zeroed slice.  Two host round trips (the sizes of what travels
+// are only known on the device) -- this form is for exchanges whose dense buffer is hundreds of megabytes.
+int sparse_exchange(ggs_handle *h) {
+  const int n = h->xg->nranks, me = h->xg->rank;
+  std::vector<int64_t> mine((size_t)n), soff((size_t)n), scnt((size_t)n), roff((size_t)n), rcnt((size_t)n);
+  std::vector<int32_t> mine32((size_t)n), all((size_t)n * n);
+  HIP_TRY(h, hipMemcpyAsync(mine.data(), h->d_sp_count, sizeof(int64_t) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  int64_t total = 0;
+  for (int r = 0; r < n; ++r) {
+    if (mine[(size_t)r] > INT32_MAX / 2) return set_err(h, GGS_ERR_UNSUPPORTED, "sparse count exchange: more than 2^30 pairs for one destination");
+    mine32[(size_t)r] = (int32_t)mine[(size_t)r];
+    soff[(size_t)r] = 2 * total; scnt[(size_t)r] = 2 * mine[(size_t)r];
+    total += mine[(size_t)r];
+  }
+  h->sp_pairs_last = total;
+  HIP_TRY(h, hipMemcpyAsync(h->d_sp_cnt32, mine32.data(), sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice, h->stream));
+  int rc = xcall(h, h->xg->ops.all_gather_i32(h->xg->ops.ctx, h->d_sp_cnt32, h->d_sp_all, n, h->stream), "all_gather_i32 (pair counts)");
+  if (rc) return rc;
+  HIP_TRY(h, hipMemcpyAsync(all.data(), h->d_sp_all, sizeof(int32_t) * (size_t)n * n, hipMemcpyDeviceToHost, h->stream));
+  // the pairs, at their destinations' offsets
+  if ((size_t)(2 * total) > h->sp_send_cap) {
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    if ((rc = dev_alloc(h, &h->d_sp_send, (size_t)(2 * total) + (size_t)(2 * total) / 8 + 64))) return rc;
+    h->sp_send_cap = (size_t)(2 * total) + (size_t)(2 * total) / 8 + 64;
+  }
+  HIP_TRY(h, hipMemcpyAsync(h->d_sp_count, soff.data(), sizeof(int64_t) * (size_t)n, hipMemcpyHostToDevice, h->stream));   // the destinations' blocks
+  if (h->sp_wgs > 0) {
+    SparseCountParams sp = sparse_params(h);
+    sp.wg_off = h->d_sp_wg_off; sp.dest_base = h->d_sp_count; sp.pairs = h->d_sp_send;
+    hipLaunchKernelGGL(sparse_count_kernel<true>, dim3((unsigned)h->sp_wgs), dim3(256), (size_t)h->K * sizeof(int32_t), h->stream, sp);
+    HIP_TRY(h, hipGetLastError());
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));        // `all` has arrived (and soff / mine32 may go out of scope)
+  int64_t rtotal = 0;
+  for (int s2 = 0; s2 < n; ++s2) {
+    rcnt[(size_t)s2] = 2 * (int64_t)all[(size_t)s2 * n + me];
+    roff[(size_t)s2] = rtotal;
+    rtotal += rcnt[(size_t)s2];
+  }
+  if ((size_t)rtotal > h->sp_recv_cap) {
+    if ((rc = dev_alloc(h, &h->d_sp_recv, (size_t)rtotal + (size_t)rtotal / 8 + 64))) return rc;
+    h->sp_recv_cap = (size_t)rtotal + (size_t)rtotal / 8 + 64;
+  }
+  if ((rc = xcall(h, h->xg->ops.all_to_all_v_i32(h->xg->ops.ctx, h->d_sp_send, soff.data(), scnt.data(), h->d_sp_recv, roff.data(), rcnt.data(), h->stream), "all_to_all_v_i32")))
+    return rc;
+  HIP_TRY(h, hipMemsetAsync(h->d_cnt_own, 0, sizeof(int32_t) * (size_t)h->V * h->Ksm, h->stream));
+  if (rtotal > 0) {
+    hipLaunchKernelGGL(scatter_add_pairs_kernel, dim3(grid_for(rtotal / 2, 256)), dim3(256), 0, h->stream, h->d_sp_recv, rtotal / 2, h->d_cnt_own);
+    HIP_TRY(h, hipGetLastError());
+  }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));        // the host arrays handed to the transport stay alive until it has used them
+  h->cnt_own_valid = true;
+  return GGS_OK;
+}
+int launch_count_rebuild(ggs_handle *h);
 int exchange_reduce_scatter(ggs_handle *h) {
   if (h->cnt_own_valid) return GGS_OK;
+  if (use_sparse(h) != h->counted_sparse) {            // the form was switched between the count and its exchange: count again in the form that travels
+    int rc = launch_count_rebuild(h);
+    if (rc) return rc;
+  }
+  if (use_sparse(h)) return sparse_exchange(h);
   int rc = xcall(h, h->xg->ops.reduce_scatter_i32(h->xg->ops.ctx, h->d_cnt_send, h->d_cnt_own, (int64_t)h->V * h->Ksm, h->stream), "reduce_scatter_i32");
   if (rc) return rc;
   h->cnt_own_valid = true;
@@ -352,7 +469,7 @@ int exchange_reduce_scatter(ggs_handle *h) {
 }
 // the send buffer's contents have been through the reduce-scatter (cnt_own is their sum): dead, clear them on `on`
 int clear_send_buffer_if_dead(ggs_handle *h, hipStream_t on) {
-  if (!h->xg || h->cnt_send_zeroed || !h->cnt_own_valid) return GGS_OK;
+  if (!h->xg || h->cnt_send_zeroed || !h->cnt_own_valid || use_sparse(h)) return GGS_OK;
   return clear_send_buffer(h, on);
 }
 
@@ -644,7 +761,7 @@ int launch_pcgs_z(ggs_handle *h) {
 // on the rank) 0.139 / 0.132 ms against 0.040 of count kernel; N = 4 (100) 0.290 / 0.26 against 0.05; N = 2 (200) 0.627 / 0.52
 // against 0.07 -- they pay up to about 64 tokens per word (GGS_DEBUG_ZCOUNTS=2 forces them).
 bool z_counts_itself(const ggs_handle *h) {
-  return h->xg && h->z_counts && h->z_sliced && !(h->flags & GGS_FLAG_PCGS) && (h->z_counts_forced || h->N <= (int64_t)64 * h->V);
+  return h->xg && h->z_counts && h->z_sliced && !(h->flags & GGS_FLAG_PCGS) && (h->z_counts_forced || h->N <= (int64_t)64 * h->V) && !use_sparse(h);
 }
 // `defer_join` (with `count`, split form): the hot words' count launch follows the hot kernel on ITS stream and the
 // handle's stream is not made to wait for that stream here -- the caller does (join_hot_stream), behind the z step's end
@@ -920,7 +1037,7 @@ int z_phase(ggs_handle *h) {
     if (counting && !h->cnt_send_zeroed && (rc = clear_send_buffer(h, h->stream))) return rc;   // nobody cleared it behind the last reduce-scatter (or none came): counts no z step asked for are overwritten, as a count rebuild overwrites them
     h->hot_counted = false;
     if ((rc = launch_z(h, false, 0, -1, counting, /*defer_join=*/counting))) return rc;
-    if (counting) { h->z_counted = true; h->cnt_send_zeroed = false; }
+    if (counting) { h->z_counted = true; h->cnt_send_zeroed = false; h->counted_sparse = false; }
     HIP_TRY(h, hipEventRecord(E.e[2], h->stream));      // the cold kernel's end; the hot chunks' stream is joined below, and by the theta draw's stream
     h->chain_on_side = h->chain_on_side && ahead;
     if (ahead && !early) {
@@ -1032,6 +1149,7 @@ int setup_exchange(ggs_handle *h, Exchange *x) {
     h->smap.rank_stride = (int64_t)h->V * h->Ksm;
     if (const char *e = debug_env("GGS_DEBUG_ZCOUNTS")) { h->z_counts = std::atoi(e) != 0; h->z_counts_forced = std::atoi(e) == 2; }
     if (const char *e = debug_env("GGS_DEBUG_TIMING_EVERY")) h->detail_every = std::max(1, std::atoi(e));
+    if (const char *e = debug_env("GGS_DEBUG_COUNT_EXCHANGE")) h->count_mode = std::max(0, std::min(2, std::atoi(e)));
   }
   std::vector<int64_t> koff((size_t)h->K);
   for (int32_t r = 0; r < x->nranks; ++r)
@@ -1105,6 +1223,7 @@ Exchange *new_rccl_exchange(ggs_handle *h, int32_t rank, int32_t nranks, int *rc
   x->ops.reduce_scatter_i32 = xops::rccl_reduce_scatter_i32;
   x->ops.all_gather_f64 = xops::rccl_all_gather_f64;
   x->ops.all_gather_i32 = xops::rccl_all_gather_i32;
+  x->ops.all_to_all_v_i32 = (api->Send && api->Recv) ? xops::rccl_all_to_all_v_i32 : nullptr;
   *rc = GGS_OK;
   return x;
 }
@@ -1404,7 +1523,8 @@ void ggs_destroy(ggs_handle *h) {
                   h->d_status, h->d_scratch, h->d_sum_pref, h->d_sum_fn, h->d_ct_tok, h->d_ct_idx, h->d_ct_ip, h->d_c_docs, h->d_hot_words, h->d_order,
                   h->d_test_ptr, h->d_test_tok, h->d_test_ll, h->d_test_docs, h->d_koff, h->d_cnt_send, h->d_cnt_own, h->d_cnt_all, h->d_n_k_own,
                   h->d_heldout_spill, h->d_phi_own, h->d_phi_all0, h->d_phi_all1, h->d_mag_own, h->d_krank, h->d_kcol, h->d_lcg, h->d_chunk_doc1,
-                  h->d_hseg_word, h->d_hseg_begin, h->d_hseg_end};
+                  h->d_hseg_word, h->d_hseg_begin, h->d_hseg_end, h->d_sp_count, h->d_sp_cnt32, h->d_sp_all, h->d_sp_send, h->d_sp_recv, h->d_sp_wg_count,
+                  h->d_sp_wg_off};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   exchange_free(h->xg);
@@ -1849,11 +1969,14 @@ int ggs_set_global_token_count(ggs_handle *h, int64_t n_tokens) {
 int ggs_attach_exchange(ggs_handle *h, int32_t rank, int32_t nranks, const ggs_exchange_ops *ops) {
   int rc = exchange_precheck(h, rank, nranks);
   if (rc) return rc;
-  if (!ops || ops->struct_size != (int32_t)sizeof(ggs_exchange_ops) || !ops->reduce_scatter_i32 || !ops->all_gather_f64 || !ops->all_gather_i32)
+  if (!ops || (ops->struct_size != (int32_t)sizeof(ggs_exchange_ops) && ops->struct_size != GGS_EXCHANGE_OPS_V3_SIZE) || !ops->reduce_scatter_i32 ||
+      !ops->all_gather_f64 || !ops->all_gather_i32)
     return set_err(h, GGS_ERR_BAD_ARG, "ggs_exchange_ops: wrong struct_size or a null callback");
   auto *x = new (std::nothrow) Exchange();
   if (!x) return GGS_ERR_HIP;
-  x->rank = rank; x->nranks = nranks; x->ops = *ops;
+  x->rank = rank; x->nranks = nranks;
+  std::memcpy(&x->ops, ops, (size_t)ops->struct_size);   // a version-3 table has no all_to_all_v_i32: it stays null, the count exchange dense
+  x->ops.struct_size = (int32_t)sizeof(ggs_exchange_ops);
   return setup_exchange(h, x);
 }
 
@@ -1867,6 +1990,7 @@ int ggs_attach_null_exchange(ggs_handle *h, int32_t rank, int32_t nranks) {
   x->ops.reduce_scatter_i32 = xops::null_reduce_scatter_i32;
   x->ops.all_gather_f64 = xops::null_all_gather<double>;
   x->ops.all_gather_i32 = xops::null_all_gather<int32_t>;
+  x->ops.all_to_all_v_i32 = xops::null_all_to_all_v_i32;
   return setup_exchange(h, x);
 }
 
@@ -1918,6 +2042,20 @@ int ggs_get_exchange_info(const ggs_handle *h, int32_t *rank, int32_t *nranks, i
   if (nranks) *nranks = h->xg ? h->xg->nranks : 1;
   if (k_begin) *k_begin = h->k0;
   if (k_end) *k_end = h->k0 + h->Ks;
+  return GGS_OK;
+}
+
+int ggs_set_count_exchange(ggs_handle *h, int32_t mode) {
+  if (!h || mode < 0 || mode > 2) return GGS_ERR_BAD_ARG;
+  if (h->in_sweep) return set_err(h, GGS_ERR_STATE, "inside a split sweep");
+  h->count_mode = mode;
+  return GGS_OK;
+}
+int ggs_get_count_exchange(const ggs_handle *h, int32_t *sparse, int64_t *pairs_last, int64_t *cells) {
+  if (!h || !sparse) return GGS_ERR_BAD_ARG;
+  *sparse = use_sparse(h) ? 1 : 0;
+  if (pairs_last) *pairs_last = h->sp_pairs_last;
+  if (cells) *cells = h->xg ? (int64_t)h->V * h->Ksm * h->xg->nranks : (int64_t)h->V * h->K;
   return GGS_OK;
 }
 
@@ -2035,6 +2173,7 @@ int ggs_group_create(const ggs_config *cfg, int32_t n, const int32_t *device_ids
     return rc;
   }
   out[0]->group.assign(out, out + n);
+  for (int32_t i = 0; i < n; ++i) out[i]->in_group = true;
   return GGS_OK;
 }
 
@@ -2046,6 +2185,7 @@ int ggs_group_adopt(ggs_handle **hs, int32_t n) {
     if (hs[i]->xg->rank != i || hs[i]->xg->nranks != n) return set_err(hs[i], GGS_ERR_BAD_ARG, "ggs_group_adopt: handle i must be rank i of n");
   }
   hs[0]->group.assign(hs, hs + n);
+  for (int32_t i = 0; i < n; ++i) hs[i]->in_group = true;
   return GGS_OK;
 }
 

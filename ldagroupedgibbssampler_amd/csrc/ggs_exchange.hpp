@@ -32,6 +32,8 @@ struct RcclApi {
   decltype(&ncclGroupStart) GroupStart = nullptr;
   decltype(&ncclGroupEnd) GroupEnd = nullptr;
   decltype(&ncclGetErrorString) GetErrorString = nullptr;
+  decltype(&ncclSend) Send = nullptr;                    // optional: the sparse count exchange (all_to_all_v_i32)
+  decltype(&ncclRecv) Recv = nullptr;
   decltype(&ncclCommCount) CommCount = nullptr;           // optional: what the communicator itself says (ggs_get_exchange_provider)
   decltype(&ncclCommUserRank) CommUserRank = nullptr;
 
@@ -59,6 +61,8 @@ struct RcclApi {
       api.GroupStart = reinterpret_cast<decltype(api.GroupStart)>(sym("ncclGroupStart"));
       api.GroupEnd = reinterpret_cast<decltype(api.GroupEnd)>(sym("ncclGroupEnd"));
       api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(sym("ncclGetErrorString"));
+      api.Send = reinterpret_cast<decltype(api.Send)>(dlsym(api.lib, "ncclSend"));
+      api.Recv = reinterpret_cast<decltype(api.Recv)>(dlsym(api.lib, "ncclRecv"));
       api.CommCount = reinterpret_cast<decltype(api.CommCount)>(dlsym(api.lib, "ncclCommCount"));
       api.CommUserRank = reinterpret_cast<decltype(api.CommUserRank)>(dlsym(api.lib, "ncclCommUserRank"));
     });
@@ -97,6 +101,42 @@ inline int rccl_all_gather_i32(void *ctx, const void *send, void *recv, int64_t 
   auto *x = static_cast<Exchange *>(ctx);
   const ncclResult_t r = x->api->AllGather(send, recv, (size_t)send_count, ncclInt32, x->comm, static_cast<hipStream_t>(stream));
   return r == ncclSuccess ? 0 : rccl_fail(x, r, "ncclAllGather(i32)");
+}
+
+// all-to-all of variable blocks: one ncclSend + ncclRecv per peer inside a group (the own block: a device copy)
+inline int rccl_all_to_all_v_i32(void *ctx, const void *send, const int64_t *soff, const int64_t *scnt, void *recv, const int64_t *roff,
+                                 const int64_t *rcnt, void *stream) {
+  auto *x = static_cast<Exchange *>(ctx);
+  auto st = static_cast<hipStream_t>(stream);
+  const int32_t *sp = static_cast<const int32_t *>(send);
+  int32_t *rp = static_cast<int32_t *>(recv);
+  if (scnt[x->rank] != rcnt[x->rank]) { x->err = "all_to_all_v: own block counts differ"; return 1; }
+  if (scnt[x->rank] > 0 &&
+      hipMemcpyAsync(rp + roff[x->rank], sp + soff[x->rank], (size_t)scnt[x->rank] * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) { x->err = "all_to_all_v: own block copy"; return 1; }
+  if (x->nranks == 1) return 0;
+  ncclResult_t r = x->api->GroupStart();
+  for (int p = 0; p < x->nranks && r == ncclSuccess; ++p) {
+    if (p == x->rank) continue;
+    if (scnt[p] > 0) r = x->api->Send(sp + soff[p], (size_t)scnt[p], ncclInt32, p, x->comm, st);
+    if (r == ncclSuccess && rcnt[p] > 0) r = x->api->Recv(rp + roff[p], (size_t)rcnt[p], ncclInt32, p, x->comm, st);
+  }
+  const ncclResult_t e = x->api->GroupEnd();
+  if (r == ncclSuccess) r = e;
+  return r == ncclSuccess ? 0 : rccl_fail(x, r, "ncclSend/ncclRecv (all_to_all_v)");
+}
+// the timing aid: the block this rank addresses to itself stands in for every peer's (the null all-gather of the pair
+// counts has told the caller to expect exactly that many elements from each)
+inline int null_all_to_all_v_i32(void *ctx, const void *send, const int64_t *soff, const int64_t *scnt, void *recv, const int64_t *roff,
+                                 const int64_t *rcnt, void *stream) {
+  auto *x = static_cast<Exchange *>(ctx);
+  const int me = x->rank;
+  for (int s = 0; s < x->nranks; ++s) {
+    const int64_t n = rcnt[s] < scnt[me] ? rcnt[s] : scnt[me];
+    if (n > 0 && hipMemcpyAsync(static_cast<int32_t *>(recv) + roff[s], static_cast<const int32_t *>(send) + soff[me], (size_t)n * 4, hipMemcpyDeviceToDevice,
+                                static_cast<hipStream_t>(stream)) != hipSuccess)
+      return 1;
+  }
+  return 0;
 }
 
 // the timing aid: this rank's own contribution stands in for every peer's

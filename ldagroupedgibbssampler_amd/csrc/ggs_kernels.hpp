@@ -229,6 +229,102 @@ __global__ __launch_bounds__(256) void count_sorted_kernel(CountParams p) {
 }
 
 // ------------------------------------------------------------------------------
+// The SPARSE count exchange (include/ggs_hip.h, ggs_set_count_exchange): instead of the dense [nranks][V][Ksm] histogram a
+// rank ships the non-zero cells of its (word, topic) histogram as (cell, count) pairs, cell = v * Ksm + column in the
+// destination rank's slice.  The reference tracks exactly this touched-cell set per topic (globalDeltaNUpdates,
+// UPLDA:1166-1176).  Two passes over the word-sorted z, each a per-segment LDS histogram [K]:
+//   EMIT = false   how many pairs go to every destination (dest_count [nranks])
+//   EMIT = true    the pairs, appended at dest_cursor[r] (initialised with the destination's offset in the send buffer)
+// A word with several segments emits a cell several times: the receiver adds them up.  Pair order is whatever the
+// atomics make it; the sums are order-free.
+// ------------------------------------------------------------------------------
+struct SparseCountParams {
+  const int32_t *zw, *seg_word, *seg_begin;
+  int32_t K, num_segs, nranks;
+  int32_t ksm;
+  int32_t *wg_count;          // [workgroups][nranks] pairs per destination (EMIT = false: written)
+  const int64_t *wg_off;      // [workgroups][nranks] exclusive prefix of wg_count over the workgroups (EMIT = true: read)
+  const int64_t *dest_base;   // [nranks] element offset of a destination's block in `pairs` (EMIT = true)
+  int32_t *pairs;             // (cell, count) int32 pairs
+  // topic -> (rank, column): the even split of EvenSplitTopicBatchBuilder.java:28-39
+  int32_t rem, size;
+  uint32_t m_size, m_size1;
+};
+constexpr int kSparseMaxRanks = 64;
+constexpr int kSparseSegsPerBlock = 32;   // segments per workgroup: one row of the offset table per workgroup
+
+// No global atomics: pass A leaves every workgroup's pair count per destination, a scan turns them into offsets, and pass B
+// writes each workgroup's pairs into its own stretch of the destination's block (positions inside it by an LDS cursor).
+// (A first version appended every pair at a global cursor per destination: 28 M returning atomics on 8 addresses, 571 ms.)
+template <bool EMIT>
+__global__ __launch_bounds__(256) void sparse_count_kernel(SparseCountParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  int32_t *hist = reinterpret_cast<int32_t *>(smem);                       // [K]
+  __shared__ int32_t dest_n[kSparseMaxRanks];                              // pass A: pairs so far; pass B: pairs written so far
+  __shared__ long long dest_at[kSparseMaxRanks];                           // pass B: this workgroup's first element in each destination's block
+  const int tid = threadIdx.x, K = p.K;
+  const int seg0 = blockIdx.x * kSparseSegsPerBlock, seg1 = min(seg0 + kSparseSegsPerBlock, p.num_segs);
+  if (tid < kSparseMaxRanks) {
+    dest_n[tid] = 0;
+    if (EMIT && tid < p.nranks) dest_at[tid] = p.dest_base[tid] + 2 * p.wg_off[(size_t)blockIdx.x * p.nranks + tid];
+  }
+  auto owner = [&](int k, int &r, int &c) {
+    const int cut = p.rem * (p.size + 1);
+    if (k < cut) { r = udiv_small(k, p.m_size1); c = k - r * (p.size + 1); }
+    else { const int q = udiv_small(k - cut, p.m_size); r = p.rem + q; c = k - cut - q * p.size; }
+  };
+  for (int seg = seg0; seg < seg1; ++seg) {
+    const int beg = p.seg_begin[seg], end = p.seg_begin[seg + 1], w = p.seg_word[seg];
+    for (int k = tid; k < K; k += 256) hist[k] = 0;
+    __syncthreads();
+    for (int i = beg + tid; i < end; i += 256) atomicAdd(&hist[p.zw[i]], 1);
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) {
+      const int32_t cnt = hist[k];
+      if (!cnt) continue;
+      int r, c;
+      owner(k, r, c);
+      const int slot = atomicAdd(&dest_n[r], 1);                         // LDS
+      if (EMIT) {
+        const long long at = dest_at[r] + 2ll * slot;
+        p.pairs[at] = w * p.ksm + c;                                     // V * Ksm < 2^31 (checked by the host)
+        p.pairs[at + 1] = cnt;
+      }
+    }
+    __syncthreads();
+  }
+  if (!EMIT && tid < p.nranks) p.wg_count[(size_t)blockIdx.x * p.nranks + tid] = dest_n[tid];
+}
+
+// wg_off[g][r] = sum over g' < g of wg_count[g'][r]; total[r] = the sum over all workgroups.  One workgroup per destination.
+__global__ __launch_bounds__(256) void sparse_scan_kernel(const int32_t *wg_count, int32_t num_wg, int32_t nranks, int64_t *wg_off, int64_t *total) {
+  __shared__ long long part[256];
+  const int r = blockIdx.x, tid = threadIdx.x;
+  const int per = (num_wg + 255) / 256, g0 = tid * per, g1 = min(g0 + per, num_wg);
+  long long s = 0;
+  for (int g = g0; g < g1; ++g) s += wg_count[(size_t)g * nranks + r];
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) {
+    long long run = 0;
+    for (int i = 0; i < 256; ++i) { const long long v = part[i]; part[i] = run; run += v; }
+    total[r] = run;
+  }
+  __syncthreads();
+  long long run = part[tid];
+  for (int g = g0; g < g1; ++g) { wg_off[(size_t)g * nranks + r] = run; run += wg_count[(size_t)g * nranks + r]; }
+}
+
+// cnt_own[cell] += count for the received pairs (cnt_own zeroed before the launch)
+__global__ __launch_bounds__(256) void scatter_add_pairs_kernel(const int32_t *pairs, int64_t num_pairs, int32_t *cnt_own) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < num_pairs; i += stride) {
+    const int2 pc = reinterpret_cast<const int2 *>(pairs)[i];
+    atomicAdd(&cnt_own[pc.x], pc.y);
+  }
+}
+
+// ------------------------------------------------------------------------------
 // K6/K8: Phi draw (GGS:182-198 / MarsagliaSparseDirichlet.java:31-55).
 //   column sum <int32,true>    magnitude_k = sum_v (beta + n_kv), v ascending (the
 //                              Dirichlet(double[]) constructor); also tokensPerTopic

@@ -39,6 +39,12 @@ __device__ __forceinline__ int64_t slice_cell(const SliceMap &m, int k, int w) {
   return (int64_t)r * m.rank_stride + (int64_t)w * m.ksm + c;
 }
 
+__device__ __forceinline__ void slice_rank_col(const SliceMap &m, int k, int &r, int &c) {
+  const int cut = m.rem * (m.size + 1);
+  if (k < cut) { r = udiv_small(k, m.m_size1); c = k - r * (m.size + 1); }
+  else { const int q = udiv_small(k - cut, m.m_size); r = m.rem + q; c = k - cut - q * m.size; }
+}
+
 struct ZParams {
   const int32_t *tok;
   const int32_t *inv_perm;     // position of token i in the word-sorted order

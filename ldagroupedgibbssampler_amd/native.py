@@ -99,8 +99,10 @@ class GGSHandle:
         """Timing aid only (results are wrong by construction): rank `rank` of `nranks` with the peers missing."""
         self._chk(self._L.ggs_attach_null_exchange(self._h, int(rank), int(nranks)))
 
-    def attach_exchange(self, rank, nranks, reduce_scatter_i32, all_gather_f64, all_gather_i32):
-        """Caller-supplied transport: three callables (send_ptr, recv_ptr, count, hip_stream_ptr) -> 0 on success."""
+    def attach_exchange(self, rank, nranks, reduce_scatter_i32, all_gather_f64, all_gather_i32, all_to_all_v_i32=None):
+        """Caller-supplied transport: three callables (send_ptr, recv_ptr, count, hip_stream_ptr) -> 0 on success, and
+        optionally the one of the sparse count exchange: (send_ptr, send_offsets, send_counts, recv_ptr, recv_offsets,
+        recv_counts, hip_stream_ptr) with the four lists in int32 elements, one entry per rank."""
         def wrap(fn):
             def cb(_ctx, send, recv, count, stream):
                 try:
@@ -113,8 +115,28 @@ class GGSHandle:
         ops = _lib.GGSExchangeOps()
         ops.struct_size = C.sizeof(_lib.GGSExchangeOps)
         ops.reduce_scatter_i32, ops.all_gather_f64, ops.all_gather_i32 = wrap(reduce_scatter_i32), wrap(all_gather_f64), wrap(all_gather_i32)
+        if all_to_all_v_i32 is not None:
+            def a2a(_ctx, send, soff, scnt, recv, roff, rcnt, stream):
+                try:
+                    n = int(nranks)
+                    return int(all_to_all_v_i32(send, [soff[i] for i in range(n)], [scnt[i] for i in range(n)], recv, [roff[i] for i in range(n)],
+                                                [rcnt[i] for i in range(n)], stream) or 0)
+                except Exception:
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            ops.all_to_all_v_i32 = _lib.A2AV_CB(a2a)
         self._keep.append(ops)             # the library copies the table, the thunks must outlive the handle
         self._chk(self._L.ggs_attach_exchange(self._h, int(rank), int(nranks), C.byref(ops)))
+
+    def set_count_exchange(self, mode):
+        """How the counts travel: "auto" (sparse where the dense buffer is large and mostly zero), "dense", "sparse"."""
+        self._chk(self._L.ggs_set_count_exchange(self._h, {"auto": 0, "dense": 1, "sparse": 2}[mode]))
+
+    def count_exchange(self):
+        sp, pairs, cells = C.c_int32(), C.c_int64(), C.c_int64()
+        self._chk(self._L.ggs_get_count_exchange(self._h, C.byref(sp), C.byref(pairs), C.byref(cells)))
+        return {"sparse": bool(sp.value), "pairs_last": pairs.value, "dense_cells": cells.value}
 
     def exchange_info(self):
         r, n, a, b = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()

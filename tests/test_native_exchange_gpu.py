@@ -418,6 +418,128 @@ def test_forced_split_point_of_the_all_gather(native, oracle, monkeypatch, split
     h.close()
 
 
+def _sparse_rank(native, tr, rank, world, whole, K, scheme, mode, sweeps, out, errs):
+    import torch
+    from ldagroupedgibbssampler_amd.sharded import _DevPtr
+    try:
+        dev = torch.device("cuda", 0)
+
+        def view(ptr, n, typestr):
+            return torch.as_tensor(_DevPtr(ptr, n, typestr), device=dev)
+
+        def reduce_scatter_i32(send, recv, count, stream):
+            torch.cuda.synchronize()
+            parts = tr.exchange(rank, view(send, count * world, "<i4").cpu().numpy().reshape(world, count))
+            view(recv, count, "<i4").copy_(torch.from_numpy(np.sum([p[rank] for p in parts], axis=0, dtype=np.int32)))
+            torch.cuda.synchronize()
+            out[rank]["dense_calls"] += 1
+            return 0
+
+        def all_gather(typestr):
+            def cb(send, recv, count, stream):
+                torch.cuda.synchronize()
+                parts = tr.exchange(rank, view(send, count, typestr).cpu().numpy())
+                view(recv, count * world, typestr).copy_(torch.from_numpy(np.concatenate(parts)))
+                torch.cuda.synchronize()
+                return 0
+            return cb
+
+        def all_to_all_v(send, soff, scnt, recv, roff, rcnt, stream):
+            torch.cuda.synchronize()
+            total = max(soff[i] + scnt[i] for i in range(world))
+            mine = view(send, max(total, 1), "<i4").cpu().numpy()
+            blocks = [mine[soff[d]:soff[d] + scnt[d]].copy() for d in range(world)]
+            everyone = tr.exchange(rank, blocks)                   # everyone[s][d] = what rank s addresses to rank d
+            for s_ in range(world):
+                got = everyone[s_][rank]
+                assert got.size == rcnt[s_], "rank %d expected %d elements from rank %d, got %d" % (rank, rcnt[s_], s_, got.size)
+                if got.size:
+                    view(recv + 4 * roff[s_], got.size, "<i4").copy_(torch.from_numpy(got))
+            torch.cuda.synchronize()
+            out[rank]["sparse_calls"] += 1
+            out[rank]["pairs_sent"] += sum(scnt) // 2
+            return 0
+
+        bounds = even_split(whole.num_docs, world)
+        sub, doc_base, tok_base = whole.shard(bounds[rank], bounds[rank + 1])
+        flags = native.FLAG_PCGS if scheme == "pcgs" else 0
+        h = native.GGSHandle(K, whole.num_types, 0.1, 0.01, 515, flags=flags)
+        h.attach_exchange(rank, world, reduce_scatter_i32, all_gather("<f8"), all_gather("<i4"), all_to_all_v)
+        h.set_count_exchange(mode)
+        h.set_corpus(sub.doc_ptr, sub.tokens, doc_base, tok_base)
+        h.set_global_token_count(whole.num_tokens)
+        z0 = java_lcg_initial_z(whole.num_tokens, K, 23)
+        h.set_z(z0[tok_base:tok_base + sub.num_tokens], redraw_phi=True)
+        h.sweep(sweeps - 1)
+        h.sweep_begin()
+        h.sweep_end()
+        h.check_invariants()
+        out[rank].update(z=h.get_z(), nwk=h.get_type_topic_counts(), nk=h.get_topic_totals(), phi=h.get_phi(), how=h.count_exchange())
+        h.close()
+    except BaseException as e:                      # noqa: BLE001
+        errs.append(e)
+        tr.bar.abort()
+
+
+@pytest.mark.parametrize("scheme,K,world,V", [("ggs", 100, 3, 900), ("ggs", 200, 3, 1500), ("pcgs", 24, 2, 700), ("ggs", 2, 3, 300), ("ggs", 37, 4, 1100)])
+def test_sparse_count_exchange_equals_the_dense_one(native, oracle, scheme, K, world, V):
+    """ggs_set_count_exchange: the counts as (cell, count) pairs of the non-zero cells over all_to_all_v_i32 (what BASELINE
+    config 5 asks for: a shard's histogram there is 3 % dense) against the dense reduce-scatter and against the unsharded
+    oracle: the same integers, hence the same Phi and the same z.  Unequal slices, a rank without a topic, pcgs, the
+    score-register and the streaming z kernels."""
+    whole = random_corpus(240, V, 110, seed=3 + K, empty_every=9)
+    sweeps = 3
+    res = {}
+    for mode in ("sparse", "dense"):
+        tr, errs = ThreadTransport(world), []
+        out = [dict(dense_calls=0, sparse_calls=0, pairs_sent=0) for _ in range(world)]
+        ts = [threading.Thread(target=_sparse_rank, args=(native, tr, r, world, whole, K, scheme, mode, sweeps, out, errs)) for r in range(world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if errs:
+            raise errs[0]
+        res[mode] = out
+    o = reference_run(oracle, whole, K, 0.1, 0.01, 515, 23, sweeps, scheme)
+    for mode, out in res.items():
+        assert_bit_equal(np.concatenate([p["z"] for p in out]), o.get_z(), mode + " z")
+        for r, p in enumerate(out):
+            assert_bit_equal(p["nwk"], o.get_type_topic_counts(), "%s n_wk on rank %d" % (mode, r))
+            assert_bit_equal(p["nk"], o.get_topic_totals(), "%s n_k on rank %d" % (mode, r))
+            assert_bit_equal(p["phi"], o.get_phi(), "%s phi on rank %d" % (mode, r))
+            assert p["how"]["sparse"] == (mode == "sparse")
+            if mode == "sparse":
+                assert p["dense_calls"] == 0 and p["sparse_calls"] >= sweeps + 1 and 0 < p["pairs_sent"]
+                assert p["how"]["pairs_last"] <= p["how"]["dense_cells"]
+            else:
+                assert p["sparse_calls"] == 0 and p["dense_calls"] >= sweeps + 1
+
+
+def test_sparse_count_exchange_through_rccl_with_one_rank(native, oracle):
+    """The RCCL provider's all_to_all_v_i32 (ncclSend/ncclRecv in a group; one rank: the own block) and the host round
+    trips of the sparse form, forced on a small corpus; also switching the form between two sweeps."""
+    c = random_corpus(200, 1300, 120, seed=19, empty_every=8)
+    K = 29
+    h = native.GGSHandle(K, c.num_types, 0.1, 0.01, 4, flags=native.FLAG_PARANOID)
+    h.attach_rccl(0, 1, native.rccl_unique_id())
+    h.set_count_exchange("sparse")
+    h.set_corpus(c.doc_ptr, c.tokens)
+    h.set_z(java_lcg_initial_z(c.num_tokens, K, 2), redraw_phi=True)
+    assert h.count_exchange()["sparse"]
+    h.sweep(2)
+    assert 0 < h.count_exchange()["pairs_last"] <= c.num_tokens
+    h.set_count_exchange("dense")
+    h.sweep(1)
+    h.set_count_exchange("sparse")
+    h.sweep(1)
+    o = reference_run(oracle, c, K, 0.1, 0.01, 4, 2, 4)
+    assert_bit_equal(h.get_z(), o.get_z(), "z")
+    assert_bit_equal(h.get_type_topic_counts(), o.get_type_topic_counts(), "n_wk")
+    assert_bit_equal(h.get_phi(), o.get_phi(), "phi")
+    h.close()
+
+
 @pytest.mark.parametrize("zcounts,every", [("0", "1"), ("2", "1"), ("2", "3"), ("0", "4")])
 def test_who_counts_and_how_often_the_phases_are_timed(native, oracle, monkeypatch, zcounts, every):
     """With an exchange the score-register z kernels add the cold tokens' (word, topic) cells into the send buffer themselves

@@ -58,8 +58,11 @@ namespace ggs {
 constexpr int kSliceTopics = 16;
 constexpr int kSliceUnits = 8;            // 16-byte units per row per slice
 constexpr int kSliceBytes = 64 * 128;     // 64 rows x 16 topics x 8 B
+// Two slots (one slice in flight beyond the one being scored) since round 4: the LDS a third slot takes is worth more as
+// hot-word table -- measured at BASELINE config 2, sweep / z step in ms: 2 slots 1.496 / 0.922 (96 hot rows), 3 slots
+// 1.548 / 0.968 (57 rows), 4 slots 1.622 / 1.048 (19 rows).  (Round 1 chose 3 when the hot chunks still cost twice as much.)
 #ifndef GGS_RING_SLOTS
-#define GGS_RING_SLOTS 3
+#define GGS_RING_SLOTS 2
 #endif
 constexpr int kRingSlots = GGS_RING_SLOTS;
 constexpr int kSlicedMaxTopics = 192;     // 384 score registers (VGPR + AGPR) + working set < 512

@@ -361,6 +361,9 @@ def main():
                          "the native exchange then runs over its callback provider with host staging")
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (rehearsal only; the number is not a multi-GPU result)")
     ap.add_argument("--no-weak-leg", action="store_true", help="N>1: skip the second measurement (the other scaling regime)")
+    ap.add_argument("--large-factor", type=int, default=3,
+                    help="N>1: a third leg, the strong split of a corpus this many times the headline's (0/1: none), with its own one-GPU time from the same run")
+    ap.add_argument("--no-large-leg", action="store_true", help="N>1: skip that leg")
     ap.add_argument("--no-verify", action="store_true",
                     help="N>1 / --force-sharded: skip the comparison of the N-rank end state with one handle over the whole corpus (parity_vs_one_gpu)")
     ap.add_argument("--force-sharded", action="store_true",
@@ -422,9 +425,9 @@ def main():
 
     K = args.topics
 
-    def run_sharded(weak):
+    def run_sharded(weak, docs=None):
         """One measurement over `world` ranks: dict(dt, phases, docs, tokens, n_local, V, info, local corpus)"""
-        corpus = synthetic_lda_corpus(args.docs, args.types, args.mean_len, true_topics=100, seed=args.seed + (rank if weak else 0))
+        corpus = synthetic_lda_corpus(docs or args.docs, args.types, args.mean_len, true_topics=100, seed=args.seed + (rank if weak else 0))
         h = make_handle(native, K, corpus.num_types, args, local_rank)
         try:
             return run_sharded_on(h, corpus, weak)
@@ -494,9 +497,14 @@ def main():
             try:
                 h1.set_corpus(corpus.doc_ptr, corpus.tokens)
                 h1.set_z(java_lcg_initial_z(corpus.num_tokens, K, args.seed), redraw_phi=True)
+                one_dt = None
                 for n in (args.warmup, args.steps):             # the same batches; only the number of sweeps matters to the state
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
                     for i in range(0, n, 5):
                         h1.sweep(min(5, n - i))
+                    torch.cuda.synchronize()
+                    one_dt = time.perf_counter() - t1           # of the second batch: the same --steps sweeps the N ranks were timed on
                 z1, th1 = h1.get_z(), h1.get_theta()
                 one = state_digests(h1, z1)
                 bounds = even_split(corpus.num_docs, world)
@@ -516,7 +524,10 @@ def main():
                        "compared": "sha256 of the bit patterns of z and theta (per shard), phi and n_k (on every rank) after %d sweeps from the same z0, against ONE handle "
                                    "over the whole corpus run by rank 0 after the timed region" % (args.warmup + args.steps),
                        "mismatches": bad, "one_gpu_z_form": h1.launch_info().get("z_form"), "z_form_per_rank": [e["z_form"] for e in every],
-                       "comm_nranks_per_rank": [e["comm_nranks"] for e in every]}
+                       "comm_nranks_per_rank": [e["comm_nranks"] for e in every],
+                       # the same corpus, the same sweeps, ONE GPU (rank 0's), in this very run: the strong-scaling ratio without a second invocation
+                       "one_gpu_ms_per_step": round(one_dt / args.steps * 1e3, 4),
+                       "speedup_vs_one_gpu_same_run": round(one_dt / r["dt"], 3)}
             finally:
                 h1.close()
             stage(rank, "verification %s" % ("OK: bit-identical to the one-GPU run" if out["parity_vs_one_gpu"] else "FAILED: %s" % out["mismatches"]))
@@ -526,14 +537,14 @@ def main():
 
     fallback = []
 
-    def run_sharded_or_fall_back(weak):
+    def run_sharded_or_fall_back(weak, docs=None):
         """A native exchange that cannot be set up on every rank (librccl not loadable, ncclCommInitRank refused) would cost
         the whole scaling record: all ranks then agree to repeat the leg over torch.distributed (round 1's form: dense
         count all-reduce, Phi re-drawn everywhere) and the line says so.  Only failures every rank sees before its first
         sweep are covered -- one rank failing inside a collective leaves the others waiting, as with any collective."""
         err = None
         try:
-            res = run_sharded(weak)
+            res = run_sharded(weak, docs)
         except Exception as e:      # noqa: BLE001 -- whatever it was, the other ranks must hear of it
             res, err = None, "%s: %s" % (type(e).__name__, e)
         bad = torch.tensor([0 if err is None else 1], dtype=torch.int32, device="cuda" if args.backend == "nccl" else "cpu")
@@ -545,10 +556,11 @@ def main():
         stage(rank, "native exchange failed (%s); falling back to --exchange torch" % (err or "on another rank"))
         fallback.append(err or "failed on another rank")
         args.exchange = "torch"
-        return run_sharded(weak)
+        return run_sharded(weak, docs)
 
     sha = csrc_sha16()
     other = None
+    large = None
     corpus = z0 = None
     verification = None
     if sharded:
@@ -560,6 +572,21 @@ def main():
         strong_leg = r2 if weak_first else r
         if strong_leg is not None and "digests" in strong_leg:
             verification = verify_against_one_gpu(strong_leg)
+            strong_leg.pop("corpus", None)
+        # The strong split of a corpus --large-factor times the headline's: where the per-rank budget of DESIGN.md section 6
+        # puts 8 GPUs at >= 6x one (the headline corpus is 1.5 ms of work on ONE GPU: its split is bound by what does not
+        # shrink -- the Phi slice's chain and the collectives).  Timed and verified against one handle like the headline leg.
+        if world > 1 and args.large_factor > 1 and not args.no_large_leg and not args.no_verify:
+            r3 = run_sharded_or_fall_back(False, docs=args.large_factor * args.docs)
+            v3 = verify_against_one_gpu(r3)
+            r3.pop("corpus", None)
+            if rank == 0:
+                large = {"workload": "the strong split of a %dx corpus: D=%d, N=%d tokens over %d ranks" % (args.large_factor, r3["docs"], r3["tokens"], world),
+                         "value": round(r3["tokens"] * args.steps / r3["dt"] / 1e6, 3), "unit": "M tokens/s", "ms_per_step": round(r3["dt"] / args.steps * 1e3, 4),
+                         "phase_ms_per_sweep": r3["phases"], "parity_vs_one_gpu": v3["parity_vs_one_gpu"], "one_gpu_ms_per_step": v3["one_gpu_ms_per_step"],
+                         "speedup_vs_one_gpu_same_run": v3["speedup_vs_one_gpu_same_run"]}
+                if not v3["parity_vs_one_gpu"]:
+                    verification = dict(verification or {}, parity_vs_one_gpu=False, mismatches=(verification or {}).get("mismatches", []) + ["large leg: %s" % v3["mismatches"]])
         if r2 is not None:
             other = {"value": round(r2["tokens"] * args.steps / r2["dt"] / 1e6, 3), "unit": "M tokens/s",
                      "ms_per_step": round(r2["dt"] / args.steps * 1e3, 4), "phase_ms_per_sweep": r2["phases"],
@@ -621,6 +648,8 @@ def main():
                 line["parity_vs_one_gpu"] = None
         if other is not None:
             line["weak_scaling" if args.scaling == "strong" else "strong_scaling"] = other
+        if sharded and large is not None:
+            line["strong_scaling_large_corpus"] = large
         if not sharded and args.simulate_world <= 1:
             if not args.no_extra_configs and args.scheme == "ggs" and K == 100 and args.docs == 100000:
                 line["extra_configs"] = extra_configs(native, corpus, args, local_rank, fence, sha)

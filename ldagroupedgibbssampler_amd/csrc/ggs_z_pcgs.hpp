@@ -225,7 +225,11 @@ __global__ __launch_bounds__(64) void pcgs_sliced_kernel(PcgsParams p) {
 #pragma unroll
     for (int m = 0; m < 8; ++m) {
       const int row = 8 * m + lrow;
+#ifdef GGS_PCGS_ABL                                             // timing-only experiment (results wrong): every row the same one -- the kernel without its gather
+      const int wm = __shfl(w, row) & (GGS_PCGS_ABL - 1);
+#else
       const int wm = __shfl(w, row);
+#endif
       ra[m] = phib + (size_t)wm * rowbytes + (size_t)(((lslot - (row >> 1)) & 7) << 4);
     }
   };

@@ -9,7 +9,7 @@ cd $GRAFT_REPO_ROOT
 python3 bench.py --force-sharded --steps 10 --warmup 3 > $out/force_sharded.json 2> $out/force_sharded.err || { tail -20 $out/force_sharded.err; exit 1; }
 for n in ${REHEARSE_RANKS:-2 4}; do
   python3 -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port $((29600 + n)) bench.py --gpus $n --backend gloo --single-device \
-      --steps 10 --warmup 3 --no-weak-leg > $out/gloo_$n.json 2> $out/gloo_$n.err || { tail -30 $out/gloo_$n.err; exit 1; }
+      --steps 10 --warmup 3 --no-weak-leg --no-large-leg > $out/gloo_$n.json 2> $out/gloo_$n.err || { tail -30 $out/gloo_$n.err; exit 1; }
 done
 for f in $out/*.json; do echo "== $f"; python3 - $f <<'PY'
 import json, sys

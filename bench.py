@@ -361,6 +361,8 @@ def main():
                          "the native exchange then runs over its callback provider with host staging")
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (rehearsal only; the number is not a multi-GPU result)")
     ap.add_argument("--no-weak-leg", action="store_true", help="N>1: skip the second measurement (the other scaling regime)")
+    ap.add_argument("--count-exchange", default="auto", choices=["auto", "dense", "sparse"],
+                    help="N>1, native exchange: how the counts travel (auto: (cell, count) pairs where the dense buffer is large and mostly zero)")
     ap.add_argument("--large-factor", type=int, default=3,
                     help="N>1: a third leg, the strong split of a corpus this many times the headline's (0/1: none), with its own one-GPU time from the same run")
     ap.add_argument("--no-large-leg", action="store_true", help="N>1: skip that leg")
@@ -449,6 +451,8 @@ def main():
             total_docs, total_tokens = corpus.num_docs, corpus.num_tokens
             sh = ShardedGGS(h, exchange_factory(), corpus, rank, world)
             sh.set_z_global(java_lcg_initial_z(corpus.num_tokens, K, args.seed))
+        if args.exchange == "native" and args.count_exchange != "auto":
+            h.set_count_exchange(args.count_exchange)
         xinfo = h.exchange_info() if args.exchange == "native" else {"provider": "torch.distributed all-reduce", "comm_nranks": world, "comm_rank": rank, "nranks": world}
         stage(rank, "exchange attached, shard uploaded (%d documents, %d tokens), initial z / counts / Phi in place; exchange: %s"
               % (sh.local.num_docs, sh.local.num_tokens, json.dumps(xinfo)))
@@ -468,6 +472,8 @@ def main():
         stage(rank, "timed region done: %d sweeps in %.2f ms (max over ranks)" % (args.steps, dt * 1e3))
         tm = h.get_timings()
         h.check_invariants()            # with the native exchange: a collective call (gathers the corpus-wide counts)
+        if args.exchange == "native":
+            xinfo = dict(xinfo, count_exchange=h.count_exchange())     # dense reduce-scatter or (cell, count) pairs, and how many pairs the last sweep sent
         res = dict(dt=dt, phases=phases(tm), docs=total_docs, tokens=total_tokens, n_local=sh.local.num_tokens, V=corpus.num_types,
                    info=h.launch_info(), local=sh.local, exchange=xinfo)
         if not weak and not args.no_verify:
@@ -641,7 +647,7 @@ def main():
             # who carried the collectives, as the library reports it: for RCCL the rank count read back from the communicator
             x = r.get("exchange", {})
             line["exchange"] = {"provider": x.get("provider"), "rccl_nranks": x.get("comm_nranks") if x.get("provider") == "rccl" else None,
-                                "nranks": x.get("nranks"), "topic_slice_rank0": [x.get("k_begin"), x.get("k_end")]}
+                                "nranks": x.get("nranks"), "topic_slice_rank0": [x.get("k_begin"), x.get("k_end")], "count_exchange": x.get("count_exchange")}
             if verification is not None:
                 line.update({"parity_vs_one_gpu": verification["parity_vs_one_gpu"], "verification": verification})
             else:

@@ -328,6 +328,7 @@ NOT_CALLED_FROM_JAVA = {
     "ggs_attach_rccl": "section 4: one process per GPU, not the one-JVM binding",
     "ggs_check_invariants": "listed among the collective getters; the Java side keeps its own ensureConsistentTopicTypeCounts",
     "ggs_counts_device_ptr": "the round-1 exchange, described as superseded",
+    "ggs_set_count_exchange": "section 4: one process per GPU (the sparse count exchange needs a host round trip the one-JVM group calls do not make)",
 }
 
 

@@ -202,6 +202,26 @@ class TopicSliceLayout:
             out[r, :, :b - a] = m_vk[:, a:b]
         return out
 
+    def pairs(self, m_vk):
+        """The sparse form of the count exchange (ggs_set_count_exchange): for every destination rank the non-zero cells of
+        its topic slice as an int32 array of (cell, count) pairs, cell = v * Ksm + column in that rank's [V][Ksm] slice."""
+        out = []
+        for r in range(self.n):
+            a, b = self.slice_of(r)
+            v, c = np.nonzero(m_vk[:, a:b])
+            blk = np.empty(2 * v.size, np.int32)
+            blk[0::2] = v * self.Ksm + c
+            blk[1::2] = m_vk[v, a + c]
+            out.append(blk)
+        return out
+
+    def from_pairs(self, blocks):
+        """[V][Ksm]: the received (cell, count) blocks of every rank added up (a cell may come several times)."""
+        own = np.zeros(self.V * self.Ksm, np.int32)
+        for blk in blocks:
+            np.add.at(own, blk[0::2], blk[1::2])
+        return own.reshape(self.V, self.Ksm)
+
     def unpack(self, m_nvk):
         """[nranks][V][Ksm] -> [V][K]"""
         out = np.empty((self.V, self.K), m_nvk.dtype)
@@ -230,6 +250,29 @@ class GlooSliceTransport:
         out = [self.torch.empty_like(t) for _ in range(self.world)]
         self.dist.all_gather(out, t, group=self.group)
         return np.stack([o.numpy() for o in out])
+
+    def all_to_all_v(self, blocks):
+        """blocks[d] (int32, any length) goes to rank d; returns what every rank addressed to this one, in rank order.
+        The lengths travel first (an all-gather of the length matrix's row, as the library all-gathers its pair counts),
+        then point-to-point sends in a fixed order."""
+        lens = self.all_gather(np.asarray([b.size for b in blocks], np.int64))       # [src][dst]
+        got = [None] * self.world
+        got[self.rank] = np.ascontiguousarray(blocks[self.rank]).copy()
+        reqs, keep = [], []
+        for p in range(self.world):
+            if p == self.rank:
+                continue
+            if blocks[p].size:
+                t = self.torch.from_numpy(np.ascontiguousarray(blocks[p]).copy())
+                keep.append(t)
+                reqs.append(self.dist.isend(t, dst=p, group=self.group))
+            n = int(lens[p][self.rank])
+            got[p] = np.empty(n, np.int32)
+            if n:
+                reqs.append(self.dist.irecv(self.torch.from_numpy(got[p]), src=p, group=self.group))
+        for r in reqs:
+            r.wait()
+        return got
 
 
 def gloo_callback_exchange(rank, world_size, group=None):
@@ -260,7 +303,20 @@ def gloo_callback_exchange(rank, world_size, group=None):
                 return 0
             return cb
 
-        engine.attach_exchange(rank, world_size, reduce_scatter_i32, all_gather("<f8"), all_gather("<i4"))
+        def all_to_all_v_i32(send, soff, scnt, recv, roff, rcnt, stream):
+            torch.cuda.synchronize()
+            total = max(int(soff[i] + scnt[i]) for i in range(world_size))
+            mine = view(send, max(total, 1), "<i4").cpu().numpy()
+            got = tr.all_to_all_v([mine[soff[d]:soff[d] + scnt[d]] for d in range(world_size)])
+            for s_ in range(world_size):
+                if got[s_].size != rcnt[s_]:
+                    raise RuntimeError("all_to_all_v: expected %d elements from rank %d, got %d" % (rcnt[s_], s_, got[s_].size))
+                if got[s_].size:
+                    view(recv + 4 * int(roff[s_]), got[s_].size, "<i4").copy_(torch.from_numpy(got[s_]))
+            torch.cuda.synchronize()
+            return 0
+
+        engine.attach_exchange(rank, world_size, reduce_scatter_i32, all_gather("<f8"), all_gather("<i4"), all_to_all_v_i32)
         return NativeExchange()
     return factory
 

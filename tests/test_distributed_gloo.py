@@ -230,8 +230,9 @@ class OracleSlicedEngine:
     (loopOverTopics, GGS:182-198, on the batch EvenSplitTopicBatchBuilder would hand it) and the slices are
     all-gathered.  `transport` supplies reduce_scatter / all_gather of numpy arrays (gloo here)."""
 
-    def __init__(self, oracle, K, V, alpha, beta, seed, rank, world, transport, scheme="ggs"):
+    def __init__(self, oracle, K, V, alpha, beta, seed, rank, world, transport, scheme="ggs", sparse=False):
         from ldagroupedgibbssampler_amd.sharded import TopicSliceLayout
+        self.sparse = sparse
         self.o = oracle.OracleSampler(K, V, alpha, beta, seed)
         self.o.set_scheme(scheme)
         self.K, self.V, self.rank = K, V, rank
@@ -251,7 +252,10 @@ class OracleSlicedEngine:
         return h
 
     def _exchange_counts(self):
-        own = self.tr.reduce_scatter(self.lay.pack(self._local_histogram()))          # [V][Ksm]: corpus-wide counts of my topics
+        if self.sparse:       # ggs_set_count_exchange: the non-zero cells as (cell, count) pairs, all-to-all, added up on arrival
+            own = self.lay.from_pairs(self.tr.all_to_all_v(self.lay.pairs(self._local_histogram())))
+        else:
+            own = self.tr.reduce_scatter(self.lay.pack(self._local_histogram()))      # [V][Ksm]: corpus-wide counts of my topics
         self.o.set_counts(self.lay.unpack(self.tr.all_gather(own)))                  # (the product gathers these lazily)
 
     def _exchange_phi(self, initial):
@@ -299,7 +303,7 @@ class OracleSlicedEngine:
         return self.o.heldout_log_likelihood(self._test[0], self._test[1], num_particles, self._test[2])
 
 
-def _worker_sliced(rank, world, port, out_dir, scheme, K):
+def _worker_sliced(rank, world, port, out_dir, scheme, K, sparse=False):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from ldagroupedgibbssampler_amd.corpus import random_corpus
@@ -309,7 +313,7 @@ def _worker_sliced(rank, world, port, out_dir, scheme, K):
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     c = random_corpus(157, 1100, 60, seed=17, empty_every=10)          # 18 segments of 64 types: the gammas travel in two halves
-    eng = OracleSlicedEngine(O, K, c.num_types, 0.1, 0.01, 4242, rank, world, GlooSliceTransport(rank, world), scheme)
+    eng = OracleSlicedEngine(O, K, c.num_types, 0.1, 0.01, 4242, rank, world, GlooSliceTransport(rank, world), scheme, sparse)
     sh = ShardedGGS(eng, NativeExchange, c, rank, world)
     sh.set_z_global(java_lcg_initial_z(c.num_tokens, K, 77))
     sh.sweep(3)
@@ -320,12 +324,12 @@ def _worker_sliced(rank, world, port, out_dir, scheme, K):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scheme,K", [("ggs", 9), ("pcgs", 9), ("ggs", 1)])
-def test_two_rank_topic_sliced_exchange_equals_unsharded(oracle, tmp_path, scheme, K):
-    """The topic-sliced exchange (reduce-scatter of counts, per-rank Phi batch, all-gather of the unnormalised gammas in
-    two halves with the column sums behind the second, division on arrival) over gloo, two real processes:
-    bit-identical to the unsharded oracle.  K = 9 over 2 ranks has unequal slices (5, 4); K = 1 leaves rank 1
-    without a topic."""
+@pytest.mark.parametrize("scheme,K,sparse", [("ggs", 9, False), ("pcgs", 9, False), ("ggs", 1, False), ("ggs", 9, True), ("ggs", 1, True)])
+def test_two_rank_topic_sliced_exchange_equals_unsharded(oracle, tmp_path, scheme, K, sparse):
+    """The topic-sliced exchange (reduce-scatter of counts -- or, sparse, the non-zero cells as (cell, count) pairs
+    all-to-all --, per-rank Phi batch, all-gather of the unnormalised gammas in two halves with the column sums behind the
+    second, division on arrival) over gloo, two real processes: bit-identical to the unsharded oracle.  K = 9 over 2 ranks
+    has unequal slices (5, 4); K = 1 leaves rank 1 without a topic."""
     import torch.multiprocessing as mp
     from ldagroupedgibbssampler_amd.corpus import random_corpus
     from ldagroupedgibbssampler_amd.sharded import java_lcg_initial_z
@@ -334,7 +338,7 @@ def test_two_rank_topic_sliced_exchange_equals_unsharded(oracle, tmp_path, schem
     port = s.getsockname()[1]
     s.close()
     world = 2
-    mp.spawn(_worker_sliced, args=(world, port, str(tmp_path), scheme, K), nprocs=world, join=True)
+    mp.spawn(_worker_sliced, args=(world, port, str(tmp_path), scheme, K, sparse), nprocs=world, join=True)
     c = random_corpus(157, 1100, 60, seed=17, empty_every=10)
     ref = oracle.OracleSampler(K, c.num_types, 0.1, 0.01, 4242)
     ref.set_scheme(scheme)

@@ -223,7 +223,7 @@ def test_topic_sliced_exchange_between_handles(native, oracle, scheme, K, world,
     assert abs((ll_docs + out[0]["ll"][1]) - ref_ll) <= 1e-9 * abs(ref_ll)
 
 
-def _process_rank(rank, world, port, out_dir, scheme, K):
+def _process_rank(rank, world, port, out_dir, scheme, K, count_exchange="auto"):
     sys.path.insert(0, ROOT)
     import torch
     import torch.distributed as dist
@@ -235,7 +235,10 @@ def _process_rank(rank, world, port, out_dir, scheme, K):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     whole = random_corpus(200, 400, 110, seed=77, empty_every=9)
     h = native.GGSHandle(K, whole.num_types, 0.1, 0.01, 777, device_id=0, flags=native.FLAG_PCGS if scheme == "pcgs" else 0)
+    if count_exchange != "auto":
+        h.set_count_exchange(count_exchange)
     sh = ShardedGGS(h, gloo_callback_exchange(rank, world), whole, rank, world)
+    assert h.count_exchange()["sparse"] == (count_exchange == "sparse")
     sh.set_z_global(java_lcg_initial_z(whole.num_tokens, K, 5))
     sh.sweep(2)
     sh.sweep(1)
@@ -248,17 +251,18 @@ def _process_rank(rank, world, port, out_dir, scheme, K):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("scheme", ["ggs", "pcgs"])
-def test_two_processes_native_exchange_over_gloo(oracle, tmp_path, scheme):
+@pytest.mark.parametrize("scheme,count_exchange", [("ggs", "auto"), ("pcgs", "auto"), ("ggs", "sparse")])
+def test_two_processes_native_exchange_over_gloo(oracle, tmp_path, scheme, count_exchange):
     """Two real processes, each with its own HIP handle, joined by the callback exchange over gloo: what bench.py runs
-    at --gpus 2 with the RCCL provider swapped for host staging."""
+    at --gpus 2 with the RCCL provider swapped for host staging -- also with the counts travelling as (cell, count) pairs
+    (gloo point-to-point sends behind all_to_all_v_i32)."""
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     world, K = 2, 33
-    mp.spawn(_process_rank, args=(world, port, str(tmp_path), scheme, K), nprocs=world, join=True)
+    mp.spawn(_process_rank, args=(world, port, str(tmp_path), scheme, K, count_exchange), nprocs=world, join=True)
     whole = random_corpus(200, 400, 110, seed=77, empty_every=9)
     o = reference_run(oracle, whole, K, 0.1, 0.01, 777, 5, 3, scheme)
     t = random_corpus(30, 400, 60, seed=6, empty_every=5)

@@ -92,7 +92,7 @@ def measured_traffic(kernel_prefixes, workload, sha):
 SLICED_MAX_K = 160      # ggs_api.hip: the score-register z kernels up to here, the one-pass streaming kernel above
 
 
-def z_kernels(K, scheme):
+def z_kernels(K, scheme, warm_tiers=0):
     kmax = 8 * ((K + 7) // 8)
     nb = 1
     while nb * 128 < K + (K & 1):
@@ -101,7 +101,9 @@ def z_kernels(K, scheme):
         return ["pcgs_sliced_kernel<%d, true>" % kmax] if K <= 96 else ["pcgs_wave_kernel<%d, true>" % nb]
     if scheme == "pcgs":
         return ["pcgs_sliced_kernel<%d>" % kmax] if K <= 176 else ["pcgs_wave_kernel<%d, false>" % nb]
-    return ["z_sliced_kernel<%d>" % kmax, "z_hot_kernel<%d>" % kmax] if K <= SLICED_MAX_K else ["z_stream1_kernel"]
+    if K > SLICED_MAX_K:
+        return ["z_stream1_kernel"]
+    return ["z_sliced_kernel<%d>" % kmax, "z_hot_kernel<%d>" % kmax] + (["z_warm_kernel<%d>" % kmax] if warm_tiers else [])
 
 
 def row_stats(corpus, K, num_hot):
@@ -124,7 +126,7 @@ def row_stats(corpus, K, num_hot):
     }
 
 
-def roofline_block(corpus, K, scheme, n_local, z_ms, workload, sha, num_hot, z_parts=1):
+def roofline_block(corpus, K, scheme, n_local, z_ms, workload, sha, num_hot, z_parts=1, warm_tiers=0):
     """What bounds the dominant kernel (the z step), in three consistent readings:
       achieved / frac    HBM bytes per launch over the launch time against the HBM peak -- from the PMC counters when a
                          profile of this very workload and build is committed (`traffic`), else from the compulsory
@@ -139,7 +141,7 @@ def roofline_block(corpus, K, scheme, n_local, z_ms, workload, sha, num_hot, z_p
                          (K=1024: 410 MB), so the rate sits between the two: this is the memory-side limit that
                          applies, and the PMC profile's L2 hit rate says where between."""
     btok = algorithmic_bytes_per_token(K)
-    zk = z_kernels(K, scheme)
+    zk = z_kernels(K, scheme, warm_tiers)
     rs = row_stats(corpus, K, num_hot)
     traffic, src = measured_traffic(["ggs::" + k.split("<")[0] for k in zk], workload, sha)
     if traffic is not None:
@@ -330,7 +332,7 @@ def extra_configs(native, corpus2, args, local_rank, fence, sha):
         workload = workload_string(corpus.num_docs, corpus.num_types, corpus.num_tokens, K, args)
         out[tag] = {"workload": workload, "value": round(corpus.num_tokens * steps / dt / 1e6, 3), "unit": "M tokens/s", "steps": steps,
                     "ms_per_step": round(dt / steps * 1e3, 4), "phase_ms_per_sweep": ph,
-                    "roofline": roofline_block(corpus, K, "ggs", corpus.num_tokens, ph["z_ms"], workload, sha, info.get("num_hot", 0), info.get("z_parts", 1))}
+                    "roofline": roofline_block(corpus, K, "ggs", corpus.num_tokens, ph["z_ms"], workload, sha, info.get("num_hot", 0), info.get("z_parts", 1), info.get("warm_tiers", 0))}
     return out
 
 
@@ -637,10 +639,10 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": workload, "parallelism": par},
-            "roofline": roofline_block(r["local"], K, args.scheme, r["n_local"], r["phases"]["z_ms"], workload, sha, r["info"].get("num_hot", 0), r["info"].get("z_parts", 1)),
+            "roofline": roofline_block(r["local"], K, args.scheme, r["n_local"], r["phases"]["z_ms"], workload, sha, r["info"].get("num_hot", 0), r["info"].get("z_parts", 1), r["info"].get("warm_tiers", 0)),
             "phase_ms_per_sweep": r["phases"],
             # which z kernel(s) ran, and which of the two forms of the K <= 160 step the first z step's timed comparison kept
-            "z_step": {k: r["info"].get(k) for k in ("z_kernel", "z_form", "z_form_calibrated", "z_parts", "num_hot")},
+            "z_step": {k: r["info"].get(k) for k in ("z_kernel", "z_form", "z_form_calibrated", "z_parts", "num_hot", "warm_tiers", "num_warm", "warm_docs_per_chunk")},
             "build": {"csrc_sha16": sha},
         }
         if sharded:

@@ -41,7 +41,7 @@
 extern "C" {
 #endif
 
-#define GGS_ABI_VERSION 4
+#define GGS_ABI_VERSION 5
 
 typedef struct ggs_handle ggs_handle;
 
@@ -318,9 +318,14 @@ int ggs_reset_timings(ggs_handle *h);
 int ggs_check_invariants(ggs_handle *h);
 /* Launch geometry of the z kernel, for bench.py's roofline accounting. */
 int ggs_get_launch_info(ggs_handle *h, int64_t *num_chunks, int32_t *lds_bytes_z, int32_t *docs_per_block_theta);
-/* Rows of the z kernels' LDS hot-word table for the current corpus (0 for K > 192 and scheme pcgs): tokens of these
- * words read no phiT row from memory -- bench.py's cold-row byte accounting. */
+/* Words whose phiT rows the z kernels keep in LDS tables for the current corpus -- the hot-word table plus the warm
+ * tiers' tables (0 for K > 192 and scheme pcgs): tokens of these, the most frequent words of the handle's corpus, read
+ * no phiT row from memory -- bench.py's cold-row byte accounting. */
 int ggs_get_num_hot_words(ggs_handle *h, int32_t *num_hot);
+/* The warm tiers of the current corpus (z_warm_kernel: the words next in frequency after the hot table's, one LDS table
+ * per tier, their chunks drawn from up to *docs_per_chunk documents): tiers kept, their words in all (part of what
+ * ggs_get_num_hot_words reports).  All 0 where the score-register kernels do not run.  ABI version 5. */
+int ggs_get_warm_tiers(ggs_handle *h, int32_t *tiers, int32_t *warm_words, int32_t *docs_per_chunk);
 /* Launches of the z kernel per sweep for the current corpus: 1, or the number of document parts the streaming kernel's
  * step is cut into (K > 192; the next theta of a part is drawn beside the following parts) -- bench.py scales the
  * per-launch PMC counters of a profile by it. */

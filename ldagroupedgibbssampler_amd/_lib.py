@@ -13,7 +13,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.environ.get("GGS_HIP_LIB") or os.path.join(CSRC, "libggs_hip.so")   # override: kernel experiments only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ggs_hip.h")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class GGSConfig(C.Structure):
@@ -114,6 +114,7 @@ SIGNATURES = {
     "ggs_get_num_hot_words": (C.c_int, [_vp, _ip]),
     "ggs_get_z_parts": (C.c_int, [_vp, _ip]),
     "ggs_get_z_form": (C.c_int, [_vp, _ip, _ip, _ip]),
+    "ggs_get_warm_tiers": (C.c_int, [_vp, _ip, _ip, _ip]),
     "ggs_attach_exchange": (C.c_int, [_vp, C.c_int32, C.c_int32, C.POINTER(GGSExchangeOps)]),
     "ggs_rccl_unique_id": (C.c_int, [_vp]),
     "ggs_attach_rccl": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp]),

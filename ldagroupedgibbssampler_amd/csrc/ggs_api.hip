@@ -112,6 +112,15 @@ struct ggs_handle {
   bool z_split = true;                                 // GGS_DEBUG_SPLIT=0: one kernel takes cold and hot chunks in turn
   bool z_split_allowed = true, z_split_forced = false, z_split_tried = false;  // the first z step of a corpus times both forms and keeps the faster
   int32_t hot_wave_lds = 0;
+  // the warm tiers (z_warm_kernel): tables of the words next in frequency after the hot table's, chunks of up to warm_docs documents
+  int32_t warm_docs = 0, warm_wave_lds = 0, warm_cap = 0;   // LDS layout: theta rows per wave; rows a tier's table may have
+  // What a tier must bring (measured on the benchmark corpus, ggs_set_corpus): chunks at least 40 % full, at least 10 of them
+  // per resident wave, three tiers at most -- GGS_DEBUG_WARM / GGS_DEBUG_WARM_FILL / GGS_DEBUG_WARM_CPW
+  int32_t warm_tiers_max = 3, warm_min_fill_pct = 40, warm_min_chunks_per_wave = 10;
+  int32_t warm_tiers = 0, num_warm = 0, warm_rows_max = 0;  // of the current corpus: tiers kept, their words in all, the largest table
+  int64_t Cw = 0, warm_chunks_max = 0;                      // warm chunks in all, of the largest tier
+  int32_t *d_wt_pack = nullptr, *d_w_docs = nullptr, *d_warm_words = nullptr;   // d_wt_pack: four int32 per lane (ZParams::wt_pack)
+  int64_t *d_warm_meta = nullptr;
   bool overlap_theta = true;
   // K > 192: the z step is cut into parts of consecutive documents and the NEXT iteration's theta of a part is drawn
   // (side stream) while the following parts are still being sampled: the streaming z kernel waits on memory, the theta
@@ -681,6 +690,7 @@ int launch_theta(ggs_handle *h, hipStream_t stream, double *dst, int32_t iterati
   }
 const void *sliced_kernel_for(int K) { GGS_KMAX_SWITCH(z_sliced_kernel) }
 const void *hot_kernel_for(int K) { GGS_KMAX_SWITCH(z_hot_kernel) }
+const void *warm_kernel_for(int K) { GGS_KMAX_SWITCH(z_warm_kernel) }
 const void *pcgs_kernel_for(int K) { GGS_KMAX_SWITCH(pcgs_sliced_kernel) }
 const void *collapsed_kernel_for(int K) {
   switch ((K + 7) / 8) {
@@ -786,6 +796,8 @@ int launch_z(ggs_handle *h, bool force_fused = false, int64_t c0 = 0, int64_t c1
   zp.wave_lds = h->wave_lds; zp.hot_off = kSlicedWaves * h->wave_lds; zp.ring_base = h->ring_base;
   zp.cnt_send = (count && z_counts_itself(h)) ? h->d_cnt_send : nullptr;
   zp.smap = h->smap;
+  zp.wt_pack = reinterpret_cast<const int4 *>(h->d_wt_pack); zp.w_docs = h->d_w_docs; zp.warm_words = h->d_warm_words;
+  zp.warm_meta = h->d_warm_meta; zp.warm_tiers = h->warm_tiers; zp.warm_rows = h->warm_cap;
   if (!h->z_sliced) {                                  // a range of the chunk table (the one-document chunks are in document order)
     zp.chunk_start += c0; zp.chunk_doc += c0; zp.chunk_len += c0; zp.num_chunks = c1 - c0;
     if (zp.chunk_doc1) zp.chunk_doc1 += c0;
@@ -799,6 +811,15 @@ int launch_z(ggs_handle *h, bool force_fused = false, int64_t c0 = 0, int64_t c1
     void *args[] = {&zp};
     const dim3 sblock(kSlicedWaves * 64);
     auto grid_of = [&](int64_t chunks) { return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((chunks + kSlicedWaves - 1) / kSlicedWaves, (int64_t)h->num_cus))); };
+    // the warm tiers (z_warm_kernel): behind the hot chunks on their stream, or behind the one kernel of the fused form
+    ZParams wp = zp;
+    wp.wave_lds = h->warm_wave_lds; wp.hot_off = kSlicedWaves * h->warm_wave_lds;
+    void *wargs[] = {&wp};
+    auto launch_warm = [&](hipStream_t st) -> int {
+      if (h->Cw == 0) return GGS_OK;
+      HIP_TRY(h, hipLaunchKernel(warm_kernel_for(h->K), grid_of(h->warm_chunks_max), sblock, wargs, (size_t)(wp.hot_off + h->warm_rows_max * h->hot_pitch + kHotTailBytes), st));
+      return GGS_OK;
+    };
     if (h->z_split && !force_fused && h->Cs > h->Cc && h->Cc > 0) {
       // cold chunks on the main stream, hot chunks beside them (z_hot_kernel): two waves per SIMD
       ZParams hp = zp;
@@ -814,6 +835,7 @@ int launch_z(ggs_handle *h, bool force_fused = false, int64_t c0 = 0, int64_t c1
       static const int only = debug_env("GGS_DEBUG_ONLY") ? std::atoi(debug_env("GGS_DEBUG_ONLY")) : 0;   // timing experiments: 1 cold only, 2 hot only
       if (only != 2) HIP_TRY(h, hipLaunchKernel(sliced_kernel_for(h->K), grid_of(h->Cc), sblock, args, (size_t)(kSlicedWaves * h->wave_lds), h->stream));
       if (only != 1) HIP_TRY(h, hipLaunchKernel(hot_kernel_for(h->K), grid_of(h->Cs - h->Cc), sblock, hargs, (size_t)(hp.hot_off + h->num_hot * h->hot_pitch + kHotTailBytes), h->side_hot));
+      if (only != 1) { const int rc = launch_warm(h->side_hot); if (rc) return rc; }
       if (defer_join && zp.cnt_send && only == 0) {
         hipStream_t main_stream = h->stream;
         h->stream = h->side_hot;
@@ -828,6 +850,8 @@ int launch_z(ggs_handle *h, bool force_fused = false, int64_t c0 = 0, int64_t c1
     } else {
       HIP_TRY(h, hipLaunchKernel(sliced_kernel_for(h->K), grid_of(std::max(h->Cc, h->Cs - h->Cc)), sblock, args,
                                  (size_t)(kSlicedWaves * h->wave_lds + h->num_hot * h->hot_pitch), h->stream));
+      const int rc = launch_warm(h->stream);
+      if (rc) return rc;
     }
   } else if (h->z_stream && h->z_two_pass) hipLaunchKernelGGL(z_stream_kernel, grid, block, h->z_lds, h->stream, zp);
   else if (h->z_stream && h->z_regck && h->z_group == 1) hipLaunchKernelGGL((z_stream1_kernel<true, 1>), grid, block, h->z_lds, h->stream, zp);
@@ -1355,6 +1379,16 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
       if (const char *e = debug_env("GGS_DEBUG_HOT")) h->hot_cap = std::max(0, std::min(h->hot_cap, std::atoi(e)));
       h->z_lds = kSlicedWaves * h->wave_lds + h->hot_cap * h->hot_pitch;
       h->z_waves_per_cu = kSlicedWaves;
+      // the warm tiers: the same LDS beside the cold kernel's workgroup, more of it for theta rows (warm_docs per wave), the rest a table
+      h->warm_docs = warm_docs_for(kmax);
+      h->warm_wave_lds = (h->warm_docs * (ns * kSliceTopics * 8 + kWarmThetaPad) + 255) / 256 * 256;
+      h->warm_cap = ((kMaxLdsBytes - alloc_of(kSlicedWaves * h->wave_lds) - kSlicedWaves * h->warm_wave_lds) / kGranule * kGranule - kHotTailBytes) / h->hot_pitch;
+      h->warm_cap = std::max(0, std::min(255, h->warm_cap));
+      if (h->warm_cap < 16) h->warm_cap = 0;                           // the table loads and barriers of a tier want tokens to pay them
+      if (const char *e = debug_env("GGS_DEBUG_WARM")) h->warm_tiers_max = std::max(0, std::min(kWarmMaxTiers, std::atoi(e)));
+      if (const char *e = debug_env("GGS_DEBUG_WARM_ROWS")) h->warm_cap = std::max(0, std::min(h->warm_cap, std::atoi(e)));
+      if (const char *e = debug_env("GGS_DEBUG_WARM_FILL")) h->warm_min_fill_pct = std::max(1, std::min(100, std::atoi(e)));
+      if (const char *e = debug_env("GGS_DEBUG_WARM_CPW")) h->warm_min_chunks_per_wave = std::max(0, std::atoi(e));
     } else {
     int T = (kMaxLdsBytes / 6 / kGranule * kGranule - thbytes) / pitch;
     if (const char *e = debug_env("GGS_DEBUG_TILE")) T = std::atoi(e);
@@ -1412,7 +1446,8 @@ int ggs_create(const ggs_config *cfg, ggs_handle **out) {
     h->cfg_parts.theta_lds = h->theta_lds; h->cfg_parts.theta_lds_beside_z = h->theta_lds_beside_z;
   }
   if (h->z_sliced && (hipFuncSetAttribute(sliced_kernel_for(h->K), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess ||
-                      hipFuncSetAttribute(hot_kernel_for(h->K), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess))
+                      hipFuncSetAttribute(hot_kernel_for(h->K), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess ||
+                      hipFuncSetAttribute(warm_kernel_for(h->K), hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLdsBytes) != hipSuccess))
     return bail(GGS_ERR_HIP);
   const void *zk[] = {reinterpret_cast<const void *>(z_kernel<1>), reinterpret_cast<const void *>(z_kernel<2>),
                       reinterpret_cast<const void *>(z_kernel<4>), reinterpret_cast<const void *>(z_kernel<8>),
@@ -1524,7 +1559,7 @@ void ggs_destroy(ggs_handle *h) {
                   h->d_test_ptr, h->d_test_tok, h->d_test_ll, h->d_test_docs, h->d_koff, h->d_cnt_send, h->d_cnt_own, h->d_cnt_all, h->d_n_k_own,
                   h->d_heldout_spill, h->d_phi_own, h->d_phi_all0, h->d_phi_all1, h->d_mag_own, h->d_krank, h->d_kcol, h->d_lcg, h->d_chunk_doc1,
                   h->d_hseg_word, h->d_hseg_begin, h->d_hseg_end, h->d_sp_count, h->d_sp_cnt32, h->d_sp_all, h->d_sp_send, h->d_sp_recv, h->d_sp_wg_count,
-                  h->d_sp_wg_off};
+                  h->d_sp_wg_off, h->d_wt_pack, h->d_w_docs, h->d_warm_words, h->d_warm_meta};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   exchange_free(h->xg);
@@ -1613,7 +1648,7 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
   // count-kernel work items: tokens sorted by word (counting sort, stable), each word's run
   // cut into segments of at most kSegTokens entries.
   constexpr int64_t kSegTokens = 4096;
-  std::vector<int32_t> perm((size_t)N), seg_word, seg_begin, hot_words, hseg_word, hseg_begin, hseg_end;
+  std::vector<int32_t> perm((size_t)N), seg_word, seg_begin, hot_words, warm_cand, hseg_word, hseg_begin, hseg_end;
   {
     std::vector<int64_t> wptr((size_t)h->V + 1, 0);
     for (int64_t i = 0; i < N; ++i) wptr[(size_t)tokens[i] + 1]++;
@@ -1628,9 +1663,12 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
       std::vector<int32_t> order((size_t)h->V);
       for (int32_t w = 0; w < h->V; ++w) order[(size_t)w] = w;
       const size_t nh = (size_t)std::min<int32_t>(h->hot_cap, h->V);
+      // ... and, behind them, the candidates of the warm tiers (z_warm_kernel): the next warm_tiers_max x warm_cap words
+      const size_t nw = std::min<size_t>((size_t)h->V, nh + (size_t)h->warm_tiers_max * (size_t)h->warm_cap);
       auto freq = [&](int32_t w) { return wptr[(size_t)w + 1] - wptr[(size_t)w]; };
-      std::partial_sort(order.begin(), order.begin() + nh, order.end(), [&](int32_t a, int32_t b) { return freq(a) != freq(b) ? freq(a) > freq(b) : a < b; });
+      std::partial_sort(order.begin(), order.begin() + nw, order.end(), [&](int32_t a, int32_t b) { return freq(a) != freq(b) ? freq(a) > freq(b) : a < b; });
       for (size_t r = 0; r < nh && freq(order[r]) > 0; ++r) hot_words.push_back(order[r]);
+      for (size_t r = nh; r < nw && freq(order[r]) > 0; ++r) warm_cand.push_back(order[r]);
       for (int32_t w : hot_words)
         for (int64_t b = wptr[(size_t)w]; b < wptr[(size_t)w + 1]; b += kSegTokens) {
           hseg_word.push_back(w); hseg_begin.push_back((int32_t)b); hseg_end.push_back((int32_t)std::min(b + kSegTokens, wptr[(size_t)w + 1]));
@@ -1696,7 +1734,7 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
     if (P != h->z_parts) { h->part_doc.resize(2); h->part_chunk.resize(2); h->part_doc[1] = D; h->part_chunk[1] = (int64_t)cstart.size(); }
   }
   if ((rc = dev_alloc(h, &h->d_doc_ptr, (size_t)D + 1)) || (rc = dev_alloc(h, &h->d_tok, (size_t)N)) || (rc = dev_alloc(h, &h->d_z, (size_t)N)) ||
-      (rc = dev_alloc(h, &h->d_theta, (size_t)D * h->K)) || (rc = dev_alloc(h, &h->d_theta_next, (size_t)D * h->K)) || (rc = dev_alloc(h, &h->d_chunk_start, (size_t)h->C)) ||
+      (rc = dev_alloc(h, &h->d_theta, (size_t)D * h->K + 2)) || (rc = dev_alloc(h, &h->d_theta_next, (size_t)D * h->K + 2)) || (rc = dev_alloc(h, &h->d_chunk_start, (size_t)h->C)) ||
       (rc = dev_alloc(h, &h->d_chunk_doc, (size_t)h->C)) || (rc = dev_alloc(h, &h->d_chunk_len, (size_t)h->C)) ||
       (rc = dev_alloc(h, &h->d_perm, (size_t)N)) || (rc = dev_alloc(h, &h->d_inv_perm, (size_t)N)) || (rc = dev_alloc(h, &h->d_zw, (size_t)N)) || (rc = dev_alloc(h, &h->d_seg_word, (size_t)h->S)) ||
       (rc = dev_alloc(h, &h->d_seg_begin, (size_t)h->S + 1)))
@@ -1721,33 +1759,65 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
     HIP_TRY(h, hipMemcpy(h->d_hseg_end, hseg_end.data(), sizeof(int32_t) * hseg_end.size(), hipMemcpyHostToDevice));
   }
   h->Cs = h->Cc = 0;
+  h->warm_tiers = 0; h->num_warm = 0; h->Cw = 0;
   if (h->z_sliced) {
     // Chunk lists of the sliced kernel: walk the documents in order and deal every token to the open
     // cold chunk or the open hot chunk; a chunk closes at 64 tokens or when a third document would enter it.
+    // (documents are visited in order, so a token's document is always the chunk's newest: slot = documents so far - 1)
     struct Builder {
+      int maxdocs = kChunkDocs, docslots = kChunkDocs, shift = kSlotShift;   // documents a chunk may draw from; ids stored per chunk
       std::vector<int32_t> tok, idx, docs;
       int fill = 64, ndocs = 0, last = -1;
+      int64_t tokens = 0;
       void add(int32_t value, int32_t token, int32_t doc) {
-        if (fill == 64 || (doc != last && ndocs == kChunkDocs)) {
+        if (fill == 64 || (doc != last && ndocs == maxdocs)) {
           tok.resize(tok.size() + 64, 0); idx.resize(idx.size() + 64, -1);
-          docs.push_back(doc); docs.push_back(doc);
+          docs.insert(docs.end(), (size_t)docslots, doc);
           fill = 0; ndocs = 1; last = doc;
         } else if (doc != last) {
-          docs[docs.size() - 1] = doc; ndocs = 2; last = doc;
+          docs[docs.size() - (size_t)docslots + (size_t)ndocs] = doc; ++ndocs; last = doc;
         }
         const size_t at = tok.size() - 64 + (size_t)fill;
-        const int32_t slot = doc == docs[docs.size() - 2] ? 0 : 1;
-        tok[at] = value | (slot << kSlotShift); idx[at] = token;
-        ++fill;
+        tok[at] = value | ((ndocs - 1) << shift); idx[at] = token;
+        ++fill; ++tokens;
       }
+      int64_t chunks() const { return (int64_t)(tok.size() / 64); }
     } cold, hot;
     std::vector<int32_t> row_of((size_t)h->V, -1);
     for (size_t r = 0; r < hot_words.size(); ++r) row_of[(size_t)hot_words[r]] = (int32_t)r;
+    // The warm tiers: tier t = candidates [t*warm_cap, (t+1)*warm_cap).  A tier is kept while its chunks (64 lanes, up to
+    // warm_docs documents) are reasonably full -- a token in a half-empty chunk costs what two cost -- and numerous enough
+    // to pay for the tier's table load, its two barriers and the ragged end of its chunk list; tiers are kept in order: the
+    // first one that falls short ends the list, its words and all later ones stay cold.  Measured, sweep in ms with 0 / 1 /
+    // 2 / 3 / 4 tiers: the benchmark corpus (20 M tokens; 14.4, 11.7, 10.7, 9 chunks per wave) 1.517 / 1.494 / 1.490 /
+    // 1.481 / 1.492; half of it (rank 0 of 2: 7 chunks per wave in the first tier) 0.904 / 0.897 / 0.912 / 0.934; an
+    // eighth 0.379 / 0.407 / 0.408 / 0.423.
+    std::vector<Builder> warm;
+    int32_t tiers = 0;
+    if (h->warm_cap > 0 && hot_words.size() == (size_t)h->hot_cap && !warm_cand.empty()) {
+      const int32_t cand_tiers = (int32_t)((warm_cand.size() + (size_t)h->warm_cap - 1) / (size_t)h->warm_cap);
+      warm.resize((size_t)cand_tiers);
+      for (Builder &b : warm) { b.maxdocs = h->warm_docs; b.docslots = kWarmDocSlots; b.shift = kWarmSlotShift; }
+      std::vector<int32_t> warm_of((size_t)h->V, -1);
+      for (size_t r = 0; r < warm_cand.size(); ++r) warm_of[(size_t)warm_cand[r]] = (int32_t)r;
+      for (int64_t d = 0; d < D; ++d)
+        for (int64_t i = doc_ptr[d]; i < doc_ptr[d + 1]; ++i) {
+          const int32_t r = warm_of[(size_t)tokens[i]];
+          if (r >= 0) warm[(size_t)(r / h->warm_cap)].add(r % h->warm_cap, (int32_t)i, (int32_t)d);
+        }
+      const int64_t min_chunks = (int64_t)h->warm_min_chunks_per_wave * h->num_cus * kSlicedWaves;
+      while (tiers < cand_tiers && warm[(size_t)tiers].tokens > 0 && warm[(size_t)tiers].chunks() >= min_chunks &&
+             warm[(size_t)tiers].tokens * 100 >= warm[(size_t)tiers].chunks() * 64 * h->warm_min_fill_pct)
+        ++tiers;
+      warm.resize((size_t)tiers);
+      warm_cand.resize(std::min(warm_cand.size(), (size_t)tiers * (size_t)h->warm_cap));
+      for (int32_t w : warm_cand) row_of[(size_t)w] = -2;              // in a kept tier: neither cold nor hot
+    }
     for (int64_t d = 0; d < D; ++d)
       for (int64_t i = doc_ptr[d]; i < doc_ptr[d + 1]; ++i) {
         const int32_t r = row_of[(size_t)tokens[i]];
         if (r >= 0) hot.add(r, (int32_t)i, (int32_t)d);
-        else cold.add(tokens[i], (int32_t)i, (int32_t)d);
+        else if (r == -1) cold.add(tokens[i], (int32_t)i, (int32_t)d);
       }
     // Lanes of a chunk in (document, row) order: the 16 lanes one LDS pass serves then mostly read the same theta row
     // and, in hot chunks, few distinct table rows (tokens of one word share a row: a broadcast, not a bank conflict).
@@ -1763,6 +1833,7 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
     };
     sort_lanes(cold);
     sort_lanes(hot);
+    for (Builder &b : warm) sort_lanes(b);
     h->Cc = (int64_t)(cold.docs.size() / 2);
     h->Cs = h->Cc + (int64_t)(hot.docs.size() / 2);
     cold.tok.insert(cold.tok.end(), hot.tok.begin(), hot.tok.end());
@@ -1782,6 +1853,38 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
       HIP_TRY(h, hipMemcpy(h->d_c_docs, cold.docs.data(), sizeof(int32_t) * cold.docs.size(), hipMemcpyHostToDevice));
     }
     if (h->num_hot) HIP_TRY(h, hipMemcpy(h->d_hot_words, hot_words.data(), sizeof(int32_t) * hot_words.size(), hipMemcpyHostToDevice));
+    // the warm tiers' lists, tier after tier; meta = [tiers + 1] first chunk of a tier, then [tiers] rows of its table
+    h->warm_tiers = tiers; h->num_warm = (int32_t)warm_cand.size(); h->Cw = 0; h->warm_chunks_max = 0; h->warm_rows_max = 0;
+    if (tiers > 0) {
+      std::vector<int32_t> wtok, widx, wdocs, wwords((size_t)tiers * (size_t)h->warm_cap, 0);
+      std::vector<int64_t> meta((size_t)(2 * tiers + 1), 0);
+      for (int32_t t = 0; t < tiers; ++t) {
+        const Builder &b = warm[(size_t)t];
+        meta[(size_t)t] = (int64_t)(wtok.size() / 64);
+        const int32_t rows = (int32_t)std::min<size_t>((size_t)h->warm_cap, warm_cand.size() - (size_t)t * (size_t)h->warm_cap);
+        meta[(size_t)(tiers + 1 + t)] = rows;
+        h->warm_rows_max = std::max(h->warm_rows_max, rows);
+        h->warm_chunks_max = std::max(h->warm_chunks_max, b.chunks());
+        wtok.insert(wtok.end(), b.tok.begin(), b.tok.end());
+        widx.insert(widx.end(), b.idx.begin(), b.idx.end());
+        wdocs.insert(wdocs.end(), b.docs.begin(), b.docs.end());
+        for (int32_t r = 0; r < rows; ++r) wwords[(size_t)t * (size_t)h->warm_cap + (size_t)r] = warm_cand[(size_t)t * (size_t)h->warm_cap + (size_t)r];
+      }
+      meta[(size_t)tiers] = (int64_t)(wtok.size() / 64);
+      h->Cw = meta[(size_t)tiers];
+      std::vector<int32_t> wpack(4 * widx.size(), 0);
+      for (size_t j = 0; j < widx.size(); ++j) {
+        wpack[4 * j] = wtok[j]; wpack[4 * j + 1] = widx[j];
+        if (widx[j] >= 0) wpack[4 * j + 2] = inv[(size_t)widx[j]];
+      }
+      if ((rc = dev_alloc(h, &h->d_wt_pack, wpack.size())) ||
+          (rc = dev_alloc(h, &h->d_w_docs, wdocs.size())) || (rc = dev_alloc(h, &h->d_warm_words, wwords.size())) || (rc = dev_alloc(h, &h->d_warm_meta, meta.size())))
+        return rc;
+      HIP_TRY(h, hipMemcpy(h->d_wt_pack, wpack.data(), sizeof(int32_t) * wpack.size(), hipMemcpyHostToDevice));
+      HIP_TRY(h, hipMemcpy(h->d_w_docs, wdocs.data(), sizeof(int32_t) * wdocs.size(), hipMemcpyHostToDevice));
+      HIP_TRY(h, hipMemcpy(h->d_warm_words, wwords.data(), sizeof(int32_t) * wwords.size(), hipMemcpyHostToDevice));
+      HIP_TRY(h, hipMemcpy(h->d_warm_meta, meta.data(), sizeof(int64_t) * meta.size(), hipMemcpyHostToDevice));
+    }
   }
   HIP_TRY(h, hipMemset(h->d_z, 0, sizeof(int32_t) * std::max<size_t>((size_t)N, 1)));
   HIP_TRY(h, hipMemset(h->d_theta, 0, sizeof(double) * std::max<size_t>((size_t)D * h->K, 1)));
@@ -2592,7 +2695,7 @@ int ggs_check_invariants(ggs_handle *h) {
 
 int ggs_get_launch_info(ggs_handle *h, int64_t *num_chunks, int32_t *lds_bytes_z, int32_t *docs_per_block_theta) {
   if (!h) return GGS_ERR_BAD_ARG;
-  if (num_chunks) *num_chunks = h->z_sliced ? h->Cs : h->C;
+  if (num_chunks) *num_chunks = h->z_sliced ? h->Cs + h->Cw : h->C;
   if (lds_bytes_z) *lds_bytes_z = h->z_lds;
   if (docs_per_block_theta) *docs_per_block_theta = h->theta_docs_per_block;
   return GGS_OK;
@@ -2600,7 +2703,7 @@ int ggs_get_launch_info(ggs_handle *h, int64_t *num_chunks, int32_t *lds_bytes_z
 
 int ggs_get_num_hot_words(ggs_handle *h, int32_t *num_hot) {
   if (!h || !num_hot) return GGS_ERR_BAD_ARG;
-  *num_hot = (h->z_sliced && !(h->flags & GGS_FLAG_PCGS)) ? h->num_hot : 0;
+  *num_hot = (h->z_sliced && !(h->flags & GGS_FLAG_PCGS)) ? h->num_hot + h->num_warm : 0;
   return GGS_OK;
 }
 
@@ -2608,6 +2711,15 @@ int ggs_get_z_parts(ggs_handle *h, int32_t *parts) {
   if (!h || !parts) return GGS_ERR_BAD_ARG;
   const int32_t P = (int32_t)h->part_doc.size() - 1;
   *parts = (h->z_stream && h->overlap_theta && P > 1 && !(h->flags & GGS_FLAG_PCGS)) ? P : 1;
+  return GGS_OK;
+}
+
+int ggs_get_warm_tiers(ggs_handle *h, int32_t *tiers, int32_t *warm_words, int32_t *docs_per_chunk) {
+  if (!h) return GGS_ERR_BAD_ARG;
+  const bool on = h->have_corpus && h->z_sliced && !(h->flags & GGS_FLAG_PCGS);
+  if (tiers) *tiers = on ? h->warm_tiers : 0;
+  if (warm_words) *warm_words = on ? h->num_warm : 0;
+  if (docs_per_chunk) *docs_per_chunk = on && h->warm_tiers ? h->warm_docs : 0;
   return GGS_OK;
 }
 

@@ -364,6 +364,132 @@ __global__ __launch_bounds__(kSlicedWaves * 64) void z_sliced_kernel(ZParams p) 
   }
 }
 
+// The LDS table of z_hot_kernel / z_warm_kernel: `nrows` phiT rows (KMAX doubles each, plain unit order), a zeroed pad
+// unit behind each (hot_pitch) and kHotTailBytes of zeros behind the last.  A row per wave at a time, its word id a scalar
+// load, six rows in flight per wave (one row per thread-loop iteration with the id fetched by the lanes was two dependent
+// memory latencies per 16 bytes and thread: ~30 us per table).  The caller puts the barrier behind it.
+template <int KMAX>
+__device__ __forceinline__ void load_phi_table(unsigned char *table, const int pitch, const unsigned char *phib, const size_t rowbytes,
+                                               const int32_t *words_g, const int nrows, const int wave, const int lane, const int tid) {
+  constexpr int upr = KMAX / 2 + 1, kRowsAhead = 6, NP = (upr + 63) / 64;
+  const const_i32_t *words = (const const_i32_t *)words_g;
+  for (int r0 = wave; r0 < nrows; r0 += kSlicedWaves * kRowsAhead) {
+    D2 v[kRowsAhead][NP];
+#pragma unroll
+    for (int a = 0; a < kRowsAhead; ++a) {
+      const int r = r0 + kSlicedWaves * a;
+      const unsigned char *src = phib + (size_t)words[r < nrows ? r : r0] * rowbytes;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const int u = q * 64 + lane;
+        v[a][q] = u < upr - 1 ? *reinterpret_cast<const D2 *>(src + (size_t)u * 16) : D2{0.0, 0.0};
+      }
+    }
+#pragma unroll
+    for (int a = 0; a < kRowsAhead; ++a) {
+      const int r = r0 + kSlicedWaves * a;
+#pragma unroll
+      for (int q = 0; q < NP; ++q) {
+        const int u = q * 64 + lane;
+        if (r < nrows && u < upr) *reinterpret_cast<D2 *>(table + r * pitch + u * 16) = v[a][q];
+      }
+    }
+  }
+  if (tid < kHotTailBytes / 8) reinterpret_cast<double *>(table + nrows * pitch)[tid] = 0.0;
+}
+
+// One token of a hot (or warm) chunk, as z_hot_kernel's comment below describes it: phi from the table row `hrow`, theta
+// from the LDS row `trow` (both zero-padded to whole slices).  Returns the new topic.
+// UB = 16-byte units of a slice read ahead of the chain at a time: 8 (a whole slice: 64 registers of operands) in z_hot_kernel,
+// 4 in z_warm_kernel, whose next chunk's theta rows take 32 registers of the same 128.
+template <int KMAX, int UB = kSliceUnits>
+__device__ __forceinline__ int hot_token(const ZParams &p, const int K, const unsigned char *hrow, const unsigned char *trow, const int id0) {
+  constexpr int NS = (KMAX + kSliceTopics - 1) / kSliceTopics;
+  double sum = 0.0, ck[NS];
+  static_for<0, NS>([&](auto sidx) {                           // GGS:96-101
+    constexpr int s = decltype(sidx)::value;
+#pragma unroll
+    for (int b = 0; b < kSliceUnits / UB; ++b) {
+      D2 ph[UB], th[UB];
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (s * kSliceTopics + 2 * (b * UB + u) + 1 < KMAX) {
+          ph[u] = lds_d2(hrow + s * (kSliceTopics * 8) + (b * UB + u) * 16);
+          th[u] = lds_d2(trow + s * (kSliceTopics * 8) + (b * UB + u) * 16);
+        }
+#pragma unroll
+      for (int u = 0; u < UB; ++u)
+        if (s * kSliceTopics + 2 * (b * UB + u) + 1 < KMAX) {
+          sum += th[u].a * ph[u].a;
+          sum += th[u].b * ph[u].b;
+        }
+      asm volatile("" : "+v"(sum) : : "memory");               // one batch of reads in flight at a time (the register budget is 128): the chain is pinned before the next batch's reads
+    }
+    ck[s] = sum;
+  });
+  const uint64_t gtok = (uint64_t)(p.tok_base + id0);
+  const U4 o = philox4x32_10((uint32_t)gtok, (uint32_t)(gtok >> 32), (uint32_t)GGS_PURPOSE_Z << 24, p.iteration,
+                             (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
+  const double t0 = u53(o.x, o.y) * sum;                       // GGS:107-108
+  const double delta = (sum * (double)K) * 0x1p-51 * p.margin_scale;
+  // the first slice whose closing checkpoint proves the walk has stopped (d = t0 - s is monotone)
+  int gsel = NS;
+  static_for<0, NS>([&](auto sidx) {
+    constexpr int s = NS - 1 - decltype(sidx)::value;
+    if (t0 - ck[s] < -delta) gsel = s;
+  });
+  bool undecided = gsel == NS;                                 // the walk would not end inside the row, NaN, or too close to call
+  if (undecided) gsel = 0;
+  double s = 0.0;                                              // the chain as it stood when pass 1 entered the slice
+  static_for<0, NS - 1>([&](auto sidx) {
+    constexpr int q = decltype(sidx)::value;
+    if (gsel == q + 1) s = ck[q];
+  });
+  undecided |= fabs(t0 - s) <= delta;                          // d_{r-1} > delta for r at the head of the slice (t_0 > delta for r = 0)
+  int ahead = 0;                                               // topics of the slice the walk is proved to pass
+  {
+    const unsigned char *hs = hrow + gsel * (kSliceTopics * 8), *ts = trow + gsel * (kSliceTopics * 8);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                              // half a slice's reads in flight at a time
+      D2 ph[kSliceUnits / 2], th[kSliceUnits / 2];
+#pragma unroll
+      for (int u = 0; u < kSliceUnits / 2; ++u) {
+        ph[u] = lds_d2(hs + (h * (kSliceUnits / 2) + u) * 16);
+        th[u] = lds_d2(ts + (h * (kSliceUnits / 2) + u) * 16);
+      }
+#pragma unroll
+      for (int u = 0; u < kSliceUnits / 2; ++u) {
+        s += th[u].a * ph[u].a;
+        double d = t0 - s;
+        ahead += d >= -delta;
+        undecided |= fabs(d) <= delta;
+        s += th[u].b * ph[u].b;
+        d = t0 - s;
+        ahead += d >= -delta;
+        undecided |= fabs(d) <= delta;
+      }
+      asm volatile("" ::: "memory");
+    }
+  }
+  int new_topic = gsel * kSliceTopics + ahead;
+  if (undecided || ahead >= kSliceTopics || new_topic >= K) {
+    // the exact replay: GGS:108-113 element by element from the table row (rare; see ggs_z_stream.hpp)
+    const double *prow = reinterpret_cast<const double *>(hrow), *trw = reinterpret_cast<const double *>(trow);
+    double sample = t0;
+    new_topic = -1;
+    while (sample > 0.0) {
+      ++new_topic;
+      if (new_topic >= K) break;
+      sample -= trw[new_topic] * prow[new_topic];
+    }
+    if (new_topic < 0 || new_topic >= K) {                     // GGS:116-118 (and the index past K Java would throw on)
+      atomicOr(p.status, ST_INVALID_TOPIC);
+      new_topic = new_topic < 0 ? 0 : K - 1;
+    }
+  }
+  return new_topic;
+}
+
 // ------------------------------------------------------------------------------------------------
 // z_hot_kernel: the hot chunks on their own, launched on a second stream BESIDE z_sliced_kernel (which
 // then takes the cold chunks only).  A lone wave issues one VALU instruction per ~8 cycles and sits out
@@ -393,15 +519,7 @@ __global__ __launch_bounds__(kSlicedWaves * 64) __attribute__((amdgpu_waves_per_
   const const_i32_t *cdocs = (const const_i32_t *)p.c_docs;
   const int64_t stride = (int64_t)gridDim.x * kSlicedWaves;
   const int64_t C = p.num_chunks;
-  {
-    constexpr int upr = KMAX / 2 + 1;                              // a row's units and the pad unit behind it (hot_pitch), zeroed
-    for (int i = threadIdx.x; i < p.num_hot * upr; i += kSlicedWaves * 64) {
-      const int r = i / upr, u = i - r * upr;
-      *reinterpret_cast<D2 *>(smem + p.hot_off + r * p.hot_pitch + u * 16) =
-          u < upr - 1 ? *reinterpret_cast<const D2 *>(phib + (size_t)p.hot_words[r] * rowbytes + (size_t)u * 16) : D2{0.0, 0.0};
-    }
-    if (threadIdx.x < kHotTailBytes / 8) reinterpret_cast<double *>(smem + p.hot_off + p.num_hot * p.hot_pitch)[threadIdx.x] = 0.0;
-  }
+  load_phi_table<KMAX>(smem + p.hot_off, p.hot_pitch, phib, rowbytes, p.hot_words, p.num_hot, wave, lane, threadIdx.x);
   __syncthreads();
   auto load_theta = [&](const int d0, const int d1, double (&tv)[kChunkDocs][NT]) {
     const double *t0 = p.theta + (size_t)d0 * K, *t1 = p.theta + (size_t)d1 * K;
@@ -435,85 +553,7 @@ __global__ __launch_bounds__(kSlicedWaves * 64) __attribute__((amdgpu_waves_per_
     const unsigned char *trow = thb + ((unsigned)w0 >> kSlotShift) * kThetaRow;
     const unsigned char *hrow = smem + p.hot_off + (w0 & ((1 << kSlotShift) - 1)) * p.hot_pitch;
     if (id0 >= 0) {
-      double sum = 0.0, ck[NS];
-      static_for<0, NS>([&](auto sidx) {                           // GGS:96-101
-        constexpr int s = decltype(sidx)::value;
-        D2 ph[kSliceUnits], th[kSliceUnits];
-#pragma unroll
-        for (int u = 0; u < kSliceUnits; ++u)
-          if (s * kSliceTopics + 2 * u + 1 < KMAX) {
-            ph[u] = lds_d2(hrow + s * (kSliceTopics * 8) + u * 16);
-            th[u] = lds_d2(trow + s * (kSliceTopics * 8) + u * 16);
-          }
-#pragma unroll
-        for (int u = 0; u < kSliceUnits; ++u)
-          if (s * kSliceTopics + 2 * u + 1 < KMAX) {
-            sum += th[u].a * ph[u].a;
-            sum += th[u].b * ph[u].b;
-          }
-        asm volatile("" : "+v"(sum) : : "memory");                 // one slice's reads in flight at a time (the register budget is 128): the chain is pinned before the next slice's reads
-        ck[s] = sum;
-      });
-      const uint64_t gtok = (uint64_t)(p.tok_base + id0);
-      const U4 o = philox4x32_10((uint32_t)gtok, (uint32_t)(gtok >> 32), (uint32_t)GGS_PURPOSE_Z << 24, p.iteration,
-                                 (uint32_t)p.seed, (uint32_t)(p.seed >> 32));
-      const double t0 = u53(o.x, o.y) * sum;                       // GGS:107-108
-      const double delta = (sum * (double)K) * 0x1p-51 * p.margin_scale;
-      // the first slice whose closing checkpoint proves the walk has stopped (d = t0 - s is monotone)
-      int gsel = NS;
-      static_for<0, NS>([&](auto sidx) {
-        constexpr int s = NS - 1 - decltype(sidx)::value;
-        if (t0 - ck[s] < -delta) gsel = s;
-      });
-      bool undecided = gsel == NS;                                 // the walk would not end inside the row, NaN, or too close to call
-      if (undecided) gsel = 0;
-      double s = 0.0;                                              // the chain as it stood when pass 1 entered the slice
-      static_for<0, NS - 1>([&](auto sidx) {
-        constexpr int q = decltype(sidx)::value;
-        if (gsel == q + 1) s = ck[q];
-      });
-      undecided |= fabs(t0 - s) <= delta;                          // d_{r-1} > delta for r at the head of the slice (t_0 > delta for r = 0)
-      int ahead = 0;                                               // topics of the slice the walk is proved to pass
-      {
-        const unsigned char *hs = hrow + gsel * (kSliceTopics * 8), *ts = trow + gsel * (kSliceTopics * 8);
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {                              // half a slice's reads in flight at a time
-          D2 ph[kSliceUnits / 2], th[kSliceUnits / 2];
-#pragma unroll
-          for (int u = 0; u < kSliceUnits / 2; ++u) {
-            ph[u] = lds_d2(hs + (h * (kSliceUnits / 2) + u) * 16);
-            th[u] = lds_d2(ts + (h * (kSliceUnits / 2) + u) * 16);
-          }
-#pragma unroll
-          for (int u = 0; u < kSliceUnits / 2; ++u) {
-            s += th[u].a * ph[u].a;
-            double d = t0 - s;
-            ahead += d >= -delta;
-            undecided |= fabs(d) <= delta;
-            s += th[u].b * ph[u].b;
-            d = t0 - s;
-            ahead += d >= -delta;
-            undecided |= fabs(d) <= delta;
-          }
-          asm volatile("" ::: "memory");
-        }
-      }
-      int new_topic = gsel * kSliceTopics + ahead;
-      if (undecided || ahead >= kSliceTopics || new_topic >= K) {
-        // the exact replay: GGS:108-113 element by element from the table row (rare; see ggs_z_stream.hpp)
-        const double *prow = reinterpret_cast<const double *>(hrow), *trw = reinterpret_cast<const double *>(trow);
-        double sample = t0;
-        new_topic = -1;
-        while (sample > 0.0) {
-          ++new_topic;
-          if (new_topic >= K) break;
-          sample -= trw[new_topic] * prow[new_topic];
-        }
-        if (new_topic < 0 || new_topic >= K) {                     // GGS:116-118 (and the index past K Java would throw on)
-          atomicOr(p.status, ST_INVALID_TOPIC);
-          new_topic = new_topic < 0 ? 0 : K - 1;
-        }
-      }
+      const int new_topic = hot_token<KMAX>(p, K, hrow, trow, id0);
       p.z[id0] = new_topic;
       p.zw[ip0] = new_topic;
     }
@@ -524,6 +564,123 @@ __global__ __launch_bounds__(kSlicedWaves * 64) __attribute__((amdgpu_waves_per_
     for (int r = 0; r < kChunkDocs; ++r)
 #pragma unroll
       for (int t = 0; t < NT; ++t) tv0[r][t] = tv1[r][t];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// z_warm_kernel: the WARM tiers (round 4).  A token whose row sits in an LDS table costs about 0.4 of one whose row is
+// gathered (z_hot_kernel alone: 27 M tokens per ms, the cold chunks alone: 10.6), and the split z step ends when the COLD
+// kernel does (0.94 ms; the hot kernel beside it is through after 0.57) -- so the words next in frequency after the hot
+// table's get tables of their own, one after the other: tier t = the next `warm_rows` words, its table loaded by every
+// workgroup (a few us from L2), its chunks taken like hot chunks, then a barrier and the next tier.  Such words are rarer
+// per document (benchmark corpus: 12 tokens per document in the first tier after the hot table's 110, then 7, 5, ...), so
+// a warm chunk draws its 64 tokens from up to DOCS = warm_docs_for(KMAX) documents (8 up to K = 112) instead of 2: lane t
+// reads theta from its own document's LDS row, as it always did.  The theta rows of the NEXT chunk travel through
+// registers (DOCS rows x NS slices = at most 14 doubles per lane) while this chunk is sampled.  Everything else is
+// z_hot_kernel: the same hot_token(), hence the same z bit for bit whichever list a token is in.  Launched behind
+// z_hot_kernel on its stream (split form) or behind z_sliced_kernel (fused form).  With an exchange whose send buffer the
+// z kernels fill themselves (ZParams::cnt_send) a warm token adds its own cell, like a cold one.
+constexpr int kWarmMaxTiers = 8;
+constexpr int kWarmSlotShift = 16;         // warm chunk token word: table row | (which of the chunk's documents) << 16
+constexpr int kWarmDocSlots = 8;           // document ids stored per warm chunk (one 32-byte scalar load), whatever warm_docs_for() says
+// LDS pitch of a warm chunk's theta rows = whole slices + 16 bytes: the rows are a multiple of 128 bytes, so without the pad
+// lanes of different documents reading the same topics hit the same banks (measured: 54 % of the warm kernel's LDS cycles
+// were bank conflicts against the hot kernel's 38 %); with it the 16-byte reads of 8 rows at one offset touch 8 disjoint
+// groups of 4 banks.
+constexpr int kWarmThetaPad = 16;
+#ifndef GGS_WARM_UNITS
+#define GGS_WARM_UNITS 4                   // hot_token's read-ahead in z_warm_kernel (16-byte units of a slice)
+#endif
+#ifndef GGS_WARM_LANE_DOUBLES
+#define GGS_WARM_LANE_DOUBLES 16           // registers (pairs) a lane spends on the next chunk's theta rows
+#endif
+constexpr int warm_docs_for(const int kmax) {
+  const int rowd = (kmax + kSliceTopics - 1) / kSliceTopics * kSliceTopics;
+  const int d = GGS_WARM_LANE_DOUBLES / (2 * ((rowd + 127) / 128));   // a lane holds 16-byte pieces: 128 topics per piece and row
+  return d < 2 ? 2 : d > 8 ? 8 : d;
+}
+struct alignas(8) D2u { double a, b; };    // two doubles at an 8-byte aligned address (a theta row starts at d*K*8)
+
+template <int KMAX>
+__global__ __launch_bounds__(kSlicedWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void z_warm_kernel(ZParams p) {
+  constexpr int NS = (KMAX + kSliceTopics - 1) / kSliceTopics;
+  constexpr int kRowD = NS * kSliceTopics;                         // doubles of a theta row in LDS (zero-padded to whole slices)
+  constexpr int kThetaRow = kRowD * 8 + kWarmThetaPad;             // ... and the pad that spreads the rows over the banks
+  constexpr int DOCS = warm_docs_for(KMAX);
+  constexpr int NQ = (kRowD + 127) / 128;                          // 16-byte pieces per lane of a theta row
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int K = p.K;
+  unsigned char *thb = smem + wave * p.wave_lds;                   // this wave's DOCS theta rows
+  const unsigned char *phib = reinterpret_cast<const unsigned char *>(p.phiT);
+  const size_t rowbytes = (size_t)p.Kp * 8;
+  const const_i32_t *cdocs = (const const_i32_t *)p.w_docs;
+  const const_i64_t *meta = (const const_i64_t *)p.warm_meta;
+  const int64_t stride = (int64_t)gridDim.x * kSlicedWaves;
+  const int64_t wid = (int64_t)blockIdx.x * kSlicedWaves + wave;
+  // Lane l holds topics 2l, 2l + 1 (+ 128q) of each of the chunk's DOCS rows, 0.0 beyond K: one 16-byte load per row and
+  // lane from a scalar row base (the document ids stay in SGPRs).  Few and wide on purpose: beside the cold kernel every
+  // vector-memory instruction of this wave queues behind that kernel's row gather at the CU's one address unit (measured:
+  // a warm chunk with 16 eight-byte theta loads and three list loads took 20 000 cycles beside the cold kernel against
+  // 8 300 alone; the hot kernel, 7 loads per chunk, 8 200 against 5 900).  The last lane of an odd K reads 8 bytes past its
+  // row -- the next row, or the slack ggs_set_corpus leaves behind the theta buffers.
+  auto load_theta = [&](const int64_t c, D2 (&tv)[DOCS][NQ]) {
+    typedef int docs8_t __attribute__((ext_vector_type(8)));
+    const docs8_t dd = *reinterpret_cast<const __attribute__((address_space(4))) docs8_t *>(cdocs + c * kWarmDocSlots);   // one s_load_dwordx8
+#pragma unroll
+    for (int r = 0; r < DOCS; ++r) {
+      const double *tr = p.theta + (size_t)dd[r] * K;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        // unconditional (a lane past the row re-reads its head), and untouched until it is staged: a select on the loaded
+        // value here would make the wave wait for every load right behind its issue
+        const int k0 = 2 * (q * 64 + lane);
+        const D2u v = *reinterpret_cast<const D2u *>(tr + (k0 < K ? k0 : 0));
+        tv[r][q] = D2{v.a, v.b};
+      }
+    }
+  };
+
+  for (int tier = 0; tier < p.warm_tiers; ++tier) {
+    if (tier) __syncthreads();                                     // every wave is through with the previous table
+    if (!(p.ablate & 32)) load_phi_table<KMAX>(smem + p.hot_off, p.hot_pitch, phib, rowbytes, p.warm_words + (size_t)tier * p.warm_rows, (int)meta[p.warm_tiers + 1 + tier], wave, lane, threadIdx.x);
+    __syncthreads();
+    const int64_t C = meta[tier + 1];
+    int64_t c = meta[tier] + wid;
+    if (c < C) {
+      int4 e0 = p.wt_pack[c * 64 + lane];
+      D2 tv[DOCS][NQ];                                             // ONE register set: staged into LDS, then refilled for the next chunk
+      load_theta(c, tv);
+      for (;;) {
+        const bool has1 = c + stride < C;
+        const int w0 = e0.x, id0 = e0.y, ip0 = e0.z;
+#pragma unroll
+        for (int r = 0; r < DOCS; ++r)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q)
+            if (2 * (q * 64 + lane) < kRowD) {                     // 0.0 beyond K: the table's filler there is multiplied by it
+              const int k0 = 2 * (q * 64 + lane);
+              *reinterpret_cast<D2 *>(thb + r * kThetaRow + k0 * 8) = D2{k0 < K ? tv[r][q].a : 0.0, k0 + 1 < K ? tv[r][q].b : 0.0};
+            }
+        if (has1) {                                                // the next chunk's operands land during this chunk's arithmetic
+          const int64_t c1 = c + stride;
+          e0 = p.wt_pack[c1 * 64 + lane];
+          if (!(p.ablate & 16)) load_theta(c1, tv);               // (GGS_DEBUG_ABLATE, timing only: 16 one theta load per tier and wave, 32 no table loads, 64 no arithmetic)
+        }
+        const int row = w0 & ((1 << kWarmSlotShift) - 1);
+        const unsigned char *trow = thb + ((unsigned)w0 >> kWarmSlotShift) * kThetaRow;
+        const unsigned char *hrow = smem + p.hot_off + row * p.hot_pitch;
+        if (id0 >= 0) {
+          const int new_topic = (p.ablate & 64) ? (ip0 & 1) : hot_token<KMAX, GGS_WARM_UNITS>(p, K, hrow, trow, id0);
+          p.z[id0] = new_topic;
+          p.zw[ip0] = new_topic;
+          if (p.cnt_send)
+            __hip_atomic_fetch_add(&p.cnt_send[slice_cell(p.smap, new_topic, p.warm_words[(size_t)tier * p.warm_rows + row])], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (!has1) break;
+        c += stride;
+      }
+    }
   }
 }
 

@@ -310,8 +310,11 @@ class GGSHandle:
         self._chk(self._L.ggs_get_z_parts(self._h, C.byref(zp)))
         zk, zf, zc = C.c_int32(), C.c_int32(), C.c_int32()
         self._chk(self._L.ggs_get_z_form(self._h, C.byref(zk), C.byref(zf), C.byref(zc)))
+        wt, ww, wd = C.c_int32(), C.c_int32(), C.c_int32()
+        self._chk(self._L.ggs_get_warm_tiers(self._h, C.byref(wt), C.byref(ww), C.byref(wd)))
         return {"num_chunks": c.value, "lds_bytes_z": l.value, "docs_per_block_theta": b.value, "num_hot": nh.value, "z_parts": zp.value,
-                "z_kernel": Z_KERNEL_NAMES.get(zk.value, str(zk.value)), "z_form": {0: "n/a", 1: "split", 2: "fused"}.get(zf.value, str(zf.value)),
+                "warm_tiers": wt.value, "num_warm": ww.value, "warm_docs_per_chunk": wd.value,
+                "z_kernel": Z_KERNEL_NAMES.get(zk.value, str(zk.value)) + (" + z_warm_kernel (%d tiers)" % wt.value if wt.value else ""), "z_form": {0: "n/a", 1: "split", 2: "fused"}.get(zf.value, str(zf.value)),
                 "z_form_calibrated": bool(zc.value)}
 
 

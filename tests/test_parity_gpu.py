@@ -163,7 +163,8 @@ def test_wide_topic_rows_use_the_streaming_kernel(native, oracle, K):
 
 @pytest.mark.parametrize("mode,K", [(2, 33), (2, 48), (2, 100), (2, 184), (1, 192), (1, 185), (3, 48), (3, 257), (3, 1024), ("margin9", 257), ("margin9", 1024), ("margin13", 64),
                                     ("margin13", 300), ("ldsck", 300), ("ldsck", 1024), ("group2", 200), ("group4", 200), ("group4", 500), ("onerow", 200), ("onerow", 40), ("tworows", 1024), ("tworows", 600), (0, 5), (0, 100), (0, 257), ("fused", 20), ("fused", 100), ("chain", 9), ("nohot", 20), ("hot3", 100), ("queue0", 100), ("queue5", 24), ("queue5", 300),
-                                    ("split", 100), ("split", 8), ("split", 97), ("split", 184), ("hotmargin9", 100), ("hotmargin9", 184), ("hotmargin13", 20), ("hotmargin13", 104), ("hotmargin13", 113)])
+                                    ("split", 100), ("split", 8), ("split", 97), ("split", 184), ("hotmargin9", 100), ("hotmargin9", 184), ("hotmargin13", 20), ("hotmargin13", 104), ("hotmargin13", 113),
+                                    ("warm0", 100), ("warm1", 100), ("warmsparse", 100), ("warmsparse", 20), ("warmsparse", 160), ("warmsparse", 113), ("warmfused", 100), ("warmmargin13", 100)])
 def test_alternate_z_kernels_agree(native, oracle, K, mode, monkeypatch):
     """The z kernels are interchangeable: GGS_DEBUG_ZKERNEL=2 forces the (one-pass) streaming kernel below 193 topics,
     =3 its two-pass form (every row streamed twice, the walk replayed in full: the cross-check of the one-pass kernel's
@@ -176,7 +177,34 @@ def test_alternate_z_kernels_agree(native, oracle, K, mode, monkeypatch):
     the same margin argument, so GGS_DEBUG_MARGIN drives its tokens through its own exact replay;
     GGS_DEBUG_HOT caps the hot-word table (0: every chunk is a cold chunk; 3: three hot words);
     GGS_DEBUG_GAMMA_QUEUE caps the LDS queue of the gamma draws' leftovers (0 / 5 entries: the elements the straight-line
-    first try does not settle are drawn by the general loops on the spot instead of gathered into full waves)."""
+    first try does not settle are drawn by the general loops on the spot instead of gathered into full waves);
+    GGS_DEBUG_WARM caps the warm tiers of z_warm_kernel (0: none, the words behind the hot table stay cold; 1: one tier), and
+    "warmsparse" cuts the tables to 16 rows (hot: 8) and accepts tiers however empty their chunks are (GGS_DEBUG_WARM_ROWS,
+    GGS_DEBUG_WARM_FILL=1): eight tiers, most tokens of the corpus warm, chunks drawn from the full number of documents."""
+    warm_env = {"warm0": {"GGS_DEBUG_WARM": "0"}, "warm1": {"GGS_DEBUG_WARM": "1"},
+                "warmsparse": {"GGS_DEBUG_WARM": "8", "GGS_DEBUG_WARM_ROWS": "16", "GGS_DEBUG_WARM_FILL": "1", "GGS_DEBUG_HOT": "8"},
+                "warmfused": {"GGS_DEBUG_WARM_ROWS": "24", "GGS_DEBUG_WARM_FILL": "1", "GGS_DEBUG_SPLIT": "0"},
+                "warmmargin13": {"GGS_DEBUG_WARM_ROWS": "32", "GGS_DEBUG_MARGIN": "1e13", "GGS_DEBUG_SPLIT": "2", "GGS_DEBUG_HOT": "8"}}.get(mode)
+    if warm_env is not None:
+        for k, v in warm_env.items():
+            monkeypatch.setenv(k, v)
+        monkeypatch.setenv("GGS_DEBUG_WARM_CPW", "0")               # unasked, a tier wants 10 chunks per resident wave (a corpus of millions of tokens)
+        monkeypatch.setenv("GGS_DEBUG_ZKERNEL", "1")
+        c = random_corpus(150, 400, 140, seed=K + 7, empty_every=11)
+        g, o = make_pair(native, oracle, c, K, 0.1, 0.01, 70 + K, flags=native.FLAG_PARANOID, zseed=K)
+        for k in list(warm_env) + ["GGS_DEBUG_ZKERNEL", "GGS_DEBUG_WARM_CPW"]:
+            monkeypatch.delenv(k)
+        info = g.launch_info()
+        if mode == "warm0":
+            assert info["num_warm"] == 0
+        elif mode == "warmsparse":
+            assert info["warm_tiers"] == 8 and info["num_warm"] == 128
+        else:
+            assert info["warm_tiers"] >= 1 and info["num_warm"] > 0
+        g.sweep(3)
+        o.sweep(3)
+        compare_state(g, o, "z kernel mode %s K=%d" % (mode, K))
+        return
     env = {"fused": ("GGS_DEBUG_SPLIT", "0"), "chain": ("GGS_DEBUG_CHAIN", "1"), "nohot": ("GGS_DEBUG_HOT", "0"),
            "hot3": ("GGS_DEBUG_HOT", "3"), "margin9": ("GGS_DEBUG_MARGIN", "1e9"), "margin13": ("GGS_DEBUG_MARGIN", "1e13"), "ldsck": ("GGS_DEBUG_REGCK", "0"), "group2": ("GGS_DEBUG_GROUP", "2"), "group4": ("GGS_DEBUG_GROUP", "4"),
            "onerow": ("GGS_DEBUG_TWOROWS", "0"), "tworows": ("GGS_DEBUG_TWOROWS", "1"),

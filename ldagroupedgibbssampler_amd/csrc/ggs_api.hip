@@ -120,6 +120,7 @@ struct ggs_handle {
   int32_t warm_tiers = 0, num_warm = 0, warm_rows_max = 0;  // of the current corpus: tiers kept, their words in all, the largest table
   int64_t Cw = 0, warm_chunks_max = 0;                      // warm chunks in all, of the largest tier
   int32_t *d_wt_pack = nullptr, *d_w_docs = nullptr, *d_warm_words = nullptr;   // d_wt_pack: four int32 per lane (ZParams::wt_pack)
+  int32_t *d_ht_pack = nullptr, *d_h_docs = nullptr;        // the hot chunks in the same packed form (z_hot_kernel)
   int64_t *d_warm_meta = nullptr;
   bool overlap_theta = true;
   // K > 192: the z step is cut into parts of consecutive documents and the NEXT iteration's theta of a part is drawn
@@ -796,6 +797,7 @@ int launch_z(ggs_handle *h, bool force_fused = false, int64_t c0 = 0, int64_t c1
   zp.wave_lds = h->wave_lds; zp.hot_off = kSlicedWaves * h->wave_lds; zp.ring_base = h->ring_base;
   zp.cnt_send = (count && z_counts_itself(h)) ? h->d_cnt_send : nullptr;
   zp.smap = h->smap;
+  zp.ht_pack = reinterpret_cast<const int4 *>(h->d_ht_pack); zp.h_docs = h->d_h_docs;
   zp.wt_pack = reinterpret_cast<const int4 *>(h->d_wt_pack); zp.w_docs = h->d_w_docs; zp.warm_words = h->d_warm_words;
   zp.warm_meta = h->d_warm_meta; zp.warm_tiers = h->warm_tiers; zp.warm_rows = h->warm_cap;
   if (!h->z_sliced) {                                  // a range of the chunk table (the one-document chunks are in document order)
@@ -817,7 +819,23 @@ int launch_z(ggs_handle *h, bool force_fused = false, int64_t c0 = 0, int64_t c1
     void *wargs[] = {&wp};
     auto launch_warm = [&](hipStream_t st) -> int {
       if (h->Cw == 0) return GGS_OK;
+#ifdef GGS_WARM_TRACE
+      static long long *dbg = nullptr;
+      static int launches = 0;
+      if (!dbg) HIP_TRY(h, hipMalloc(&dbg, sizeof(long long) * 8 * 1024 * 4));
+      wp.dbg = dbg;
+#endif
       HIP_TRY(h, hipLaunchKernel(warm_kernel_for(h->K), grid_of(h->warm_chunks_max), sblock, wargs, (size_t)(wp.hot_off + h->warm_rows_max * h->hot_pitch + kHotTailBytes), st));
+#ifdef GGS_WARM_TRACE
+      if (++launches == 12) {                                        // a steady-state sweep: print the phase averages once
+        HIP_TRY(h, hipDeviceSynchronize());
+        std::vector<long long> v(8 * 1024);
+        HIP_TRY(h, hipMemcpy(v.data(), dbg, sizeof(long long) * v.size(), hipMemcpyDeviceToHost));
+        double a[7] = {0, 0, 0, 0, 0, 0, 0};
+        for (int w = 0; w < 1024; ++w) for (int i = 0; i < 7; ++i) a[i] += (double)v[(size_t)w * 8 + i] / 1024;
+        fprintf(stderr, "[warm trace] cycles per wave: wait %.0f stage %.0f issue %.0f arithmetic %.0f stores %.0f rest %.0f | kernel %.0f\n", a[0], a[1], a[2], a[3], a[4], a[5], a[6]);
+      }
+#endif
       return GGS_OK;
     };
     if (h->z_split && !force_fused && h->Cs > h->Cc && h->Cc > 0) {
@@ -1559,7 +1577,7 @@ void ggs_destroy(ggs_handle *h) {
                   h->d_test_ptr, h->d_test_tok, h->d_test_ll, h->d_test_docs, h->d_koff, h->d_cnt_send, h->d_cnt_own, h->d_cnt_all, h->d_n_k_own,
                   h->d_heldout_spill, h->d_phi_own, h->d_phi_all0, h->d_phi_all1, h->d_mag_own, h->d_krank, h->d_kcol, h->d_lcg, h->d_chunk_doc1,
                   h->d_hseg_word, h->d_hseg_begin, h->d_hseg_end, h->d_sp_count, h->d_sp_cnt32, h->d_sp_all, h->d_sp_send, h->d_sp_recv, h->d_sp_wg_count,
-                  h->d_sp_wg_off, h->d_wt_pack, h->d_w_docs, h->d_warm_words, h->d_warm_meta};
+                  h->d_sp_wg_off, h->d_ht_pack, h->d_h_docs, h->d_wt_pack, h->d_w_docs, h->d_warm_words, h->d_warm_meta};
   for (void *b : bufs)
     if (b) (void)hipFree(b);
   exchange_free(h->xg);
@@ -1836,6 +1854,25 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
     for (Builder &b : warm) sort_lanes(b);
     h->Cc = (int64_t)(cold.docs.size() / 2);
     h->Cs = h->Cc + (int64_t)(hot.docs.size() / 2);
+    {
+      // z_hot_kernel reads its chunks in the packed form of the warm tiers: one 16-byte entry per lane, the chunk's
+      // documents in kWarmDocSlots slots, the document slot at kWarmSlotShift
+      const size_t nh64 = hot.tok.size(), nhc = nh64 / 64;
+      std::vector<int32_t> hpack(4 * nh64, 0), hdocs(nhc * (size_t)kWarmDocSlots, 0);
+      for (size_t j = 0; j < nh64; ++j) {
+        const uint32_t t = (uint32_t)hot.tok[j];
+        hpack[4 * j] = (int32_t)((t & ((1u << kSlotShift) - 1)) | ((t >> kSlotShift) << kWarmSlotShift));
+        hpack[4 * j + 1] = hot.idx[j];
+        if (hot.idx[j] >= 0) hpack[4 * j + 2] = inv[(size_t)hot.idx[j]];
+      }
+      for (size_t c = 0; c < nhc; ++c)
+        for (int r = 0; r < kWarmDocSlots; ++r) hdocs[c * (size_t)kWarmDocSlots + (size_t)r] = hot.docs[2 * c + (size_t)std::min(r, 1)];
+      if ((rc = dev_alloc(h, &h->d_ht_pack, hpack.size())) || (rc = dev_alloc(h, &h->d_h_docs, hdocs.size()))) return rc;
+      if (nh64) {
+        HIP_TRY(h, hipMemcpy(h->d_ht_pack, hpack.data(), sizeof(int32_t) * hpack.size(), hipMemcpyHostToDevice));
+        HIP_TRY(h, hipMemcpy(h->d_h_docs, hdocs.data(), sizeof(int32_t) * hdocs.size(), hipMemcpyHostToDevice));
+      }
+    }
     cold.tok.insert(cold.tok.end(), hot.tok.begin(), hot.tok.end());
     cold.idx.insert(cold.idx.end(), hot.idx.begin(), hot.idx.end());
     cold.docs.insert(cold.docs.end(), hot.docs.begin(), hot.docs.end());

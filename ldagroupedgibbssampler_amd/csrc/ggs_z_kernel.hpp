@@ -87,12 +87,15 @@ struct ZParams {
   SliceMap smap;
   // z_warm_kernel (ggs_z_sliced.hpp): the WARM tiers -- the words next in frequency after the hot table's, a table load
   // each, their chunks drawn from up to warm_docs_for(KMAX) documents.  Chunk lists like ct_*, tier after tier.
+  const int4 *ht_pack;         // z_hot_kernel's chunks (the hot chunks of ct_*, in order) in the packed form of wt_pack
+  const int32_t *h_docs;       // ... and their documents, kWarmDocSlots per chunk (two in use)
   const int4 *wt_pack;         // per lane {row of the tier's table | (which of the chunk's documents) << kWarmSlotShift, local token
                                // index or -1, its word-sorted position, 0}: ONE 16-byte load per lane and chunk
   const int32_t *w_docs;       // [warm chunks][kWarmDocSlots] local documents, the first warm_docs_for(KMAX) in use (unused slots repeat the first)
   const int32_t *warm_words;   // [warm_tiers][warm_rows] word ids of the tables' rows
   const int64_t *warm_meta;    // [warm_tiers + 1] first chunk of a tier, then [warm_tiers] rows of its table
   int32_t warm_tiers, warm_rows;
+  long long *dbg;              // -DGGS_WARM_TRACE builds only: per wave, cycles by phase of z_warm_kernel's chunk loop
 };
 
 struct alignas(16) D2 { double a, b; };

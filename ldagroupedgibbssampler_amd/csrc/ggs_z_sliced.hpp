@@ -73,6 +73,30 @@ constexpr int kChunkDocs = 2;             // documents a chunk may draw tokens f
 constexpr int kHotTailBytes = 64;          // zeroed bytes after z_hot_kernel's table: what a lane refining the last slice reads past the last row
 constexpr int kSlotShift = 30;            // chunk token word: value | (which of the chunk's documents) << 30
 
+// ---- the warm tiers (z_warm_kernel, below)
+constexpr int kWarmMaxTiers = 8;
+constexpr int kWarmSlotShift = 16;         // warm chunk token word: table row | (which of the chunk's documents) << 16
+constexpr int kWarmDocSlots = 8;           // document ids stored per warm chunk (one 32-byte scalar load), whatever warm_docs_for() says
+// LDS pitch of a warm chunk's theta rows = whole slices + 16 bytes: the rows are a multiple of 128 bytes, so without the pad
+// lanes of different documents reading the same topics hit the same banks (measured: 54 % of the warm kernel's LDS cycles
+// were bank conflicts against the hot kernel's 38 %); with it the 16-byte reads of 8 rows at one offset touch 8 disjoint
+// groups of 4 banks.
+constexpr int kWarmThetaPad = 16;
+#ifndef GGS_WARM_UNITS
+#define GGS_WARM_UNITS 4                   // hot_token's read-ahead in z_warm_kernel (16-byte units of a slice)
+#endif
+#ifndef GGS_WARM_LANE_DOUBLES
+#define GGS_WARM_LANE_DOUBLES 12           // registers (pairs) a lane spends on the theta rows of ONE of the two chunks whose operands are in flight
+#endif
+constexpr int warm_docs_for(const int kmax) {
+  const int rowd = (kmax + kSliceTopics - 1) / kSliceTopics * kSliceTopics;
+  // a lane holds 16-byte pieces, 128 topics per piece and row; what keeps every instance of the kernel out of scratch (a
+  // register of a load in flight must never be spilled)
+  const int d = rowd <= 112 ? GGS_WARM_LANE_DOUBLES / 2 : rowd <= 128 ? GGS_WARM_LANE_DOUBLES / 2 - 1 : 2;
+  return d < 2 ? 2 : d > 8 ? 8 : d;
+}
+struct alignas(8) D2u { double a, b; };    // two doubles at an 8-byte aligned address (a theta row starts at d*K*8)
+
 template <int S, int N, class F>
 __device__ __forceinline__ void static_for(F &&f) {
   if constexpr (S < N) {
@@ -505,66 +529,138 @@ __device__ __forceinline__ int hot_token(const ZParams &p, const int K, const un
 // 64 zero bytes follow the table, so a lane refining the last slice multiplies finite bytes by 0.
 // If the two kernels happen not to share the CUs the results are the same and the hot chunks simply run
 // before or after the cold ones.
-template <int KMAX>
-__global__ __launch_bounds__(kSlicedWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void z_hot_kernel(ZParams p) {
+// The chunk loop of the two table kernels (z_hot_kernel: DOCS = 2 documents per chunk; z_warm_kernel: warm_docs_for(KMAX)).
+// Its loads run two chunks ahead and are counted by hand.  Measured (in-kernel cycle counters and kernel timelines): beside the
+// cold kernel -- whose row gather keeps the CU's vector-memory pipeline full -- a guest wave waits hundreds of cycles to
+// ISSUE each vector-memory instruction, its loads come back after ~4 us where a chunk's arithmetic takes 2-3, and the
+// compiler's wait insertion puts s_waitcnt vmcnt(0) at the head of such a loop (the z stores of the chunk before are
+// waited for as well).  Hence: few and wide loads (one 16-byte list entry per lane, one 16-byte piece per theta row and
+// lane); every load of the loop issued by inline assembly (the compiler neither sees nor waits for it), for the chunk
+// after next, into one of two register sets; and the wait in front of a set's first use counts what was issued behind
+// that set's loads and may stay in flight: the other set's kLoads loads and one chunk's two z stores (vector memory
+// operations complete in issue order on gfx9, stores included -- the assumption the compiler's own counts rest on; every
+// chunk has an active lane, so its stores are issued; anything issued beyond that, a rare replay's status atomic or the
+// count update, only makes the wait stricter).  A set's registers are handed to the compiler through empty asm statements
+// behind the wait, so no use can move above it -- and no instance of these kernels may spill (a register of a load in
+// flight must never be copied): tests/test_abi_symbols.py checks the build's resource summary.
+typedef int i3v_t __attribute__((ext_vector_type(3)));
+typedef int i4v_t __attribute__((ext_vector_type(4)));
+// The wait and, IN THE SAME asm statement, the copies of the list entry's three words into registers of their own: those
+// words outlive the set (it is refilled while the chunk is sampled), and copies the compiler makes for that reason it may
+// place anywhere behind the load statement -- in front of the wait, reading registers the load has not written yet (it
+// did: a memory access fault on the first run).  The theta registers are only masked and stored to LDS right behind the
+// wait; they go through empty asm statements there.  tests/test_abi_symbols.py reads the generated assembly of every
+// instance: outside the asm statements nothing but those masking selects may read a register an asm load writes.
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_take(const i3v_t &e, int &w, int &id, int &ip) {
+  asm volatile("s_waitcnt vmcnt(%6)\n\tv_mov_b32 %0, %3\n\tv_mov_b32 %1, %4\n\tv_mov_b32 %2, %5"
+               : "=&v"(w), "=&v"(id), "=&v"(ip) : "v"(e.x), "v"(e.y), "v"(e.z), "n"(N) : "memory");
+}
+
+// pack: per lane {table row | (which of the chunk's documents) << kWarmSlotShift, local token index or -1, its word-sorted
+// position, 0}; docs: kWarmDocSlots local documents per chunk (the first DOCS in use); chunks first + wid, + stride, ... < C.
+// count_words: null, or the word ids of the table's rows -- then every token adds its cell into p.cnt_send.
+template <int KMAX, int DOCS, int PAD, int UB>
+__device__ __forceinline__ void table_chunks(const ZParams &p, unsigned char *smem, unsigned char *thb, const int4 *pack, const int32_t *docs_g,
+                                             const int64_t first, const int64_t C, const int64_t stride, const int lane, const int32_t *count_words) {
   constexpr int NS = (KMAX + kSliceTopics - 1) / kSliceTopics;
-  constexpr int NT = (KMAX + 63) / 64;
-  constexpr int kThetaRow = NS * kSliceTopics * 8;                 // zero-padded to whole slices
-  extern __shared__ __align__(16) unsigned char smem[];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int kRowD = NS * kSliceTopics;                         // doubles of a theta row in LDS (zero-padded to whole slices)
+  constexpr int kThetaRow = kRowD * 8 + PAD;
+  constexpr int NQ = (kRowD + 127) / 128;                          // 16-byte pieces per lane of a theta row
+  constexpr int kLoads = 1 + DOCS * NQ;                            // vector loads per chunk: its list entry and its theta rows
+  constexpr int kStores = 2;                                       // ... and stores: z in document order and in word order
   const int K = p.K;
-  unsigned char *thb = smem + wave * p.wave_lds;                   // this wave's kChunkDocs theta rows
-  const unsigned char *phib = reinterpret_cast<const unsigned char *>(p.phiT);
-  const size_t rowbytes = (size_t)p.Kp * 8;
-  const const_i32_t *cdocs = (const const_i32_t *)p.c_docs;
-  const int64_t stride = (int64_t)gridDim.x * kSlicedWaves;
-  const int64_t C = p.num_chunks;
-  load_phi_table<KMAX>(smem + p.hot_off, p.hot_pitch, phib, rowbytes, p.hot_words, p.num_hot, wave, lane, threadIdx.x);
-  __syncthreads();
-  auto load_theta = [&](const int d0, const int d1, double (&tv)[kChunkDocs][NT]) {
-    const double *t0 = p.theta + (size_t)d0 * K, *t1 = p.theta + (size_t)d1 * K;
+  const const_i32_t *cdocs = (const const_i32_t *)docs_g;
+  const uint32_t loff = (uint32_t)lane * 16;
+  // Lane l holds topics 2l, 2l + 1 (+ 128q) of each of the chunk's DOCS rows: one 16-byte load per row and lane from a scalar
+  // row base (the document ids stay in SGPRs), unconditional (a lane past the row re-reads its head; the last lane of an odd K
+  // reads 8 bytes past its row -- the next row, or the slack ggs_set_corpus leaves behind the theta buffers) and masked to
+  // 0.0 beyond K when it is staged.
+  uint32_t toff[NQ];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-      tv[0][t] = (t * 64 + lane < K) ? t0[t * 64 + lane] : 0.0;
-      tv[1][t] = (t * 64 + lane < K) ? t1[t * 64 + lane] : 0.0;
+  for (int q = 0; q < NQ; ++q) { const int k0 = 2 * (q * 64 + lane); toff[q] = (uint32_t)(k0 < K ? k0 : 0) * 8; }
+  struct Set { i3v_t e; i4v_t t[DOCS][NQ]; };
+  auto issue = [&](const int64_t c, Set &S) {
+    typedef int docs8_t __attribute__((ext_vector_type(8)));
+    const docs8_t dd = *reinterpret_cast<const __attribute__((address_space(4))) docs8_t *>(cdocs + c * kWarmDocSlots);   // one s_load_dwordx8
+    const int4 *lp = pack + c * 64;
+    asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(S.e) : "v"(loff), "s"(lp) : "memory");
+#pragma unroll
+    for (int r = 0; r < DOCS; ++r) {
+      const double *tr = p.theta + (size_t)dd[r] * K;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(S.t[r][q]) : "v"(toff[q]), "s"(tr) : "memory");
     }
   };
-  int64_t c = p.num_cold + (int64_t)blockIdx.x * kSlicedWaves + wave;
-  if (c >= C) return;
-  int w0 = p.ct_tok[c * 64 + lane], id0 = p.ct_idx[c * 64 + lane], ip0 = p.ct_ip[c * 64 + lane];
-  double tv0[kChunkDocs][NT];
-  load_theta(cdocs[2 * c], cdocs[2 * c + 1], tv0);
-  for (;;) {
-    const bool has1 = c + stride < C;
-    int w1 = 0, id1 = -1, ip1 = 0;
-    double tv1[kChunkDocs][NT];
-    if (has1) {
-      const int64_t c1 = c + stride;
-      w1 = p.ct_tok[c1 * 64 + lane]; id1 = p.ct_idx[c1 * 64 + lane]; ip1 = p.ct_ip[c1 * 64 + lane];
-      load_theta(cdocs[2 * c1], cdocs[2 * c1 + 1], tv1);
-    } else {
-      load_theta(0, 0, tv1);
-    }
+  // `after`: what was issued behind this set's loads and may stay in flight -- 0 nothing known, 1 the other set's loads, 2
+  // those and the stores of the chunk sampled in between
+  auto arrive = [&](Set &S, const int after, int &w0, int &id0, int &ip0) {
+    if (after == 2) wait_vmcnt_take<kLoads + kStores>(S.e, w0, id0, ip0);
+    else if (after == 1) wait_vmcnt_take<kLoads>(S.e, w0, id0, ip0);
+    else wait_vmcnt_take<0>(S.e, w0, id0, ip0);
 #pragma unroll
-    for (int r = 0; r < kChunkDocs; ++r)
+    for (int r = 0; r < DOCS; ++r)
 #pragma unroll
-      for (int t = 0; t < NT; ++t)
-        if (t * 64 + lane < NS * kSliceTopics) reinterpret_cast<double *>(thb + r * kThetaRow)[t * 64 + lane] = tv0[r][t];
-    const unsigned char *trow = thb + ((unsigned)w0 >> kSlotShift) * kThetaRow;
-    const unsigned char *hrow = smem + p.hot_off + (w0 & ((1 << kSlotShift) - 1)) * p.hot_pitch;
+      for (int q = 0; q < NQ; ++q) asm volatile("" : "+v"(S.t[r][q]));
+  };
+  // one chunk: its operands have arrived in S; S is refilled for the chunk after next as soon as it is staged
+  auto chunk = [&](Set &S, const int64_t c, const int w0, const int id0, const int ip0) {
+#pragma unroll
+    for (int r = 0; r < DOCS; ++r)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q)
+        if (2 * (q * 64 + lane) < kRowD) {                         // 0.0 beyond K: the table's filler there is multiplied by it
+          const int k0 = 2 * (q * 64 + lane);
+          const D2 v = __builtin_bit_cast(D2, S.t[r][q]);
+          *reinterpret_cast<D2 *>(thb + r * kThetaRow + k0 * 8) = D2{k0 < K ? v.a : 0.0, k0 + 1 < K ? v.b : 0.0};
+        }
+    if (c + 2 * stride < C) issue(c + 2 * stride, S);
+    const int row = w0 & ((1 << kWarmSlotShift) - 1);
+    const unsigned char *trow = thb + ((unsigned)w0 >> kWarmSlotShift) * kThetaRow;
+    const unsigned char *hrow = smem + p.hot_off + row * p.hot_pitch;
     if (id0 >= 0) {
-      const int new_topic = hot_token<KMAX>(p, K, hrow, trow, id0);
+      const int new_topic = hot_token<KMAX, UB>(p, K, hrow, trow, id0);
       p.z[id0] = new_topic;
       p.zw[ip0] = new_topic;
+      if (count_words)
+        __hip_atomic_fetch_add(&p.cnt_send[slice_cell(p.smap, new_topic, count_words[row])], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (!has1) break;
+  };
+  int64_t c = first;
+  if (c >= C) return;
+  Set A, B;
+  issue(c, A);
+  if (c + stride < C) issue(c + stride, B);
+  int done = 0;                                                    // chunks sampled behind the loads a wait is for: 0, then steady state
+  for (;;) {
+    int w0, id0, ip0;
+    arrive(A, c + stride < C ? (done ? 2 : 1) : 0, w0, id0, ip0);
+    chunk(A, c, w0, id0, ip0);
     c += stride;
-    w0 = w1; id0 = id1; ip0 = ip1;
-#pragma unroll
-    for (int r = 0; r < kChunkDocs; ++r)
-#pragma unroll
-      for (int t = 0; t < NT; ++t) tv0[r][t] = tv1[r][t];
+    if (c >= C) break;
+    arrive(B, c + stride < C ? 2 : 0, w0, id0, ip0);
+    chunk(B, c, w0, id0, ip0);
+    c += stride;
+    if (c >= C) break;
+    done = 1;
   }
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(kSlicedWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void z_hot_kernel(ZParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  // Raised priority (round 4): beside the cold kernel each vector-memory instruction of a guest wave waited ~800 cycles to be
+  // ISSUED (in-kernel cycle counters: a third of z_warm_kernel's time went into issuing 7 loads per chunk, a tenth into its 2
+  // stores); with priority over the cold waves at the arbiter it is ~350 (z_warm_kernel 641 000 -> 451 000 cycles per wave;
+  // z step 0.92 -> 0.875 ms with both guests raised).  The cold kernel loses nothing it can use: it waits for its rows.
+  __builtin_amdgcn_s_setprio(3);
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned char *thb = smem + wave * p.wave_lds;                   // this wave's kChunkDocs theta rows
+  load_phi_table<KMAX>(smem + p.hot_off, p.hot_pitch, reinterpret_cast<const unsigned char *>(p.phiT), (size_t)p.Kp * 8, p.hot_words, p.num_hot, wave, lane, threadIdx.x);
+  __syncthreads();
+  // (from 129 topics on a theta row is two pieces per lane: half a slice of operands read ahead, like z_warm_kernel, keeps the kernel out of scratch)
+  table_chunks<KMAX, kChunkDocs, 0, (KMAX <= 128 ? kSliceUnits : kSliceUnits / 2)>(p, smem, thb, p.ht_pack, p.h_docs, (int64_t)blockIdx.x * kSlicedWaves + wave, p.num_chunks - p.num_cold,
+                                                 (int64_t)gridDim.x * kSlicedWaves, lane, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -580,107 +676,23 @@ __global__ __launch_bounds__(kSlicedWaves * 64) __attribute__((amdgpu_waves_per_
 // z_hot_kernel: the same hot_token(), hence the same z bit for bit whichever list a token is in.  Launched behind
 // z_hot_kernel on its stream (split form) or behind z_sliced_kernel (fused form).  With an exchange whose send buffer the
 // z kernels fill themselves (ZParams::cnt_send) a warm token adds its own cell, like a cold one.
-constexpr int kWarmMaxTiers = 8;
-constexpr int kWarmSlotShift = 16;         // warm chunk token word: table row | (which of the chunk's documents) << 16
-constexpr int kWarmDocSlots = 8;           // document ids stored per warm chunk (one 32-byte scalar load), whatever warm_docs_for() says
-// LDS pitch of a warm chunk's theta rows = whole slices + 16 bytes: the rows are a multiple of 128 bytes, so without the pad
-// lanes of different documents reading the same topics hit the same banks (measured: 54 % of the warm kernel's LDS cycles
-// were bank conflicts against the hot kernel's 38 %); with it the 16-byte reads of 8 rows at one offset touch 8 disjoint
-// groups of 4 banks.
-constexpr int kWarmThetaPad = 16;
-#ifndef GGS_WARM_UNITS
-#define GGS_WARM_UNITS 4                   // hot_token's read-ahead in z_warm_kernel (16-byte units of a slice)
-#endif
-#ifndef GGS_WARM_LANE_DOUBLES
-#define GGS_WARM_LANE_DOUBLES 16           // registers (pairs) a lane spends on the next chunk's theta rows
-#endif
-constexpr int warm_docs_for(const int kmax) {
-  const int rowd = (kmax + kSliceTopics - 1) / kSliceTopics * kSliceTopics;
-  const int d = GGS_WARM_LANE_DOUBLES / (2 * ((rowd + 127) / 128));   // a lane holds 16-byte pieces: 128 topics per piece and row
-  return d < 2 ? 2 : d > 8 ? 8 : d;
-}
-struct alignas(8) D2u { double a, b; };    // two doubles at an 8-byte aligned address (a theta row starts at d*K*8)
 
 template <int KMAX>
 __global__ __launch_bounds__(kSlicedWaves * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) void z_warm_kernel(ZParams p) {
-  constexpr int NS = (KMAX + kSliceTopics - 1) / kSliceTopics;
-  constexpr int kRowD = NS * kSliceTopics;                         // doubles of a theta row in LDS (zero-padded to whole slices)
-  constexpr int kThetaRow = kRowD * 8 + kWarmThetaPad;             // ... and the pad that spreads the rows over the banks
-  constexpr int DOCS = warm_docs_for(KMAX);
-  constexpr int NQ = (kRowD + 127) / 128;                          // 16-byte pieces per lane of a theta row
   extern __shared__ __align__(16) unsigned char smem[];
+  __builtin_amdgcn_s_setprio(3);                                   // a guest beside the cold kernel: see z_hot_kernel
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int K = p.K;
   unsigned char *thb = smem + wave * p.wave_lds;                   // this wave's DOCS theta rows
-  const unsigned char *phib = reinterpret_cast<const unsigned char *>(p.phiT);
-  const size_t rowbytes = (size_t)p.Kp * 8;
-  const const_i32_t *cdocs = (const const_i32_t *)p.w_docs;
   const const_i64_t *meta = (const const_i64_t *)p.warm_meta;
   const int64_t stride = (int64_t)gridDim.x * kSlicedWaves;
   const int64_t wid = (int64_t)blockIdx.x * kSlicedWaves + wave;
-  // Lane l holds topics 2l, 2l + 1 (+ 128q) of each of the chunk's DOCS rows, 0.0 beyond K: one 16-byte load per row and
-  // lane from a scalar row base (the document ids stay in SGPRs).  Few and wide on purpose: beside the cold kernel every
-  // vector-memory instruction of this wave queues behind that kernel's row gather at the CU's one address unit (measured:
-  // a warm chunk with 16 eight-byte theta loads and three list loads took 20 000 cycles beside the cold kernel against
-  // 8 300 alone; the hot kernel, 7 loads per chunk, 8 200 against 5 900).  The last lane of an odd K reads 8 bytes past its
-  // row -- the next row, or the slack ggs_set_corpus leaves behind the theta buffers.
-  auto load_theta = [&](const int64_t c, D2 (&tv)[DOCS][NQ]) {
-    typedef int docs8_t __attribute__((ext_vector_type(8)));
-    const docs8_t dd = *reinterpret_cast<const __attribute__((address_space(4))) docs8_t *>(cdocs + c * kWarmDocSlots);   // one s_load_dwordx8
-#pragma unroll
-    for (int r = 0; r < DOCS; ++r) {
-      const double *tr = p.theta + (size_t)dd[r] * K;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        // unconditional (a lane past the row re-reads its head), and untouched until it is staged: a select on the loaded
-        // value here would make the wave wait for every load right behind its issue
-        const int k0 = 2 * (q * 64 + lane);
-        const D2u v = *reinterpret_cast<const D2u *>(tr + (k0 < K ? k0 : 0));
-        tv[r][q] = D2{v.a, v.b};
-      }
-    }
-  };
-
   for (int tier = 0; tier < p.warm_tiers; ++tier) {
     if (tier) __syncthreads();                                     // every wave is through with the previous table
-    if (!(p.ablate & 32)) load_phi_table<KMAX>(smem + p.hot_off, p.hot_pitch, phib, rowbytes, p.warm_words + (size_t)tier * p.warm_rows, (int)meta[p.warm_tiers + 1 + tier], wave, lane, threadIdx.x);
-    __syncthreads();
-    const int64_t C = meta[tier + 1];
-    int64_t c = meta[tier] + wid;
-    if (c < C) {
-      int4 e0 = p.wt_pack[c * 64 + lane];
-      D2 tv[DOCS][NQ];                                             // ONE register set: staged into LDS, then refilled for the next chunk
-      load_theta(c, tv);
-      for (;;) {
-        const bool has1 = c + stride < C;
-        const int w0 = e0.x, id0 = e0.y, ip0 = e0.z;
-#pragma unroll
-        for (int r = 0; r < DOCS; ++r)
-#pragma unroll
-          for (int q = 0; q < NQ; ++q)
-            if (2 * (q * 64 + lane) < kRowD) {                     // 0.0 beyond K: the table's filler there is multiplied by it
-              const int k0 = 2 * (q * 64 + lane);
-              *reinterpret_cast<D2 *>(thb + r * kThetaRow + k0 * 8) = D2{k0 < K ? tv[r][q].a : 0.0, k0 + 1 < K ? tv[r][q].b : 0.0};
-            }
-        if (has1) {                                                // the next chunk's operands land during this chunk's arithmetic
-          const int64_t c1 = c + stride;
-          e0 = p.wt_pack[c1 * 64 + lane];
-          if (!(p.ablate & 16)) load_theta(c1, tv);               // (GGS_DEBUG_ABLATE, timing only: 16 one theta load per tier and wave, 32 no table loads, 64 no arithmetic)
-        }
-        const int row = w0 & ((1 << kWarmSlotShift) - 1);
-        const unsigned char *trow = thb + ((unsigned)w0 >> kWarmSlotShift) * kThetaRow;
-        const unsigned char *hrow = smem + p.hot_off + row * p.hot_pitch;
-        if (id0 >= 0) {
-          const int new_topic = (p.ablate & 64) ? (ip0 & 1) : hot_token<KMAX, GGS_WARM_UNITS>(p, K, hrow, trow, id0);
-          p.z[id0] = new_topic;
-          p.zw[ip0] = new_topic;
-          if (p.cnt_send)
-            __hip_atomic_fetch_add(&p.cnt_send[slice_cell(p.smap, new_topic, p.warm_words[(size_t)tier * p.warm_rows + row])], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        if (!has1) break;
-        c += stride;
-      }
-    }
+    const int32_t *words = p.warm_words + (size_t)tier * p.warm_rows;
+    load_phi_table<KMAX>(smem + p.hot_off, p.hot_pitch, reinterpret_cast<const unsigned char *>(p.phiT), (size_t)p.Kp * 8, words, (int)meta[p.warm_tiers + 1 + tier], wave, lane, threadIdx.x);
+    __syncthreads();                                               // (also: nothing of this wave's is in flight here -- the table's loads have been waited for)
+    table_chunks<KMAX, warm_docs_for(KMAX), kWarmThetaPad, GGS_WARM_UNITS>(p, smem, thb, p.wt_pack, p.w_docs, meta[tier] + wid, meta[tier + 1], stride, lane,
+                                                                          p.cnt_send ? words : nullptr);
   }
 }
 

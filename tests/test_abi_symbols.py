@@ -88,3 +88,28 @@ def test_host_side_java_lcg_utility(oracle):
     for K in (2, 3, 16, 100, 1000):
         assert np.array_equal(java_lcg_initial_z(50000, K, 2019), oracle.jrandom_ints(2019, K, 50000))
     assert np.array_equal(java_lcg_initial_z(1000, 7, -5), oracle.jrandom_ints(-5, 7, 1000))
+
+
+def test_table_kernels_never_spill():
+    """z_hot_kernel and z_warm_kernel keep the operands of the chunk after next in registers that inline-assembly loads fill
+    behind the compiler's back (ggs_z_sliced.hpp, table_chunks): a register of a load in flight must never be copied, so no
+    instance of these kernels may use scratch, and each must fit the 128 registers a guest beside the cold kernel gets.
+    Checked on the summary the build writes (csrc/ggs_resource_summary.txt: always the figures of the library that is loaded)."""
+    from ldagroupedgibbssampler_amd import _lib
+    _lib.build()
+    rows = [l.split() for l in open(os.path.join(_lib.CSRC, "ggs_resource_summary.txt")) if l.startswith("ggs::z_hot_kernel") or l.startswith("ggs::z_warm_kernel")]
+    assert len(rows) == 48, "one instance per KMAX = 8 ... 192 of each kernel"
+    for name, vgprs, agprs, sgprs, scratch, occ, lds in rows:
+        assert int(scratch) == 0, "%s spills %s bytes per lane" % (name, scratch)
+        assert int(vgprs) + int(agprs) <= 128 and int(occ) >= 4, "%s: %s + %s registers" % (name, vgprs, agprs)
+
+
+def test_table_kernels_hand_counted_loads_are_left_alone():
+    """scripts/check_table_kernels_asm.py: compiles every instance of z_hot_kernel / z_warm_kernel to assembly and checks that
+    between an inline-assembly load and its wait nothing the compiler generated reads or writes the load's registers (the
+    first build that took the list entry's words outside the wait statement copied them in front of it and faulted)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "check_table_kernels_asm.py")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "48 kernels checked, 0 complaints" in r.stdout

@@ -114,9 +114,9 @@ struct ggs_handle {
   int32_t hot_wave_lds = 0;
   // the warm tiers (z_warm_kernel): tables of the words next in frequency after the hot table's, chunks of up to warm_docs documents
   int32_t warm_docs = 0, warm_wave_lds = 0, warm_cap = 0;   // LDS layout: theta rows per wave; rows a tier's table may have
-  // What a tier must bring (measured on the benchmark corpus, ggs_set_corpus): chunks at least 40 % full, at least 10 of them
-  // per resident wave, three tiers at most -- GGS_DEBUG_WARM / GGS_DEBUG_WARM_FILL / GGS_DEBUG_WARM_CPW
-  int32_t warm_tiers_max = 3, warm_min_fill_pct = 40, warm_min_chunks_per_wave = 10;
+  // What a tier must bring (measured on the benchmark corpus and its halves, ggs_set_corpus): chunks at least 40 % full, at
+  // least 3 of them per resident wave, three tiers at most -- GGS_DEBUG_WARM / GGS_DEBUG_WARM_FILL / GGS_DEBUG_WARM_CPW
+  int32_t warm_tiers_max = 3, warm_min_fill_pct = 40, warm_min_chunks_per_wave = 3;
   int32_t warm_tiers = 0, num_warm = 0, warm_rows_max = 0;  // of the current corpus: tiers kept, their words in all, the largest table
   int64_t Cw = 0, warm_chunks_max = 0;                      // warm chunks in all, of the largest tier
   int32_t *d_wt_pack = nullptr, *d_w_docs = nullptr, *d_warm_words = nullptr;   // d_wt_pack: four int32 per lane (ZParams::wt_pack)
@@ -1806,10 +1806,12 @@ int ggs_set_corpus(ggs_handle *h, int64_t D, const int64_t *doc_ptr, const int32
     // The warm tiers: tier t = candidates [t*warm_cap, (t+1)*warm_cap).  A tier is kept while its chunks (64 lanes, up to
     // warm_docs documents) are reasonably full -- a token in a half-empty chunk costs what two cost -- and numerous enough
     // to pay for the tier's table load, its two barriers and the ragged end of its chunk list; tiers are kept in order: the
-    // first one that falls short ends the list, its words and all later ones stay cold.  Measured, sweep in ms with 0 / 1 /
-    // 2 / 3 / 4 tiers: the benchmark corpus (20 M tokens; 14.4, 11.7, 10.7, 9 chunks per wave) 1.517 / 1.494 / 1.490 /
-    // 1.481 / 1.492; half of it (rank 0 of 2: 7 chunks per wave in the first tier) 0.904 / 0.897 / 0.912 / 0.934; an
-    // eighth 0.379 / 0.407 / 0.408 / 0.423.
+    // first one that falls short ends the list, its words and all later ones stay cold.  Measured with the table kernels'
+    // hand-counted loads (profiles/r04_warm_tier_sweep.txt; before them a tier wanted 10 chunks per wave), sweep in ms with
+    // 0 / 1 / 2 / 3 tiers: the benchmark corpus (20 M tokens; 14.4, 11.7, 10.7 chunks per wave) 1.517 / 1.494 / 1.461 /
+    // 1.471 (4, 5, 6 tiers: 1.464 / 1.471 / 1.472, 8: 1.513); half of it (rank 0 of 2: 7 chunks per wave in the first tier)
+    // 0.887 / 0.873 / 0.870 / 0.864; a quarter 0.552 / 0.547 / 0.543 / 0.545; an eighth (under 2 chunks per wave) 0.376 /
+    // 0.378 / 0.380 / 0.394 -- there a tier's table load and barriers cost what its tokens save.
     std::vector<Builder> warm;
     int32_t tiers = 0;
     if (h->warm_cap > 0 && hot_words.size() == (size_t)h->hot_cap && !warm_cand.empty()) {

@@ -670,7 +670,7 @@ __global__ __launch_bounds__(kSlicedWaves * 64) __attribute__((amdgpu_waves_per_
 // table's get tables of their own, one after the other: tier t = the next `warm_rows` words, its table loaded by every
 // workgroup (a few us from L2), its chunks taken like hot chunks, then a barrier and the next tier.  Such words are rarer
 // per document (benchmark corpus: 12 tokens per document in the first tier after the hot table's 110, then 7, 5, ...), so
-// a warm chunk draws its 64 tokens from up to DOCS = warm_docs_for(KMAX) documents (8 up to K = 112) instead of 2: lane t
+// a warm chunk draws its 64 tokens from up to DOCS = warm_docs_for(KMAX) documents (6 up to K = 112) instead of 2: lane t
 // reads theta from its own document's LDS row, as it always did.  The theta rows of the NEXT chunk travel through
 // registers (DOCS rows x NS slices = at most 14 doubles per lane) while this chunk is sampled.  Everything else is
 // z_hot_kernel: the same hot_token(), hence the same z bit for bit whichever list a token is in.  Launched behind

@@ -223,6 +223,16 @@ def test_topic_sliced_exchange_between_handles(native, oracle, scheme, K, world,
     assert abs((ll_docs + out[0]["ll"][1]) - ref_ll) <= 1e-9 * abs(ref_ll)
 
 
+@pytest.mark.parametrize("K,world,V,zcounts", [(100, 3, 2100, "2"), (37, 2, 900, "0")])
+def test_topic_sliced_exchange_with_warm_tiers(native, oracle, monkeypatch, K, world, V, zcounts):
+    """The same with the warm tiers forced onto the small shards (every handle of the process reads the knobs in
+    ggs_set_corpus): what a rank of 2 or 4 of the benchmark corpus runs by itself."""
+    for k, v in WARM_TIERS_ON_A_SMALL_CORPUS.items():
+        monkeypatch.setenv(k, v)
+    monkeypatch.setenv("GGS_DEBUG_ZCOUNTS", zcounts)
+    test_topic_sliced_exchange_between_handles(native, oracle, "ggs", K, world, 310, V)
+
+
 def _process_rank(rank, world, port, out_dir, scheme, K, count_exchange="auto"):
     sys.path.insert(0, ROOT)
     import torch
@@ -544,14 +554,22 @@ def test_sparse_count_exchange_through_rccl_with_one_rank(native, oracle):
     h.close()
 
 
-@pytest.mark.parametrize("zcounts,every", [("0", "1"), ("2", "1"), ("2", "3"), ("0", "4")])
-def test_who_counts_and_how_often_the_phases_are_timed(native, oracle, monkeypatch, zcounts, every):
+WARM_TIERS_ON_A_SMALL_CORPUS = {"GGS_DEBUG": "1", "GGS_DEBUG_WARM": "8", "GGS_DEBUG_WARM_ROWS": "16", "GGS_DEBUG_WARM_FILL": "1", "GGS_DEBUG_WARM_CPW": "0",
+                               "GGS_DEBUG_HOT": "8"}
+
+
+@pytest.mark.parametrize("zcounts,every,warm", [("0", "1", False), ("2", "1", False), ("2", "3", False), ("0", "4", False), ("2", "1", True), ("0", "3", True)])
+def test_who_counts_and_how_often_the_phases_are_timed(native, oracle, monkeypatch, zcounts, every, warm):
     """With an exchange the score-register z kernels add the cold tokens' (word, topic) cells into the send buffer themselves
     and only the hot words' segments go through count_sorted_kernel (GGS_DEBUG_ZCOUNTS=2: whatever the corpus; =0: the count
     kernel alone, the cross-check); and only one sweep in GGS_DEBUG_TIMING_EVERY records every phase event.  Same bits, and
-    the timers still add up."""
+    the timers still add up.  `warm`: with warm tiers (z_warm_kernel; a rank of two or four of the benchmark corpus keeps
+    them) -- a warm token adds its own cell like a cold one."""
     monkeypatch.setenv("GGS_DEBUG_ZCOUNTS", zcounts)
     monkeypatch.setenv("GGS_DEBUG_TIMING_EVERY", every)
+    if warm:
+        for k, v in WARM_TIERS_ON_A_SMALL_CORPUS.items():
+            monkeypatch.setenv(k, v)
     c = random_corpus(260, 1300, 150, seed=41, empty_every=8)
     K = 37
     h = native.GGSHandle(K, c.num_types, 0.1, 0.01, 77, flags=native.FLAG_PARANOID)
@@ -567,6 +585,8 @@ def test_who_counts_and_how_often_the_phases_are_timed(native, oracle, monkeypat
     assert_bit_equal(h.get_type_topic_counts(), o.get_type_topic_counts(), "n_wk")
     assert_bit_equal(h.get_phi(), o.get_phi(), "phi")
     assert_bit_equal(h.get_theta(), o.get_theta(), "theta")
+    if warm:
+        assert h.launch_info()["warm_tiers"] >= 2
     t = h.get_timings()
     assert t["sweeps"] == 9 and t["z_ms"] > 0 and t["phi_ms"] > 0 and t["exchange_ms"] > 0
     assert abs(t["exchange_ms"] - (t["exchange_rs_ms"] + t["exchange_ag_ms"])) <= 1e-6 * max(t["exchange_ms"], 1.0)

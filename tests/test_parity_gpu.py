@@ -188,7 +188,7 @@ def test_alternate_z_kernels_agree(native, oracle, K, mode, monkeypatch):
     if warm_env is not None:
         for k, v in warm_env.items():
             monkeypatch.setenv(k, v)
-        monkeypatch.setenv("GGS_DEBUG_WARM_CPW", "0")               # unasked, a tier wants 10 chunks per resident wave (a corpus of millions of tokens)
+        monkeypatch.setenv("GGS_DEBUG_WARM_CPW", "0")               # unasked, a tier wants 3 chunks per resident wave (a corpus of millions of tokens)
         monkeypatch.setenv("GGS_DEBUG_ZKERNEL", "1")
         c = random_corpus(150, 400, 140, seed=K + 7, empty_every=11)
         g, o = make_pair(native, oracle, c, K, 0.1, 0.01, 70 + K, flags=native.FLAG_PARANOID, zseed=K)

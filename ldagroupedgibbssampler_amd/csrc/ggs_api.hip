@@ -1082,6 +1082,25 @@ int z_phase(ggs_handle *h) {
     if (counting) { h->z_counted = true; h->cnt_send_zeroed = false; h->counted_sparse = false; }
     HIP_TRY(h, hipEventRecord(E.e[2], h->stream));      // the cold kernel's end; the hot chunks' stream is joined below, and by the theta draw's stream
     h->chain_on_side = h->chain_on_side && ahead;
+    // TIMING EXPERIMENT (GGS_DEBUG_THETA_TAIL_PCT=p; results are WRONG on purpose): the table kernels' stream ends ~0.2 ms
+    // before the cold kernel does, and their LDS is free from then on.  What would the next theta of the first p % of the
+    // documents cost and save if it ran THERE (behind z_warm_kernel, beside the cold kernel's tail), the rest behind the z
+    // step as always?  Drawn from the z the cold kernel is still writing -- the real thing needs the z step cut into two
+    // document parts whose first is complete by then.  DESIGN.md section 5 has the numbers.
+    static const int theta_tail_pct = debug_env("GGS_DEBUG_THETA_TAIL_PCT") ? std::max(0, std::min(100, std::atoi(debug_env("GGS_DEBUG_THETA_TAIL_PCT")))) : 0;
+    static hipEvent_t ev_theta_tail = nullptr;
+    int64_t d_tail = 0;
+    if (theta_tail_pct && ahead && !early && !h->xg && h->z_sliced && h->z_split && h->chain_on_side && h->side_hot) {
+      if (!ev_theta_tail) HIP_TRY(h, hipEventCreateWithFlags(&ev_theta_tail, hipEventDisableTiming));
+      d_tail = h->D * theta_tail_pct / 100;
+      // GGS_DEBUG_THETA_TAIL_STREAM=1: on a stream of its own behind the table kernels (the count + Phi chain, which runs on
+      // their stream, then starts when the cold kernel ends and not behind this draw)
+      static const bool own = debug_env("GGS_DEBUG_THETA_TAIL_STREAM") && std::atoi(debug_env("GGS_DEBUG_THETA_TAIL_STREAM")) == 1;
+      hipStream_t tail_on = own ? h->side : h->side_hot;
+      if (own) HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_hot_join, 0));
+      if ((rc = launch_theta(h, tail_on, h->d_theta_next, h->iteration + 1, 0, d_tail, h->theta_lds_main, h->theta_b_main))) return rc;
+      HIP_TRY(h, hipEventRecord(ev_theta_tail, tail_on));
+    }
     if (ahead && !early) {
       // theta of iteration t+1 from the z just drawn, concurrent with the counts and the Phi draw
       Events &N = h->evs[(h->ev_head + 1) % kEvRing];
@@ -1090,7 +1109,8 @@ int z_phase(ggs_handle *h) {
       if (h->hot_join_pending) HIP_TRY(h, hipStreamWaitEvent(ts, h->ev_hot_join, 0));   // the theta draw reads the hot chunks' z as well
       N.theta_on_main = h->chain_on_side;
       if (!h->chain_on_side) HIP_TRY(h, hipEventRecord(N.th0, ts));
-      if ((rc = launch_theta(h, ts, h->d_theta_next, h->iteration + 1, 0, -1, h->chain_on_side ? h->theta_lds_main : 0, h->chain_on_side ? h->theta_b_main : 0))) return rc;
+      if ((rc = launch_theta(h, ts, h->d_theta_next, h->iteration + 1, d_tail, -1, h->chain_on_side ? h->theta_lds_main : 0, h->chain_on_side ? h->theta_b_main : 0))) return rc;
+      if (d_tail) HIP_TRY(h, hipStreamWaitEvent(ts, ev_theta_tail, 0));
       HIP_TRY(h, hipEventRecord(N.th1, ts));
       h->theta_ahead_iter = (int64_t)h->iteration + 1;
     }

@@ -32,6 +32,10 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+# the pool's host driver only supports dmabuf IPC: without this RCCL's buffer exchange between the ranks' processes fails
+# (hipIpcGetMemHandle: invalid argument).  Exported on the boxes already; set here, before anything initialises HIP, for a
+# launcher that does not pass the environment on.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 MALL_GATHER_PEAK_GBS = 8600.0  # measured Infinity-Cache random-row gather ceiling, same guide ("Indexed rows: gather into LDS")

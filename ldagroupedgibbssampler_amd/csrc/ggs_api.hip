@@ -101,6 +101,7 @@ struct ggs_handle {
   hipStream_t side = nullptr;
   hipStream_t side_hot = nullptr;                      // z_hot_kernel runs here, beside z_sliced_kernel on the main stream
   hipEvent_t ev_hot_fork = nullptr, ev_hot_join = nullptr;
+  hipEvent_t ev_theta_tail = nullptr;                  // GGS_DEBUG_THETA_TAIL_PCT (timing experiment), created on first use
   // Whole sweeps on one GPU (ggs_sweep, K <= 160): the next theta is the LONGER of the two legs behind the z step (0.61 ms
   // against 0.50 for the counts and the Phi chain), and a dependency across streams takes 10-25 us to resolve -- so the
   // long leg stays on the handle's stream, directly between two z steps, and the short one (count rebuild + Phi chain)
@@ -1088,10 +1089,9 @@ int z_phase(ggs_handle *h) {
     // step as always?  Drawn from the z the cold kernel is still writing -- the real thing needs the z step cut into two
     // document parts whose first is complete by then.  DESIGN.md section 5 has the numbers.
     static const int theta_tail_pct = debug_env("GGS_DEBUG_THETA_TAIL_PCT") ? std::max(0, std::min(100, std::atoi(debug_env("GGS_DEBUG_THETA_TAIL_PCT")))) : 0;
-    static hipEvent_t ev_theta_tail = nullptr;
     int64_t d_tail = 0;
     if (theta_tail_pct && ahead && !early && !h->xg && h->z_sliced && h->z_split && h->chain_on_side && h->side_hot) {
-      if (!ev_theta_tail) HIP_TRY(h, hipEventCreateWithFlags(&ev_theta_tail, hipEventDisableTiming));
+      if (!h->ev_theta_tail) HIP_TRY(h, hipEventCreateWithFlags(&h->ev_theta_tail, hipEventDisableTiming));
       d_tail = h->D * theta_tail_pct / 100;
       // GGS_DEBUG_THETA_TAIL_STREAM=1: on a stream of its own behind the table kernels (the count + Phi chain, which runs on
       // their stream, then starts when the cold kernel ends and not behind this draw)
@@ -1099,7 +1099,7 @@ int z_phase(ggs_handle *h) {
       hipStream_t tail_on = own ? h->side : h->side_hot;
       if (own) HIP_TRY(h, hipStreamWaitEvent(h->side, h->ev_hot_join, 0));
       if ((rc = launch_theta(h, tail_on, h->d_theta_next, h->iteration + 1, 0, d_tail, h->theta_lds_main, h->theta_b_main))) return rc;
-      HIP_TRY(h, hipEventRecord(ev_theta_tail, tail_on));
+      HIP_TRY(h, hipEventRecord(h->ev_theta_tail, tail_on));
     }
     if (ahead && !early) {
       // theta of iteration t+1 from the z just drawn, concurrent with the counts and the Phi draw
@@ -1110,7 +1110,7 @@ int z_phase(ggs_handle *h) {
       N.theta_on_main = h->chain_on_side;
       if (!h->chain_on_side) HIP_TRY(h, hipEventRecord(N.th0, ts));
       if ((rc = launch_theta(h, ts, h->d_theta_next, h->iteration + 1, d_tail, -1, h->chain_on_side ? h->theta_lds_main : 0, h->chain_on_side ? h->theta_b_main : 0))) return rc;
-      if (d_tail) HIP_TRY(h, hipStreamWaitEvent(ts, ev_theta_tail, 0));
+      if (d_tail) HIP_TRY(h, hipStreamWaitEvent(ts, h->ev_theta_tail, 0));
       HIP_TRY(h, hipEventRecord(N.th1, ts));
       h->theta_ahead_iter = (int64_t)h->iteration + 1;
     }
@@ -1603,6 +1603,7 @@ void ggs_destroy(ggs_handle *h) {
   exchange_free(h->xg);
   if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
   if (h->comm_stream) (void)hipStreamDestroy(h->comm_stream);
+  if (h->ev_theta_tail) (void)hipEventDestroy(h->ev_theta_tail);
   if (h->ev_half_drawn) (void)hipEventDestroy(h->ev_half_drawn);
   if (h->ev_half_gathered) (void)hipEventDestroy(h->ev_half_gathered);
   for (auto &e : h->ev_part)
